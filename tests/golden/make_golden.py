@@ -1,0 +1,250 @@
+#!/opt/conda/bin/python3.9
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (pybader v0.3.12).
+
+Runs ONLY in the build container (needs /root/reference and the conda python3.9 + numba 0.54.1):
+
+    /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py [case ...]
+
+Nothing of the reference is copied: this script drives the reference's own functions
+(`Bader.volumes_init/bader_calc/refine_volumes/...`, `refinement.edge_find/neargrid/edge_check`)
+on synthetic densities from pybader_amd/synth.py and stores inputs' parameters + outputs as
+compressed .npz files (data only).  The numba import shim is the one documented in SURVEY.md A.2.
+"""
+import hashlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference')
+
+# ---- environment the reference needs -------------------------------
+SCRATCH = tempfile.mkdtemp(prefix='golden_')
+os.makedirs(os.path.join(SCRATCH, '.config', 'bader'))
+with open(os.path.join(SCRATCH, '.config', 'bader', 'config.ini'), 'w') as f:
+    f.write("[DEFAULT]\nmethod = neargrid\nrefine_method = neargrid\nvacuum_tol = None\n"
+            "refine_mode = ('changed', 2)\nbader_volume_tol = 0.001\nexport_mode = None\nprefix = ''\n"
+            "output = pickle\nthreads = 1\nfortran_format = 0\nspeed_flag = False\nspin_flag = False\n\n"
+            "[speed]\nmethod = ongrid\nrefine_method = neargrid\nrefine_mode = ('changed', 3)\nspeed_flag = True\n")
+os.environ['HOME'] = SCRATCH
+os.environ.setdefault('NUMBA_CACHE_DIR', '/tmp/golden_nbcache')
+sys.dont_write_bytecode = True
+
+# ---- numba 0.54.1 vs numpy 1.26 import shim ------------------------
+m = types.ModuleType('numba.np.ufunc._internal')
+m.PyUFunc_None, m.PyUFunc_Zero, m.PyUFunc_One, m.PyUFunc_ReorderableNone = -1, 0, 1, -2
+m._DUFunc = type('_DUFunc', (), {})
+m.fromfunc = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+sys.modules['numba.np.ufunc._internal'] = m
+np.MachAr = type('MachAr', (), {})
+_v = np.__version__
+np.__version__ = '1.20.3'
+import numba  # noqa: E402
+np.__version__ = _v
+
+from pybader import refinement, thread_handlers  # noqa: E402
+from pybader.interface import Bader  # noqa: E402
+from pybader.utils import nostdout  # noqa: E402
+
+from pybader_amd import synth  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_bader(rho, lattice, atoms_cart, **kw):
+    info = {'filename': 'synth', 'prefix': '', 'file_type': 'synthetic', 'write_function': None,
+            'voxel_offset': np.zeros(3), 'out_dest': os.devnull}
+    return Bader({'charge': rho}, lattice, atoms_cart, info, threads=1, **kw)
+
+
+def ref_refine_logged(b, volumes, mode):
+    """thread_handlers.refine (thread_handlers.py:128-236) for threads=1, restated as direct calls of
+    the reference kernels so the per-iteration (edges, changed) counts and `known` can be captured."""
+    rho, dm, tg = b.reference, b.distance_matrix, b.T_grad
+    check_mode, iters = mode
+    idx = np.zeros(3, np.int64)
+    log = []
+    known = np.zeros(rho.shape, dtype=np.int8)
+    edges = refinement.edge_find(known, rho, volumes)
+    known0 = known.copy()
+    if edges == 0 or iters == 0:
+        return log, known0, known
+    known, changed = refinement.neargrid(known, known.copy(), rho, volumes, idx, dm, tg, np.zeros(1, np.int64))
+    log.append((edges, changed))
+    if iters < 0:
+        iters = float('inf')
+    it = 2
+    while it <= iters:
+        if check_mode == 'all':
+            known = np.zeros(rho.shape, dtype=np.int8)
+            edges = refinement.edge_find(known, rho, volumes)
+        else:
+            _, edges = refinement.edge_check(known, rho, volumes)
+        known, changed = refinement.neargrid(known, known.copy(), rho, volumes, idx, dm, tg, np.zeros(1, np.int64))
+        log.append((edges, changed))
+        if changed == 0:
+            break
+        it += 1
+    return log, known0, known
+
+
+def own_trajectory(b, main):
+    """Map F from the reference's own refinement kernel."""
+    v = main.copy()
+    known = np.where(v == -1, 0, -2).astype(np.int8)
+    refinement.neargrid(known, np.zeros_like(known), b.reference, v, np.zeros(3, np.int64),
+                        b.distance_matrix, b.T_grad, np.zeros(1, np.int64))
+    return v
+
+
+def run_case(name, shape, lattice, atoms=synth.ATOMS8, vacuum_tol=None, full_maps=True, do_F=True,
+             modes=(('changed', 2), ('changed', -1), ('all', -1), ('all', 2))):
+    t0 = time.time()
+    lattice = np.asarray(lattice, np.float64)
+    rho = synth.synth_density(shape, lattice, atoms)
+    atoms_cart = synth.atoms_cartesian(atoms, lattice)
+    out = {'shape': np.array(shape, np.int64), 'lattice': lattice, 'atoms': np.asarray(atoms, np.float64),
+           'background': np.float64(synth.BACKGROUND), 'rho_sha256': np.array(sha(rho)),
+           'vacuum_tol': np.float64(np.nan if vacuum_tol is None else vacuum_tol)}
+
+    def keep(key, a):
+        a = np.ascontiguousarray(a)
+        out[key + '_sha256'] = np.array(sha(a))
+        if full_maps or a.size < 100000:
+            out[key] = a
+
+    with nostdout():
+        # ---------------- neargrid, default profile ----------------
+        b = make_bader(rho, lattice, atoms_cart, vacuum_tol=vacuum_tol)
+        out['dist_mat'] = b.distance_matrix
+        out['T_grad'] = b.T_grad
+        out['voxel_volume'] = np.float64(b.voxel_volume)
+        b.volumes_init()
+        out['vacuum_charge'] = np.float64(b.vacuum_charge)
+        out['vacuum_volume'] = np.float64(b.vacuum_volume)
+        keep('ng_init', b.bader_volumes.astype(np.int8))
+        b.bader_calc()
+        main = b.bader_volumes.copy()
+        keep('ng_main', main)
+        ng_max = np.rint(b.bader_maxima_fractional * np.array(shape)).astype(np.int64)
+        out['ng_bader_max'] = ng_max
+        if do_F:
+            keep('ng_F', own_trajectory(b, main))
+        first = True
+        for mode in modes:
+            tag = f"ng_{mode[0]}_{'inf' if mode[1] < 0 else mode[1]}"
+            v = main.copy()
+            log, known0, known_last = ref_refine_logged(b, v, mode)
+            v2 = main.copy()
+            thread_handlers.refine('neargrid', mode, b.reference, v2, b.distance_matrix, b.T_grad, 1)
+            assert np.array_equal(v, v2), "restated refine driver != thread_handlers.refine"
+            keep(tag, v)
+            out[tag + '_log'] = np.array(log, np.int64).reshape(-1, 2)
+            if first:
+                keep('ng_known0', known0)
+                first = False
+            if mode == ('changed', 2):
+                keep('ng_changed_2_known_last', known_last)
+        # the rest of Bader.__call__ on the default ('changed', 2) result (interface.py:408-416)
+        b.refine_mode = ('changed', 2)
+        b.refine_volumes(b.bader_volumes)
+        b.sum_volumes(bader=True)
+        b.bader_to_atom_distance()
+        b.min_surface_distance()
+        b.sum_volumes()
+        out['ng_bader_charge'] = b.bader_charge
+        out['ng_bader_volume'] = b.bader_volume
+        out['ng_bader_atoms'] = b.bader_atoms
+        out['ng_bader_distance'] = b.bader_distance
+        keep('ng_atoms_volumes', b.atoms_volumes)
+        out['ng_atoms_charge'] = b.atoms_charge
+        out['ng_atoms_volume'] = b.atoms_volume
+        out['ng_atoms_surface_distance'] = b.atoms_surface_distance
+        out['bader_maxima_cart'] = b.bader_maxima
+
+        # ---------------- ongrid main pass, then the `speed` profile flow ----------------
+        b = make_bader(rho, lattice, atoms_cart, vacuum_tol=vacuum_tol, method='ongrid')
+        b.volumes_init()
+        b.bader_calc()
+        og_main = b.bader_volumes.copy()
+        keep('og_main', og_main)
+        out['og_bader_max'] = np.rint(b.bader_maxima_fractional * np.array(shape)).astype(np.int64)
+        # BASELINE config 5: ongrid assign + neargrid edge refinement on the Bader volumes
+        v = og_main.copy()
+        log, _, _ = ref_refine_logged(b, v, ('changed', 2))
+        keep('og_ngrefine_changed_2', v)
+        out['og_ngrefine_changed_2_log'] = np.array(log, np.int64).reshape(-1, 2)
+        # speed profile (entry_points.py:340-345): refine the *atom* map with ('changed', 3)
+        b.bader_to_atom_distance()
+        out['og_bader_atoms'] = b.bader_atoms
+        out['og_bader_distance'] = b.bader_distance
+        keep('og_atoms_volumes_pre', b.atoms_volumes.copy())
+        b.refine_mode = ('changed', 3)
+        b.refine_volumes(b.atoms_volumes)
+        keep('og_atoms_volumes_speed', b.atoms_volumes)
+        b.sum_volumes()
+        out['og_atoms_charge_speed'] = b.atoms_charge
+        out['og_atoms_volume_speed'] = b.atoms_volume
+
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB; "
+          f"ng maxima {ng_max.shape[0]}, og maxima {out['og_bader_max'].shape[0]}, "
+          f"logs " + json.dumps({k: out[k].tolist() for k in out if k.endswith('_log')}), flush=True)
+
+
+def tables():
+    """Small pure-function tables: dtype_calc, factor_3d, distance_matrix / T_grad for 3 lattices."""
+    from pybader.utils import dtype_calc, factor_3d
+    out = {}
+    vals = [0, 1, 127, 128, 255, 256, 32767, 32768, 65535, 65536, 2**31 - 1, 2**31, 2**32 - 1, 2**32]
+    args = [s * v for v in vals for s in (1, -1)]
+    out['dtype_calc_args'] = np.array(args, dtype=np.float64)
+    out['dtype_calc_out'] = np.array([dtype_calc(int(a)) for a in args])
+    out['factor_3d'] = np.array([factor_3d(i) for i in range(1, 65)], np.int64)
+    lats = [synth.CUBIC6, synth.TRICLINIC, np.array([[4.1, 0.2, -0.3], [0.0, 7.7, 1.9], [-2.2, 0.4, 5.3]])]
+    shapes = [(64, 64, 64), (40, 48, 56), (24, 36, 30)]
+    for k, (lat, shp) in enumerate(zip(lats, shapes)):
+        b = make_bader(np.ones(shp), np.asarray(lat, np.float64), np.zeros((1, 3)))
+        out[f'lat{k}'] = np.asarray(lat, np.float64)
+        out[f'shape{k}'] = np.array(shp, np.int64)
+        out[f'dist_mat{k}'] = b.distance_matrix
+        out[f'T_grad{k}'] = b.T_grad
+        out[f'voxel_volume{k}'] = np.float64(b.voxel_volume)
+    np.savez_compressed(os.path.join(HERE, 'tables.npz'), **out)
+    print('tables done', flush=True)
+
+
+CASES = {
+    # G6: tiny hand-checkable
+    'c12_cubic': dict(shape=(12, 12, 12), lattice=synth.CUBIC6),
+    # G1: 64^3 cubic + one ragged triclinic grid
+    'c64_cubic': dict(shape=(64, 64, 64), lattice=synth.CUBIC6),
+    'c40x48x56_tric': dict(shape=(40, 48, 56), lattice=synth.TRICLINIC),
+    # G3: vacuum (tolerance chosen so ~1/3 of the cell is vacuum for these atoms)
+    'c48_cubic_vac': dict(shape=(48, 48, 48), lattice=synth.CUBIC6, vacuum_tol=0.03),
+    # G4: larger grids, hashes only
+    'c128_tric': dict(shape=(128, 128, 128), lattice=synth.TRICLINIC, full_maps=False,
+                      modes=(('changed', 2), ('all', -1))),
+    'c256_cubic': dict(shape=(256, 256, 256), lattice=synth.CUBIC6, full_maps=False, do_F=True,
+                       modes=(('changed', 2),)),
+}
+
+if __name__ == '__main__':
+    # warm the JIT on a tiny grid first
+    which = sys.argv[1:] or ['tables'] + list(CASES)
+    for name in which:
+        if name == 'tables':
+            tables()
+        else:
+            run_case(name, **CASES[name])
