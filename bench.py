@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json: Mvoxels/s of neargrid assign + edge refinement
+on a synthetic 512^3 grid (BASELINE config 3), data resident in HBM, on N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--method neargrid]
+                    [--refine changed:2] [--cpu-size 160] [--no-cpu]
+
+A "step" is one full pass of the hot path over the grid: volumes_init (label reset) -> bader_calc
+-> refine, exactly the call sequence of Bader.__call__ (interface.py:406-409).  N > 1 is launched
+by torch.distributed.run (one rank per GPU); the grid is cut into axis-0 slabs (strong scaling:
+the 512^3 grid is fixed, north_star: ">= 6x at 8 GPUs").  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_ASSIGN = 12              # read rho f64 once + write int32 label once
+BYTES_PATH = 25                # assign 12 + first refine sweep 13 (rho 8 + label 4 + known 1)
+
+
+def cpu_baseline(size, method, mode, iters, lattice, atoms, background):
+    """The CPU oracle (a faithful sequential port of the reference's threads=1 path) timed on this
+    host, on a bounded sample: the same atoms on a size^3 grid.  Reported, never the target."""
+    import oracle
+    from pybader_amd.interface import distance_matrix, gradient_transform
+    shape = (size,) * 3
+    rho = oracle.synth_density(shape, lattice, atoms, background)
+    vl = np.divide(lattice, shape)
+    dm, tg = distance_matrix(vl), gradient_transform(vl)
+    vol = np.zeros(shape, np.int32)
+    t0 = time.perf_counter()
+    vol, _, _ = oracle.vacuum_assign(rho, vol, float('nan'), rho, 1.0)
+    bmax, main = oracle.bader_calc(method, rho, vol, dm, tg, 1)
+    t1 = time.perf_counter()
+    oracle.refine('neargrid', (mode, iters), rho, main, dm, tg, 1)
+    t2 = time.perf_counter()
+    n = float(size) ** 3
+    return {'value': n / (t2 - t0) / 1e6, 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{size}^3 grid, same 8 atoms/cell, {method} assign + refine ({mode},{iters}), '
+                      f'assign {t1 - t0:.2f}s + refine {t2 - t1:.2f}s, single thread C port of the numba path',
+            'assign_mvox_s': n / (t1 - t0) / 1e6}, (rho, dm, tg, main, bmax)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--method', default='neargrid', choices=['neargrid', 'ongrid'])
+    ap.add_argument('--refine', default='changed:2')
+    ap.add_argument('--cpu-size', type=int, default=160)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--halo', type=int, default=8)
+    args = ap.parse_args()
+    mode, iters = args.refine.split(':')
+    iters = int(iters)
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+        args.gpus = world
+
+    from pybader_amd import _lib, slab, synth
+    from pybader_amd.interface import distance_matrix, gradient_transform
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        comm = slab.TorchComm(dist)
+    else:
+        class _Solo:
+            rank, size = 0, 1
+            def barrier(self):
+                pass
+        comm = _Solo()
+
+    shape = (args.size,) * 3
+    lattice, atoms, background = synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND
+    vl = np.divide(lattice, shape)
+    dm, tg = distance_matrix(vl), gradient_transform(vl)
+    voxel_volume = abs(np.linalg.det(lattice)) / float(np.prod(shape))
+
+    ctx = _lib.Context(local_rank if world > 1 else 0)
+    runner = slab.SlabRunner(slab.GpuBackend(ctx, local_rank), comm, shape, dm, tg, halo=args.halo)
+    ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
+    ctx.enable_timing(True)
+
+    def step():
+        ctx.vacuum_assign(None, voxel_volume)           # Bader.volumes_init: labels := 0 (no vacuum)
+        n = runner.assign(args.method)                  # Bader.bader_calc
+        log = runner.refine(mode, iters)                # Bader.refine_volumes
+        return n, log
+
+    def fence():
+        ctx.sync()
+        comm.barrier()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_time_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_basins, log = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    nvox = float(np.prod(shape))
+    ms_per_step = dt / args.steps * 1e3
+    which = 0 if args.method == 'neargrid' else 1
+    k_ms, k_n = ctx.kernel_time(which)
+    ef_ms, ef_n = ctx.kernel_time(2)
+    rt_ms, rt_n = ctx.kernel_time(3)
+    own_vox = nvox * (runner.x_range[1] - runner.x_range[0]) / shape[0]
+    k_avg = k_ms / max(k_n, 1)
+    achieved = BYTES_ASSIGN * own_vox / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
+
+    out = {
+        'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',
+        'value': nvox / (dt / args.steps) / 1e6,
+        'unit': 'Mvoxels/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': f'{args.size}^3 synthetic 8-Gaussian-atom cubic cell (BASELINE config 3), '
+                               f'{args.method} assign + neargrid edge refinement {mode}:{iters}, '
+                               'density resident in HBM',
+                   'grid': list(shape), 'method': args.method, 'refine_mode': [mode, iters],
+                   'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}',
+                   'basins': int(n_basins), 'refine_log': log},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_ng_trace' if which == 0 else 'k_og_pointer',
+                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'algorithmic_bytes_per_voxel': BYTES_ASSIGN, 'kernel_ms_avg': k_avg, 'launches': int(k_n),
+                     'whole_path': {'bytes_per_voxel': BYTES_PATH,
+                                    'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
+                                    'frac': BYTES_PATH * nvox / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                     'other_kernels_ms_avg': {'edge_find': ef_ms / max(ef_n, 1), 'refine_trace': rt_ms / max(rt_n, 1)}},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cb, (rho_s, dm_s, tg_s, want, bmax) = cpu_baseline(args.cpu_size, args.method, mode, iters,
+                                                           lattice, atoms, background)
+        # the same sample through the GPU path doubles as an end-of-run parity check
+        c2 = _lib.Context(0)
+        c2.set_grid(rho_s.shape, dm_s, tg_s)
+        c2.upload_density(rho_s)
+        c2.vacuum_assign(None, 1.0)
+        c2.assign(args.method)
+        c2.refine(mode, iters)
+        got = c2.download_labels(want.dtype)
+        cb['gpu_map_equals_cpu_map'] = bool(np.array_equal(got, want) and np.array_equal(c2.maxima(), bmax))
+        c2.close()
+        out['cpu_baseline'] = cb
+    elif rank == 0:
+        out['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,132 @@
+/*
+ * bader_hip.h -- C ABI of libbader_hip.so, the MI355X (gfx950) replacement for the hot path of
+ * pybader v0.3.12: neargrid / ongrid steepest-ascent voxel->maximum assignment and the
+ * edge-refinement sweep (pybader/methods.py, refinement.py, thread_handlers.py, the njit half of
+ * utils.py).  Plain C types only; every function returns 0 on success or a negative XB_E_* code
+ * with a message available from xb_last_error().  No C++ exception crosses this boundary.
+ *
+ * Data layout (the reference's, io/vasp.py:102-103): every grid array is C-order [x][y][z],
+ * z fastest.  Density is float64; working labels ("volumes") are int32 on the device; `known`
+ * edge flags are int8.  Host buffers are caller-owned numpy arrays; device buffers belong to the
+ * context.  Label sentinels: -1 vacuum (utils.py:396-397), >=0 basin number after assignment.
+ *
+ * Each entry point cites the reference interface it replaces (file:line into pybader/).
+ */
+#ifndef BADER_HIP_H
+#define BADER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xb_ctx xb_ctx;
+
+enum { XB_OK = 0, XB_E_ARG = -1, XB_E_HIP = -2, XB_E_STATE = -3, XB_E_LIMIT = -4, XB_E_COMM = -5 };
+
+/* label dtype codes accepted at the boundary: the reference narrows/widens labels between
+ * int8/16/32/64 (utils.py:15-37 dtype_calc, jits.py:22-38 dtype matrix) */
+enum { XB_I8 = 1, XB_I16 = 2, XB_I32 = 4, XB_I64 = 8 };
+
+/* methods.__contains__ (methods.py:12) */
+enum { XB_METHOD_ONGRID = 0, XB_METHOD_NEARGRID = 1 };
+/* refine_mode[0] (thread_handlers.py:144, 201-205) */
+enum { XB_REFINE_ALL = 0, XB_REFINE_CHANGED = 1 };
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char *xb_last_error(void);
+int xb_device_count(void);                       /* number of visible HIP devices (0 = none) */
+int xb_create(int device, xb_ctx **out);         /* one context per GPU; owns a stream + buffers */
+void xb_destroy(xb_ctx *c);
+int xb_sync(xb_ctx *c);                          /* hipStreamSynchronize on the context's stream */
+void *xb_stream(xb_ctx *c);                      /* the hipStream_t every kernel is launched on */
+
+/* ---- grid residency ---------------------------------------------------------------------- */
+/* Declares the grid and the two small matrices the reference computes on the host with numpy and
+ * passes to every kernel (Bader.distance_matrix interface.py:242-259, Bader.T_grad 285-290):
+ * dist_mat[27] row-major [3][3][3] with index 2 == -1; T_grad[9] row-major.  Allocates/reuses
+ * device buffers.  x-slab [x0,x1) is the range of axis-0 planes this context owns (multi-GPU
+ * slab scheduler; x0=0,x1=nx for one GPU).  Every rank holds the full density. */
+int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], const double T_grad[9],
+                int64_t x0, int64_t x1);
+int xb_upload_density(xb_ctx *c, const double *rho_host);           /* H2D, nx*ny*nz float64 */
+/* workload generator, bit-identical to pybader_amd/synth.py (bench + tests; not in the reference) */
+int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, int64_t n_atoms,
+                     double background);
+int xb_download_density(xb_ctx *c, double *rho_host);
+/* labels: host <-> device with widening/narrowing on the device (utils.dtype_change, utils.py:255-259) */
+int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype);
+int xb_download_labels(xb_ctx *c, void *labels_host, int dtype);
+int xb_upload_known(xb_ctx *c, const int8_t *known_host);
+int xb_download_known(xb_ctx *c, int8_t *known_host);
+
+/* ---- hot path, device resident ----------------------------------------------------------- */
+/* utils.vacuum_assign (utils.py:382-401) via Bader.volumes_init (interface.py:449-469):
+ * labels := 0, then -1 where rho <= vac_tol (vac_tol NaN => no vacuum, the vacuum_tol=None case).
+ * Returns the vacuum charge (sum(rho)*voxel_volume) and volume. */
+int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume);
+
+/* thread_handlers.bader_calc (thread_handlers.py:15-75) with methods.neargrid (methods.py:222-611)
+ * or methods.ongrid (methods.py:15-219): labels (0 / -1 on entry) become 0-based basin numbers,
+ * numbered by the smallest C-order voxel index of each basin (the order the reference's scan
+ * discovers maxima).  neargrid computes every voxel's own dr=0 trajectory -- the order-independent
+ * map the reference's refinement converges to.
+ * n_maxima: number of basins.  With several slabs the numbering is completed by
+ * xb_assign_finish after the per-rank maxima tables were merged. */
+int xb_assign(xb_ctx *c, int method, int64_t *n_maxima);
+/* bader_max of thread_handlers.py:75: voxel indices int64[n][3] in label order */
+int xb_get_maxima(xb_ctx *c, int64_t *maxima_out, int64_t capacity);
+
+/* slab scheduler pieces of xb_assign (multi-GPU): phase 1 traces the owned slab and returns the
+ * local table (maximum voxel index, smallest owned voxel index reaching it); the host merges the
+ * tables of all ranks (min over ranks), sorts, and hands the global table back to phase 2. */
+int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local);
+int xb_assign_local_table(xb_ctx *c, int64_t *max_idx, int64_t *first_idx, int64_t capacity);
+int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global);
+
+/* refinement.edge_find (refinement.py:326-405) on a fresh `known`: -2 edge, -1 within the 27-box
+ * of an edge, 2 other non-vacuum, 0 untouched vacuum.  Returns the edge count of the owned slab. */
+int xb_edge_find(xb_ctx *c, int64_t *edges);
+/* refinement.neargrid (refinement.py:17-322): retrace every known==-2 voxel of the owned slab
+ * until a known==2 voxel or a maximum; relabel the start voxel if the label differs.
+ * escaped: traces that left the valid x-range [x0-halo, x1+halo) (slabs only; 0 on one GPU). */
+int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped);
+/* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels) */
+int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
+/* thread_handlers.refine (thread_handlers.py:128-236): the iteration driver on one GPU.
+ * iters < 0 => until nothing changes.  log[2*k] = edges, log[2*k+1] = changed of iteration k+1. */
+int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters);
+
+/* utils.charge_sum (utils.py:235-252) via Bader.sum_volumes (interface.py:492-525) */
+int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *charge, double *volume);
+/* utils.volume_assign (utils.py:404-421): labels[v] = swap[labels[v]] for labels >= 0 */
+int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap);
+/* utils.atom_assign (utils.py:185-232): host-side nearest atom over the 27 periodic images */
+int xb_atom_assign(const double *bader_max_cart, int64_t n_max, const double *atoms_cart, int64_t n_atoms,
+                   const double lattice[9], int64_t *atom_out, double *dist_out);
+
+/* ---- slab halo planes (multi-GPU) -------------------------------------------------------- */
+/* Device pointers of the label / known arrays and the plane size in elements, so that the slab
+ * scheduler can hand plane ranges to RCCL (ncclSend/ncclRecv) or any other transport. */
+void *xb_labels_ptr(xb_ctx *c);
+void *xb_known_ptr(xb_ctx *c);
+void *xb_density_ptr(xb_ctx *c);
+int64_t xb_plane_elems(xb_ctx *c);
+/* copy whole x-planes [xa,xb) of labels/known between host and device (halo transport over the
+ * host / gloo; the RCCL transport works on the device pointers above) */
+int xb_copy_planes(xb_ctx *c, int which /*0 labels,1 known*/, int to_device, void *host, int64_t xa, int64_t xb);
+int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that hold valid neighbour data */
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* HIP-event timing of the dominant kernel, measured on the context's stream: accumulated
+ * milliseconds and launch count since the last reset.  which: 0 neargrid trace, 1 ongrid pointer,
+ * 2 edge_find, 3 refine trace. */
+int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
+int xb_kernel_time_reset(xb_ctx *c);
+int xb_enable_timing(xb_ctx *c, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BADER_HIP_H */

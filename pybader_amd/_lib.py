@@ -1,0 +1,269 @@
+"""ctypes binding of libbader_hip.so (include/bader_hip.h).  No PyTorch, no CPU fallback: if the
+library or a GPU is missing, every entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libbader_hip.so')
+
+METHODS = {'ongrid': 0, 'neargrid': 1}          # methods.__contains__ (methods.py:12)
+REFINE_MODES = {'all': 0, 'changed': 1}         # refine_mode[0] (thread_handlers.py:201-205)
+DTYPE_CODE = {np.dtype(np.int8): 1, np.dtype(np.int16): 2, np.dtype(np.int32): 4, np.dtype(np.int64): 8}
+
+# every symbol include/bader_hip.h declares: (restype, argtypes)
+_vp, _i64, _dbl, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
+_pi64, _pdbl = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+SYMBOLS = {
+    'xb_last_error': (C.c_char_p, []),
+    'xb_device_count': (_int, []),
+    'xb_create': (_int, [_int, C.POINTER(_vp)]),
+    'xb_destroy': (None, [_vp]),
+    'xb_sync': (_int, [_vp]),
+    'xb_stream': (_vp, [_vp]),
+    'xb_set_grid': (_int, [_vp, _pi64, _pdbl, _pdbl, _i64, _i64]),
+    'xb_upload_density': (_int, [_vp, _vp]),
+    'xb_synth_density': (_int, [_vp, _pdbl, _pdbl, _i64, _dbl]),
+    'xb_download_density': (_int, [_vp, _vp]),
+    'xb_upload_labels': (_int, [_vp, _vp, _int]),
+    'xb_download_labels': (_int, [_vp, _vp, _int]),
+    'xb_upload_known': (_int, [_vp, _vp]),
+    'xb_download_known': (_int, [_vp, _vp]),
+    'xb_vacuum_assign': (_int, [_vp, _dbl, _dbl, _pdbl, _pdbl]),
+    'xb_assign': (_int, [_vp, _int, _pi64]),
+    'xb_get_maxima': (_int, [_vp, _vp, _i64]),
+    'xb_assign_trace': (_int, [_vp, _int, _pi64]),
+    'xb_assign_local_table': (_int, [_vp, _vp, _vp, _i64]),
+    'xb_assign_finish': (_int, [_vp, _vp, _i64]),
+    'xb_edge_find': (_int, [_vp, _pi64]),
+    'xb_refine_trace': (_int, [_vp, _pi64, _pi64]),
+    'xb_edge_check': (_int, [_vp, _pi64, _pi64]),
+    'xb_refine': (_int, [_vp, _int, _i64, _vp, _i64, _pi64]),
+    'xb_charge_sum': (_int, [_vp, _dbl, _i64, _vp, _vp]),
+    'xb_volume_assign': (_int, [_vp, _vp, _i64]),
+    'xb_atom_assign': (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'xb_labels_ptr': (_vp, [_vp]),
+    'xb_known_ptr': (_vp, [_vp]),
+    'xb_density_ptr': (_vp, [_vp]),
+    'xb_plane_elems': (_i64, [_vp]),
+    'xb_copy_planes': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
+    'xb_set_halo': (_int, [_vp, _i64]),
+    'xb_kernel_time': (_int, [_vp, _int, _pdbl, _pi64]),
+    'xb_kernel_time_reset': (_int, [_vp]),
+    'xb_enable_timing': (_int, [_vp, _int]),
+}
+
+_lib = None
+
+
+class BaderHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libbader_hip.so and bind every declared symbol; raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BaderHipError(f"{LIB_PATH} is missing: build it with `python -m pybader_amd.build` "
+                                "(hipcc, gfx950); pybader_amd has no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)      # AttributeError here == ABI drift; fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BaderHipError(f"libbader_hip error {rc}: {load().xb_last_error().decode()}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """One GPU context: device-resident density / labels / known + the hot-path calls."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        n = self.lib.xb_device_count()
+        if n <= 0:
+            raise BaderHipError("no HIP device visible: the MI355X path cannot run (no CPU fallback)")
+        h = C.c_void_p()
+        check(self.lib.xb_create(int(device), C.byref(h)))
+        self.h = h
+        self.shape = None
+        self.n_maxima = 0
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.xb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- residency --------------------------------------------------------------------------
+    def set_grid(self, shape, dist_mat, T_grad, x_range=None):
+        shape = tuple(int(s) for s in shape)
+        x0, x1 = (0, shape[0]) if x_range is None else x_range
+        sh = np.array(shape, dtype=np.int64)
+        dm, tg = _f64(dist_mat).reshape(27), _f64(T_grad).reshape(9)
+        check(self.lib.xb_set_grid(self.h, sh.ctypes.data_as(_pi64), dm.ctypes.data_as(_pdbl),
+                                   tg.ctypes.data_as(_pdbl), int(x0), int(x1)))
+        self.shape = shape
+        self.x_range = (int(x0), int(x1))
+
+    def set_halo(self, halo):
+        check(self.lib.xb_set_halo(self.h, int(halo)))
+
+    def upload_density(self, rho):
+        rho = _f64(rho)
+        assert rho.shape == self.shape, (rho.shape, self.shape)
+        check(self.lib.xb_upload_density(self.h, _ptr(rho)))
+
+    def synth_density(self, lattice, atoms, background):
+        lat, at = _f64(lattice).reshape(9), _f64(atoms)
+        check(self.lib.xb_synth_density(self.h, lat.ctypes.data_as(_pdbl), at.ctypes.data_as(_pdbl),
+                                        at.shape[0], float(background)))
+
+    def download_density(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        check(self.lib.xb_download_density(self.h, _ptr(out)))
+        return out
+
+    def upload_labels(self, labels):
+        labels = np.ascontiguousarray(labels)
+        assert labels.shape == self.shape
+        check(self.lib.xb_upload_labels(self.h, _ptr(labels), DTYPE_CODE[labels.dtype]))
+
+    def download_labels(self, dtype=np.int32, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=dtype)
+        assert out.flags.c_contiguous and out.shape == self.shape
+        check(self.lib.xb_download_labels(self.h, _ptr(out), DTYPE_CODE[out.dtype]))
+        return out
+
+    def upload_known(self, known):
+        known = np.ascontiguousarray(known, dtype=np.int8)
+        check(self.lib.xb_upload_known(self.h, _ptr(known)))
+
+    def download_known(self):
+        out = np.empty(self.shape, dtype=np.int8)
+        check(self.lib.xb_download_known(self.h, _ptr(out)))
+        return out
+
+    # -- hot path ---------------------------------------------------------------------------
+    def vacuum_assign(self, vac_tol, voxel_volume):
+        a, b = C.c_double(), C.c_double()
+        tol = float('nan') if vac_tol is None else float(vac_tol)
+        check(self.lib.xb_vacuum_assign(self.h, tol, float(voxel_volume), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def assign(self, method):
+        n = C.c_int64()
+        check(self.lib.xb_assign(self.h, METHODS[method], C.byref(n)))
+        self.n_maxima = n.value
+        return n.value
+
+    def maxima(self):
+        out = np.zeros((self.n_maxima, 3), dtype=np.int64)
+        check(self.lib.xb_get_maxima(self.h, _ptr(out), self.n_maxima))
+        return out
+
+    def assign_trace(self, method):
+        n = C.c_int64()
+        check(self.lib.xb_assign_trace(self.h, METHODS[method], C.byref(n)))
+        m, f = np.zeros(n.value, np.int64), np.zeros(n.value, np.int64)
+        check(self.lib.xb_assign_local_table(self.h, _ptr(m), _ptr(f), n.value))
+        return m, f
+
+    def assign_finish(self, max_sorted):
+        ms = np.ascontiguousarray(max_sorted, dtype=np.int64)
+        check(self.lib.xb_assign_finish(self.h, _ptr(ms), ms.shape[0]))
+        self.n_maxima = int(ms.shape[0])
+
+    def edge_find(self):
+        n = C.c_int64()
+        check(self.lib.xb_edge_find(self.h, C.byref(n)))
+        return n.value
+
+    def refine_trace(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_refine_trace(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def edge_check(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_edge_check(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def refine(self, mode, iters):
+        cap = 4096
+        log = np.zeros(cap, dtype=np.int64)
+        n = C.c_int64()
+        check(self.lib.xb_refine(self.h, REFINE_MODES[mode.lower()], int(iters), _ptr(log), cap, C.byref(n)))
+        k = min(n.value, cap // 2)
+        return [(int(log[2 * i]), int(log[2 * i + 1])) for i in range(k)]
+
+    def charge_sum(self, voxel_volume, n_labels):
+        ch, vo = np.zeros(n_labels, np.float64), np.zeros(n_labels, np.float64)
+        check(self.lib.xb_charge_sum(self.h, float(voxel_volume), int(n_labels), _ptr(ch), _ptr(vo)))
+        return ch, vo
+
+    def volume_assign(self, swap):
+        sw = np.ascontiguousarray(swap, dtype=np.int64)
+        check(self.lib.xb_volume_assign(self.h, _ptr(sw), sw.shape[0]))
+
+    def copy_planes(self, which, to_device, host, xa, xb):
+        check(self.lib.xb_copy_planes(self.h, int(which), int(to_device), _ptr(host), int(xa), int(xb)))
+
+    # -- measurement ------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        check(self.lib.xb_enable_timing(self.h, int(on)))
+
+    def kernel_time(self, which):
+        ms, n = C.c_double(), C.c_int64()
+        check(self.lib.xb_kernel_time(self.h, int(which), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        check(self.lib.xb_kernel_time_reset(self.h))
+
+    def sync(self):
+        check(self.lib.xb_sync(self.h))
+
+
+def atom_assign(bader_max_cart, atoms_cart, lattice):
+    """utils.atom_assign (utils.py:185-232) through the C ABI (host-side, tiny)."""
+    lib = load()
+    bm, at, lat = _f64(bader_max_cart).reshape(-1, 3), _f64(atoms_cart).reshape(-1, 3), _f64(lattice).reshape(9)
+    a, d = np.zeros(bm.shape[0], np.int64), np.zeros(bm.shape[0], np.float64)
+    check(lib.xb_atom_assign(_ptr(bm), bm.shape[0], _ptr(at), at.shape[0], _ptr(lat), _ptr(a), _ptr(d)))
+    return a, d
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context (one per device), created on first use."""
+    if device is None:
+        device = int(os.environ.get('PYBADER_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        if load().xb_device_count() == 1:
+            device = 0
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,1364 @@
+// bader_hip.hip -- libbader_hip.so: HIP kernels + C ABI (include/bader_hip.h) for gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see pybader_amd/build.py).
+#include "bader_kernels.h"
+#include "../../include/bader_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// =============================================================================================
+// kernels
+// =============================================================================================
+#define TPB 256
+
+template <typename T>
+__global__ void k_fill(T *p, T v, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// Workload generator, bit-identical to pybader_amd/synth.py (IEEE basic ops, fixed order).
+__global__ __launch_bounds__(TPB) void k_synth_density(Grid g, const double *__restrict__ lat,
+                                                       const double *__restrict__ atoms, int n_atoms,
+                                                       double background, double *__restrict__ rho) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v >= N) return;
+    const int i = (int)(v / g.nyz);
+    const int r = (int)(v - (long long)i * g.nyz);
+    const int j = r / g.nz, k = r - j * g.nz;
+    const double f0 = (double)i / (double)g.nx, f1 = (double)j / (double)g.ny, f2 = (double)k / (double)g.nz;
+    double acc = background;
+    for (int a = 0; a < n_atoms; a++) {
+        const double *A = atoms + 5 * a;
+        double d0 = f0 - A[0]; d0 = d0 - rint(d0);
+        double d1 = f1 - A[1]; d1 = d1 - rint(d1);
+        double d2 = f2 - A[2]; d2 = d2 - rint(d2);
+        double r2 = 0.;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const double xm = (d0 * lat[m] + d1 * lat[3 + m]) + d2 * lat[6 + m];
+            const double sq = xm * xm;
+            r2 = (m == 0) ? sq : (r2 + sq);
+        }
+        double t = 1.0 - r2 / ((2048.0 * A[3]) * A[3]);
+        if (!(t > 0.0)) t = 0.0;
+#pragma unroll
+        for (int s = 0; s < 10; s++) t = t * t;
+        acc = acc + A[4] * t;
+    }
+    rho[v] = acc;
+}
+
+// utils.vacuum_assign (utils.py:382-401): labels = -1 where rho <= tol, 0 elsewhere, over the
+// whole grid; charge/volume partial sums over the owned slab only (block reduce + one atomic).
+__global__ __launch_bounds__(TPB) void k_vacuum_assign(Grid g, const double *__restrict__ rho,
+                                                       int *__restrict__ labels, double tol, double *sum_rho,
+                                                       unsigned long long *count) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
+    double s = 0.;
+    unsigned int n = 0;
+    if (v < N) {
+        const double r = rho[v];
+        const bool vac = r <= tol;  // NaN tol (vacuum_tol=None, interface.py:459) => never
+        labels[v] = vac ? -1 : 0;
+        const int x = (int)(v / g.nyz);
+        if (vac && x >= g.x0 && x < g.x1) { s = r; n = 1; }
+    }
+    __shared__ double sh[TPB / XB_WAVE];
+    __shared__ unsigned int shn[TPB / XB_WAVE];
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); n += __shfl_down(n, o); }
+    const int w = threadIdx.x / XB_WAVE, l = threadIdx.x % XB_WAVE;
+    if (l == 0) { sh[w] = s; shn[w] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.;
+        unsigned int m = 0;
+        for (int q = 0; q < TPB / XB_WAVE; q++) { t += sh[q]; m += shn[q]; }
+        if (m) { atomicAdd(sum_rho, t); atomicAdd(count, (unsigned long long)m); }
+    }
+}
+
+// Record a trajectory's maximum `m` for the numbering: first[m] = min owned voxel index reaching m;
+// the thread that lowers first[m] from INT_MAX appends m to the maxima list (exactly one does).
+__device__ __forceinline__ void note_maximum(int m, int v, int *first, int *max_list, int *max_count, int max_cap) {
+    if (__builtin_nontemporal_load(&first[m]) <= v) return;  // already at or below v: nothing to do
+    const int old = atomicMin(&first[m], v);
+    if (old == XB_INT_MAX) {
+        const int k = atomicAdd(max_count, 1);
+        if (k < max_cap) max_list[k] = m;
+    }
+}
+
+// Wave-aggregated note_maximum: lanes are consecutive voxel indices, so per distinct maximum only
+// the lowest lane needs to touch memory.
+__device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *first, int *max_list,
+                                                  int *max_count, int max_cap) {
+    unsigned long long todo = __ballot(has);
+    const int lane = threadIdx.x % XB_WAVE;
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const int lm = __shfl(m, leader);
+        const unsigned long long grp = __ballot(has && m == lm);
+        if (lane == leader) note_maximum(m, v, first, max_list, max_count, max_cap);
+        todo &= ~grp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// neargrid assignment: every owned non-vacuum voxel follows its own dr=0 trajectory
+// (refinement.py:17-322 stepping rules without the early stop) to the maximum it reaches.
+// One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
+// of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const double *__restrict__ rho, int *labels, int *first,
+                                                  int *max_list, int *max_count, int max_cap, int *ovf_list,
+                                                  int *ovf_count, int ovf_cap, int maxsteps) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool valid = vv < vend;
+    const int v = valid ? (int)vv : 0;
+    int mode = TR_DONE, result = -1;
+    int px = 0, py = 0, pz = 0, lp = 0, steps = 0;
+    double c = 0., dr0 = 0., dr1 = 0., dr2 = 0.;
+    PathWindow<K> w;
+    w.init(0, 0.);
+    if (valid && labels[v] != -1) {
+        px = v / g.nyz;
+        const int r = v - px * g.nyz;
+        py = r / g.nz;
+        pz = r - py * g.nz;
+        lp = v;
+        c = rho[v];
+        w.init(v, c);
+        mode = TR_STEP;
+    }
+    for (;;) {
+        if (mode == TR_STEP) {
+            int qx, qy, qz;
+            const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
+            const int lq = lin3(g, qx, qy, qz);
+            if (stay || w.contains(lq)) {
+                mode = TR_NEED_OG;  // refinement.py:200: already been here on this path
+            } else {
+                const double cq = rho[lq];
+                if (cq <= w.m_old || ++steps > maxsteps) {
+                    result = -2;  // membership undecidable from the window: exact slow kernel
+                    mode = TR_DONE;
+                } else {
+                    w.push(lq, cq);
+                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                }
+            }
+        }
+        if (!__any(mode == TR_STEP)) {
+            if (!__any(mode == TR_NEED_OG)) break;
+            if (mode == TR_NEED_OG) {  // refinement.py:201-235: dr = 0, one ongrid step from p
+                int qx, qy, qz;
+                dr0 = dr1 = dr2 = 0.;
+                og_step(rho, g, px, py, pz, c, qx, qy, qz);
+                if (qx == px && qy == py && qz == pz) {
+                    result = lp;  // break_flag: p is the maximum
+                    mode = TR_DONE;
+                } else if (++steps > maxsteps) {
+                    result = -2;
+                    mode = TR_DONE;
+                } else {  // refinement.py:305-315: appended without a membership test
+                    const int lq = lin3(g, qx, qy, qz);
+                    const double cq = rho[lq];
+                    w.push(lq, cq);
+                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                    mode = TR_STEP;
+                }
+            }
+        }
+    }
+    // a maximum that is itself vacuum hands its -1 to the start voxel (refinement.py:286)
+    if (valid && result >= 0 && result != v && labels[result] == -1) result = -1;
+    if (valid) labels[v] = result;
+    note_maximum_wave(valid && result >= 0, result, v, first, max_list, max_count, max_cap);
+    if (valid && result == -2) {
+        const int k = atomicAdd(ovf_count, 1);
+        if (k < ovf_cap) ovf_list[k] = v;
+    }
+}
+
+// Exact slow path for the (rare) trajectories whose path membership could not be decided from the
+// window: the whole path lives in global scratch and is scanned linearly.
+// mode 0: assignment (write maximum index, note it); mode 1: refinement retrace.
+__global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
+                             int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
+                             int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    int *P = path + (size_t)t * lmax;
+    int np = 0;
+    int px = v / g.nyz;
+    int r = v - px * g.nyz;
+    int py = r / g.nz, pz = r - py * g.nz, lp = v;
+    double c = rho[v], dr0 = 0., dr1 = 0., dr2 = 0.;
+    const int vol_num = labels[v];
+    P[np++] = v;
+    int result = -3;
+    for (;;) {
+        int qx, qy, qz;
+        const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
+        int lq = lin3(g, qx, qy, qz);
+        bool on_path = stay;
+        for (int k = np - 1; k >= 0 && !on_path; k--) on_path = (P[k] == lq);
+        if (on_path) {
+            dr0 = dr1 = dr2 = 0.;
+            og_step(rho, g, px, py, pz, c, qx, qy, qz);
+            lq = lin3(g, qx, qy, qz);
+            if (qx == px && qy == py && qz == pz) { result = lp; break; }
+        }
+        if (refine) {
+            if (!plane_valid(g, qx)) { atomicAdd(escaped, 1); return; }
+            if (known_ro[lq] == 2) { result = lq; break; }
+        }
+        if (np >= lmax) { atomicExch(err, 1); return; }
+        P[np++] = lq;
+        px = qx; py = qy; pz = qz; lp = lq; c = rho[lq];
+    }
+    if (refine) {
+        const int nv = labels[result];
+        if (nv != vol_num) { labels[v] = nv; atomicAdd(changed, 1); }
+        else known[v] = -1;
+    } else {
+        if (result != v && labels[result] == -1) result = -1;
+        labels[v] = result;
+        if (result >= 0) note_maximum(result, v, first, max_list, max_count, max_cap);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ongrid assignment (methods.py:15-219).  The ascent is memoryless, so the sequential path
+// compression of the reference equals: best-neighbour pointer per voxel, then pointer jumping.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_og_pointer(Grid g, const double *__restrict__ rho, int *labels) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= N) return;
+    const int v = (int)vv;
+    if (labels[v] == -1) return;  // vacuum stays -1 (methods.py:73-74)
+    const int px = v / g.nyz;
+    const int r = v - px * g.nyz;
+    const int py = r / g.nz, pz = r - py * g.nz;
+    int qx, qy, qz;
+    og_step(rho, g, px, py, pz, rho[v], qx, qy, qz);
+    labels[v] = lin3(g, qx, qy, qz);
+}
+// A chain that steps onto a vacuum voxel inherits -1 (methods.py:166-168).  In-place and
+// asynchronous: any value read is an ancestor of the root, so progress is monotone.
+__global__ __launch_bounds__(TPB) void k_og_jump(Grid g, int *labels, int *not_done) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= N) return;
+    const int v = (int)vv;
+    int p = labels[v];
+    if (p < 0 || p == v) return;
+    int q = labels[p];
+    if (q == p) return;  // parent is a root
+    if (q >= 0) {
+        const int q2 = labels[q];  // two hops per sweep
+        if (q2 >= 0) q = q2;
+        else q = -1;
+    }
+    labels[v] = q;
+    if (q >= 0) *not_done = 1;
+}
+__global__ __launch_bounds__(TPB) void k_note_roots(Grid g, const int *labels, int *first, int *max_list,
+                                                    int *max_count, int max_cap) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool valid = vv < vend;
+    const int v = valid ? (int)vv : 0;
+    const int m = valid ? labels[v] : -1;
+    note_maximum_wave(valid && m >= 0, m, v, first, max_list, max_count, max_cap);
+}
+
+// numbering helpers ---------------------------------------------------------------------------
+__global__ void k_gather_first(const int *first, const int *max_list, int n, int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = first[max_list[i]];
+}
+__global__ void k_set_rank(int *first, const int *max_sorted, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) first[max_sorted[i]] = i;
+}
+__global__ void k_reset_first(int *first, const int *max_list, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) first[max_list[i]] = XB_INT_MAX;
+}
+// labels[v] (maximum index) -> rank stored in first[maximum]
+__global__ __launch_bounds__(TPB) void k_relabel(Grid g, int *labels, const int *__restrict__ rank) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v >= vend) return;
+    const int m = labels[v];
+    if (m >= 0) labels[v] = rank[m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement.edge_find (refinement.py:326-405) on a fresh `known`, as two order-free passes.
+// Pass 1 (planes [x0-1, x1+1)): -2 if a non-vacuum neighbour carries another label and the voxel
+// is not a 26-neighbour density maximum; else 2 (non-vacuum) / 0 (vacuum).
+// Pass 2 (owned planes): voxels >= 0 with an edge in their 27-box become -1 (refinement.py:403-404,
+// which has no vacuum test).  Together these equal the sequential in-place sweep.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void classify27(const Grid &g, const double *__restrict__ rho,
+                                           const int *__restrict__ labels, int x, int y, int z, int v,
+                                           bool &is_edge, bool &is_max) {
+    const int vol_num = labels[v];
+    is_edge = false;
+    is_max = true;
+    int nb[27];
+    int k = 0;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int tz = wrapi(z + iz, g.nz);
+                const int l = lin3(g, tx, ty, tz);
+                const int nv = labels[l];
+                nb[k++] = (nv == -1) ? -1 : l;
+                if (nv != -1 && nv != vol_num) is_edge = true;
+            }
+        }
+    }
+    if (!is_edge) return;  // is_max only matters for edges (refinement.py:376-383)
+    const double max_val = rho[v];
+#pragma unroll
+    for (k = 0; k < 27; k++)
+        if (nb[k] >= 0 && rho[nb[k]] > max_val) is_max = false;
+}
+
+__global__ __launch_bounds__(TPB) void k_edge_flag(Grid g, const double *__restrict__ rho,
+                                                   const int *__restrict__ labels, int8_t *__restrict__ known,
+                                                   int xa, int nplanes, unsigned long long *edges) {
+    // planes xa .. xa+nplanes-1 (modulo nx); edges counted on owned planes only
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    unsigned int cnt = 0;
+    if (vv < (long long)nplanes * g.nyz) {
+        const int xr = (int)(vv / g.nyz);
+        const int r = (int)(vv - (long long)xr * g.nyz);
+        int x = xa + xr;
+        if (x >= g.nx) x -= g.nx;
+        const int y = r / g.nz, z = r - y * g.nz;
+        const int v = lin3(g, x, y, z);
+        int8_t out;
+        if (labels[v] == -1) out = 0;
+        else {
+            bool is_edge, is_max;
+            classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+            out = (is_edge && !is_max) ? -2 : 2;
+            if (out == -2 && x >= g.x0 && x < g.x1) cnt = 1;
+        }
+        known[v] = out;
+    }
+    const unsigned long long b = __ballot(cnt);
+    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(edges, (unsigned long long)__popcll(b));
+}
+
+// known >= 0 with a `flag` voxel in the 27-box -> -1.  Used by edge_find (flag=-2) and edge_check
+// (flag=-3).  Reads test == flag only, writes only turn 0/2 into -1: safe in place.
+__global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int xa, int nplanes, int flag) {
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= (long long)nplanes * g.nyz) return;
+    const int xr = (int)(vv / g.nyz);
+    const int r = (int)(vv - (long long)xr * g.nyz);
+    int x = xa + xr;
+    if (x >= g.nx) x -= g.nx;
+    const int y = r / g.nz, z = r - y * g.nz;
+    const int v = lin3(g, x, y, z);
+    if (known[v] < 0) return;
+    bool near = false;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int tz = wrapi(z + iz, g.nz);
+                near |= (known[lin3(g, tx, ty, tz)] == flag);
+            }
+        }
+    }
+    if (near) known[v] = -1;
+}
+
+// compaction of owned voxels with known == value into a list (order arbitrary)
+__global__ __launch_bounds__(TPB) void k_compact_known(Grid g, const int8_t *__restrict__ known, int value,
+                                                       int *list, int *count, int cap) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool hit = v < vend && known[v] == value;
+    const unsigned long long b = __ballot(hit);
+    if (!b) return;
+    const int lane = threadIdx.x % XB_WAVE;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(b));
+    base = __shfl(base, 0);
+    if (hit) {
+        const int k = base + __popcll(b & ((1ull << lane) - 1ull));
+        if (k < cap) list[k] = (int)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement.neargrid (refinement.py:17-322): retrace the listed edge voxels (known == -2).
+// Traces only read `known` for the == 2 test and `labels` at known==2 voxels / maxima, and only
+// write their own start voxel, so they are independent -- exactly as in the reference, where the
+// +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const double *__restrict__ rho, int *labels,
+                                                      int8_t *known, const int *__restrict__ list, int n,
+                                                      int *changed, int *escaped, int *ovf_list, int *ovf_count,
+                                                      int ovf_cap, int maxsteps) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    const bool valid = t < n;
+    const int v = valid ? list[t] : 0;
+    int mode = TR_DONE, result = -3;  // result: terminal voxel index; -2 overflow; -4 escaped
+    int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
+    double c = 0., dr0 = 0., dr1 = 0., dr2 = 0.;
+    PathWindow<K> w;
+    w.init(0, 0.);
+    if (valid) {
+        px = v / g.nyz;
+        const int r = v - px * g.nyz;
+        py = r / g.nz;
+        pz = r - py * g.nz;
+        lp = v;
+        c = rho[v];
+        vol_num = labels[v];
+        w.init(v, c);
+        mode = TR_STEP;
+    }
+    for (;;) {
+        if (mode == TR_STEP) {
+            int qx, qy, qz;
+            const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
+            const int lq = lin3(g, qx, qy, qz);
+            if (stay || w.contains(lq)) {
+                mode = TR_NEED_OG;
+            } else {
+                const double cq = rho[lq];
+                if (cq <= w.m_old || ++steps > maxsteps) { result = -2; mode = TR_DONE; }
+                else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
+                else if (known[lq] == 2) { result = lq; mode = TR_DONE; }  // refinement.py:294-303
+                else {
+                    w.push(lq, cq);
+                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                }
+            }
+        }
+        if (!__any(mode == TR_STEP)) {
+            if (!__any(mode == TR_NEED_OG)) break;
+            if (mode == TR_NEED_OG) {
+                int qx, qy, qz;
+                dr0 = dr1 = dr2 = 0.;
+                og_step(rho, g, px, py, pz, c, qx, qy, qz);
+                const int lq = lin3(g, qx, qy, qz);
+                if (qx == px && qy == py && qz == pz) { result = lp; mode = TR_DONE; }  // refinement.py:283-292
+                else if (++steps > maxsteps) { result = -2; mode = TR_DONE; }
+                else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
+                else if (known[lq] == 2) { result = lq; mode = TR_DONE; }
+                else {
+                    const double cq = rho[lq];
+                    w.push(lq, cq);
+                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                    mode = TR_STEP;
+                }
+            }
+        }
+    }
+    int ch = 0, es = 0;
+    if (valid) {
+        if (result >= 0) {
+            const int nv = labels[result];
+            if (nv != vol_num) { labels[v] = nv; ch = 1; }  // known stays -2 (refinement.py:288-289)
+            else known[v] = -1;                              // refinement.py:291 (+5 +1 -5)
+        } else if (result == -2) {
+            const int k = atomicAdd(ovf_count, 1);
+            if (k < ovf_cap) ovf_list[k] = v;
+        } else if (result == -4) es = 1;
+    }
+    const unsigned long long bc = __ballot(ch), be = __ballot(es);
+    if (threadIdx.x % XB_WAVE == 0) {
+        if (bc) atomicAdd(changed, __popcll(bc));
+        if (be) atomicAdd(escaped, __popcll(be));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement.edge_check (refinement.py:409-508).  The sequential scan re-classifies the 27-box of
+// every voxel that is still -2 when the scan reaches it; an earlier processed neighbour j < i
+// rewrites i to -1 / -3 unless i is an (edge & maximum) voxel, in which case i is processed too.
+// So the processed set P is the lexicographically-first greedy choice:
+//     i in P  <=>  class(i) == edge&max  or  no j in P with j < i, j in box(i).
+// P is resolved in rounds (a voxel decides once all earlier changed neighbours have decided);
+// the final `known` is then a pure function of P and the static classes.
+// temp codes in `known`: -2 undecided, -4 processed, -5 skipped.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
+                                                   const int *__restrict__ labels, int8_t *known,
+                                                   const int *__restrict__ list, int n, int8_t *st, int *undecided) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n || st[t] != 0) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    bool blocked = false, has_proc = false;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int tz = wrapi(z + iz, g.nz);
+                const int l = lin3(g, tx, ty, tz);
+                if (l < v) {
+                    const int8_t k = __builtin_nontemporal_load(&known[l]);
+                    blocked |= (k == -2);
+                    has_proc |= (k == -4);
+                }
+            }
+        }
+    }
+    if (blocked) { atomicAdd(undecided, 1); return; }
+    bool proc = true;
+    if (has_proc) {
+        bool is_edge, is_max;
+        classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+        // classify27 leaves is_max=true when !is_edge; edge&max is the only class left untouched
+        proc = is_edge && is_max;
+    }
+    st[t] = proc ? 1 : 2;
+    known[v] = proc ? -4 : -5;
+}
+// apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
+__global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
+                                                  const int *__restrict__ labels, int8_t *known,
+                                                  const int *__restrict__ list, int n, const int8_t *st,
+                                                  unsigned long long *checked) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n || st[t] != 1) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    unsigned int nchk = 0;
+    for (int ex = -1; ex < 2; ex++) {
+        const int tx = wrapi(x + ex, g.nx);
+        for (int ey = -1; ey < 2; ey++) {
+            const int ty = wrapi(y + ey, g.ny);
+            for (int ez = -1; ez < 2; ez++) {
+                const int tz = wrapi(z + ez, g.nz);
+                const int l = lin3(g, tx, ty, tz);
+                // NB no vacuum test on the box voxel (bug-compatible)
+                bool is_edge, is_max;
+                classify27(g, rho, labels, tx, ty, tz, l, is_edge, is_max);
+                if (!is_edge) { known[l] = -1; nchk++; }
+                else if (!is_max) known[l] = -3;
+            }
+        }
+    }
+    if (nchk) atomicAdd(checked, (unsigned long long)nchk);
+}
+// restore processed edge&max voxels (untouched by their own box) to -2
+__global__ void k_ec_restore(int8_t *known, const int *list, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int8_t k = known[list[t]];
+    if (k == -4 || k == -5) known[list[t]] = -2;
+}
+// count -3 on owned planes and turn them into -2 (refinement.py:505-507)
+__global__ __launch_bounds__(TPB) void k_ec_finish(Grid g, int8_t *known, int xa, int nplanes,
+                                                   unsigned long long *edges) {
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    unsigned int cnt = 0;
+    if (vv < (long long)nplanes * g.nyz) {
+        const int xr = (int)(vv / g.nyz);
+        int x = xa + xr;
+        if (x >= g.nx) x -= g.nx;
+        const long long v = (long long)x * g.nyz + (vv - (long long)xr * g.nyz);
+        if (known[v] == -3) {
+            known[v] = -2;
+            if (x >= g.x0 && x < g.x1) cnt = 1;
+        }
+    }
+    const unsigned long long b = __ballot(cnt);
+    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(edges, (unsigned long long)__popcll(b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// utils.charge_sum (utils.py:235-252): per-label sums over the owned slab.  LDS-privatised bins
+// per block when the label count is small, global atomics otherwise.
+// ---------------------------------------------------------------------------------------------
+#define CS_BINS 1024
+__global__ __launch_bounds__(TPB) void k_charge_sum_lds(Grid g, const double *__restrict__ rho,
+                                                        const int *__restrict__ labels, int n_labels,
+                                                        double *charge, unsigned long long *count, int per_thread) {
+    __shared__ double sc[CS_BINS];
+    __shared__ unsigned int sn[CS_BINS];
+    for (int i = threadIdx.x; i < n_labels; i += TPB) { sc[i] = 0.; sn[i] = 0; }
+    __syncthreads();
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    long long v = vbeg + (long long)blockIdx.x * TPB * per_thread + threadIdx.x;
+    for (int k = 0; k < per_thread; k++, v += TPB) {
+        if (v < vend) {
+            const int a = labels[v];
+            if (a >= 0 && a < n_labels) { atomicAdd(&sc[a], rho[v]); atomicAdd(&sn[a], 1u); }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_labels; i += TPB)
+        if (sn[i]) { atomicAdd(&charge[i], sc[i]); atomicAdd(&count[i], (unsigned long long)sn[i]); }
+}
+__global__ __launch_bounds__(TPB) void k_charge_sum_glb(Grid g, const double *__restrict__ rho,
+                                                        const int *__restrict__ labels, int n_labels,
+                                                        double *charge, unsigned long long *count) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v >= vend) return;
+    const int a = labels[v];
+    if (a >= 0 && a < n_labels) { atomicAdd(&charge[a], rho[v]); atomicAdd(&count[a], 1ull); }
+}
+
+// utils.volume_assign (utils.py:404-421)
+__global__ __launch_bounds__(TPB) void k_volume_assign(Grid g, int *labels, const int *__restrict__ swap, int n_swap) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v >= vend) return;
+    const int a = labels[v];
+    if (a >= 0 && a < n_swap) labels[v] = swap[a];
+}
+
+// utils.dtype_change (utils.py:255-259): widen / narrow between the boundary dtype and int32
+template <typename T>
+__global__ void k_widen(const T *__restrict__ in, int *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)in[i];
+}
+template <typename T>
+__global__ void k_narrow(const int *__restrict__ in, T *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (T)in[i];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(XB_E_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+    } while (0)
+
+struct TimedKernel {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.;
+    long long launches = 0;
+};
+
+struct xb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Grid g{};
+    bool has_grid = false;
+    long long N = 0;
+    int halo = 0;
+    double *rho = nullptr;
+    int *labels = nullptr;
+    int8_t *known = nullptr;
+    int *first = nullptr;      // n^3: min voxel per maximum, then rank per maximum
+    int *list = nullptr;       // n^3 ints: compaction list (edges / changed voxels)
+    int8_t *st = nullptr;      // per-list-entry status for edge_check
+    void *stage = nullptr;     // staging for dtype conversion (N * 8 bytes max)
+    size_t stage_bytes = 0;
+    int *max_list = nullptr;   // maxima discovered (linear indices)
+    int *max_aux = nullptr;
+    int max_cap = 0;
+    int *ovf_list = nullptr;
+    int ovf_cap = 0;
+    int *counters = nullptr;   // small device scratch: ints
+    unsigned long long *counters64 = nullptr;
+    double *dsum = nullptr;
+    int *host_ints = nullptr;  // pinned
+    std::vector<int> maxima_sorted;  // global, label order
+    std::vector<int> local_max, local_first;
+    bool first_clean = false;
+    bool timing = false;
+    TimedKernel tk[4];
+    long long n_alloc = 0;
+};
+
+static inline unsigned nblocks(long long n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+struct ScopedTimer {
+    xb_ctx *c;
+    int which;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(xb_ctx *c_, int w) : c(c_), which(w) {
+        if (c->timing) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (c->timing) {
+            hipEventRecord(b, c->stream);
+            c->tk[which].pending.push_back({a, b});
+        }
+    }
+};
+
+extern "C" {
+
+const char *xb_last_error(void) { return g_err.c_str(); }
+
+int xb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int xb_create(int device, xb_ctx **out) {
+    if (!out) return fail(XB_E_ARG, "xb_create: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(XB_E_HIP, "xb_create: no HIP device visible (%s); libbader_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(XB_E_ARG, "xb_create: device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    xb_ctx *c = new xb_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipMalloc(&c->counters, 64 * sizeof(int)));
+    HIPCHK(hipMalloc(&c->counters64, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->dsum, 16 * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->host_ints, 64 * sizeof(long long)));
+    *out = c;
+    return XB_OK;
+}
+
+static void free_grid(xb_ctx *c) {
+    hipFree(c->rho); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
+    hipFree(c->st); hipFree(c->stage); hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    c->rho = nullptr; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
+    c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
+    c->n_alloc = 0; c->stage_bytes = 0;
+}
+
+void xb_destroy(xb_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &t : c->tk)
+        for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    free_grid(c);
+    hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum);
+    hipHostFree(c->host_ints);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int xb_sync(xb_ctx *c) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+void *xb_stream(xb_ctx *c) { return (void *)c->stream; }
+
+static void set_valid_range(xb_ctx *c) {
+    Grid &g = c->g;
+    const int own = g.x1 - g.x0;
+    if (own + 2 * c->halo >= g.nx) { g.vx0 = 0; g.vlen = g.nx; }
+    else {
+        // labels valid on [x0-H, x1+H); known (flag + dilate) on [x0-H+2, x1+H-2)
+        const int hv = c->halo - 2;
+        g.vx0 = ((g.x0 - hv) % g.nx + g.nx) % g.nx;
+        g.vlen = own + 2 * hv;
+    }
+}
+
+int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], const double T_grad[9],
+                int64_t x0, int64_t x1) {
+    if (!c || !shape) return fail(XB_E_ARG, "xb_set_grid: null argument");
+    for (int j = 0; j < 3; j++)
+        if (shape[j] < 3) return fail(XB_E_ARG, "xb_set_grid: every axis needs >= 3 voxels (got %lld)", (long long)shape[j]);
+    const long long N = (long long)shape[0] * shape[1] * shape[2];
+    if (N >= 2147483647LL) return fail(XB_E_LIMIT, "xb_set_grid: %lld voxels exceed the int32 index range", N);
+    if (x0 < 0 || x1 > shape[0] || x0 >= x1) return fail(XB_E_ARG, "xb_set_grid: bad slab [%lld,%lld)", (long long)x0, (long long)x1);
+    HIPCHK(hipSetDevice(c->device));
+    if (N != c->n_alloc) {
+        free_grid(c);
+        HIPCHK(hipMalloc(&c->rho, N * sizeof(double)));
+        HIPCHK(hipMalloc(&c->labels, N * sizeof(int)));
+        HIPCHK(hipMalloc(&c->known, N));
+        HIPCHK(hipMalloc(&c->first, N * sizeof(int)));
+        HIPCHK(hipMalloc(&c->list, N * sizeof(int)));
+        HIPCHK(hipMalloc(&c->st, N));
+        c->stage_bytes = (size_t)N * 8;
+        HIPCHK(hipMalloc(&c->stage, c->stage_bytes));
+        c->max_cap = (int)std::min<long long>(N, 1 << 22);
+        HIPCHK(hipMalloc(&c->max_list, c->max_cap * sizeof(int)));
+        HIPCHK(hipMalloc(&c->max_aux, c->max_cap * sizeof(int)));
+        c->ovf_cap = (int)std::min<long long>(N, 1 << 22);
+        HIPCHK(hipMalloc(&c->ovf_list, c->ovf_cap * sizeof(int)));
+        c->n_alloc = N;
+        c->first_clean = false;
+    }
+    Grid &g = c->g;
+    g.nx = (int)shape[0]; g.ny = (int)shape[1]; g.nz = (int)shape[2];
+    g.nyz = g.ny * g.nz;
+    g.x0 = (int)x0; g.x1 = (int)x1;
+    if (dist_mat) memcpy(g.dist, dist_mat, sizeof g.dist);
+    if (T_grad) memcpy(g.T, T_grad, sizeof g.T);
+    c->N = N;
+    c->halo = (x0 == 0 && x1 == shape[0]) ? g.nx : 0;
+    set_valid_range(c);
+    c->has_grid = true;
+    c->maxima_sorted.clear();
+    if (!c->first_clean) {
+        k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, N);
+        HIPCHK(hipGetLastError());
+        c->first_clean = true;
+    }
+    return XB_OK;
+}
+
+int xb_set_halo(xb_ctx *c, int64_t halo) {
+    if (!c || !c->has_grid) return fail(XB_E_STATE, "xb_set_halo: no grid");
+    if (halo < 2) return fail(XB_E_ARG, "xb_set_halo: halo must be >= 2 planes");
+    c->halo = (int)halo;
+    set_valid_range(c);
+    return XB_OK;
+}
+
+#define NEED_GRID(name) \
+    if (!c || !c->has_grid) return fail(XB_E_STATE, name ": call xb_set_grid first"); \
+    HIPCHK(hipSetDevice(c->device))
+
+int xb_upload_density(xb_ctx *c, const double *rho_host) {
+    NEED_GRID("xb_upload_density");
+    HIPCHK(hipMemcpyAsync(c->rho, rho_host, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+int xb_download_density(xb_ctx *c, double *rho_host) {
+    NEED_GRID("xb_download_density");
+    HIPCHK(hipMemcpyAsync(rho_host, c->rho, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, int64_t n_atoms, double background) {
+    NEED_GRID("xb_synth_density");
+    if (n_atoms < 0 || n_atoms > 4096) return fail(XB_E_ARG, "xb_synth_density: bad atom count");
+    double *tmp = (double *)c->stage;
+    HIPCHK(hipMemcpyAsync(tmp, lattice, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(tmp + 16, atoms5, n_atoms * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    k_synth_density<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, tmp, tmp + 16, (int)n_atoms, background, c->rho);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+static size_t dtype_size(int dtype) { return (dtype == XB_I8 || dtype == XB_I16 || dtype == XB_I32 || dtype == XB_I64) ? (size_t)dtype : 0; }
+
+int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
+    NEED_GRID("xb_upload_labels");
+    const size_t sz = dtype_size(dtype);
+    if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
+    if (dtype == XB_I32) {
+        HIPCHK(hipMemcpyAsync(c->labels, labels_host, c->N * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->stage, labels_host, c->N * sz, hipMemcpyHostToDevice, c->stream));
+        if (dtype == XB_I8) k_widen<int8_t><<<nblocks(c->N), TPB, 0, c->stream>>>((const int8_t *)c->stage, c->labels, c->N);
+        else if (dtype == XB_I16) k_widen<int16_t><<<nblocks(c->N), TPB, 0, c->stream>>>((const int16_t *)c->stage, c->labels, c->N);
+        else k_widen<long long><<<nblocks(c->N), TPB, 0, c->stream>>>((const long long *)c->stage, c->labels, c->N);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {
+    NEED_GRID("xb_download_labels");
+    const size_t sz = dtype_size(dtype);
+    if (!sz) return fail(XB_E_ARG, "xb_download_labels: bad dtype code %d", dtype);
+    if (dtype == XB_I32) {
+        HIPCHK(hipMemcpyAsync(labels_host, c->labels, c->N * 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (dtype == XB_I8) k_narrow<int8_t><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (int8_t *)c->stage, c->N);
+        else if (dtype == XB_I16) k_narrow<int16_t><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (int16_t *)c->stage, c->N);
+        else k_narrow<long long><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (long long *)c->stage, c->N);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(labels_host, c->stage, c->N * sz, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+int xb_upload_known(xb_ctx *c, const int8_t *known_host) {
+    NEED_GRID("xb_upload_known");
+    HIPCHK(hipMemcpyAsync(c->known, known_host, c->N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+int xb_download_known(xb_ctx *c, int8_t *known_host) {
+    NEED_GRID("xb_download_known");
+    HIPCHK(hipMemcpyAsync(known_host, c->known, c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume) {
+    NEED_GRID("xb_vacuum_assign");
+    HIPCHK(hipMemsetAsync(c->dsum, 0, sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
+    k_vacuum_assign<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, vac_tol, c->dsum, c->counters64);
+    HIPCHK(hipGetLastError());
+    double s;
+    unsigned long long n;
+    HIPCHK(hipMemcpyAsync(&s, c->dsum, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&n, c->counters64, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (vac_charge) *vac_charge = s * voxel_volume;  // utils.py:400
+    if (vac_volume) *vac_volume = (double)n * voxel_volume;
+    return XB_OK;
+}
+
+static int read_counter(xb_ctx *c, int idx, int *out) {
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c->host_ints[0];
+    return XB_OK;
+}
+
+// run the exact slow kernel over ovf_list[0..n) in chunks
+static int run_slow(xb_ctx *c, int n, int refine) {
+    const int lmax = 1 << 15, chunk = 2048;
+    int *path = nullptr;
+    HIPCHK(hipMalloc(&path, (size_t)chunk * lmax * sizeof(int)));
+    HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));  // err
+    for (int o = 0; o < n; o += chunk) {
+        const int m = std::min(chunk, n - o);
+        k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
+                                                         c->ovf_list + o, m, path, lmax, refine, c->first,
+                                                         c->max_list, c->counters + 0, c->max_cap,
+                                                         c->counters + 2, c->counters + 3, c->counters + 8);
+    }
+    hipError_t e = hipGetLastError();
+    int err = 0;
+    int rc = read_counter(c, 8, &err);
+    hipFree(path);
+    if (e != hipSuccess) return fail(XB_E_HIP, "k_trace_slow: %s", hipGetErrorString(e));
+    if (rc) return rc;
+    if (err) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", lmax);
+    return XB_OK;
+}
+
+int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
+    NEED_GRID("xb_assign_trace");
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    HIPCHK(hipMemsetAsync(c->counters, 0, 16 * sizeof(int), c->stream));
+    if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
+        k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
+        HIPCHK(hipGetLastError());
+    }
+    c->first_clean = false;
+    if (method == XB_METHOD_NEARGRID) {
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        {
+            ScopedTimer t(c, 0);
+            k_ng_trace<4><<<nblocks(own), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->first, c->max_list,
+                                                               c->counters + 0, c->max_cap, c->ovf_list,
+                                                               c->counters + 1, c->ovf_cap, maxsteps);
+        }
+        HIPCHK(hipGetLastError());
+        int novf = 0;
+        if (int rc = read_counter(c, 1, &novf)) return rc;
+        if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
+        if (novf > 0)
+            if (int rc = run_slow(c, novf, 0)) return rc;
+    } else if (method == XB_METHOD_ONGRID) {
+        {
+            ScopedTimer t(c, 1);
+            k_og_pointer<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->rho, c->labels);
+        }
+        HIPCHK(hipGetLastError());
+        for (int it = 0; it < 64; it++) {
+            HIPCHK(hipMemsetAsync(c->counters + 4, 0, sizeof(int), c->stream));
+            k_og_jump<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->labels, c->counters + 4);
+            HIPCHK(hipGetLastError());
+            int nd = 0;
+            if (int rc = read_counter(c, 4, &nd)) return rc;
+            if (!nd) break;
+            if (it == 63) return fail(XB_E_LIMIT, "ongrid pointer jumping did not converge");
+        }
+        k_note_roots<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap);
+        HIPCHK(hipGetLastError());
+    } else
+        return fail(XB_E_ARG, "xb_assign: unknown method %d", method);
+    int nmax = 0;
+    if (int rc = read_counter(c, 0, &nmax)) return rc;
+    if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    c->local_max.resize(nmax);
+    c->local_first.resize(nmax);
+    if (nmax) {
+        k_gather_first<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, c->max_aux);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->local_max.data(), c->max_list, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->local_first.data(), c->max_aux, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (n_local) *n_local = nmax;
+    return XB_OK;
+}
+
+int xb_assign_local_table(xb_ctx *c, int64_t *max_idx, int64_t *first_idx, int64_t capacity) {
+    NEED_GRID("xb_assign_local_table");
+    if ((int64_t)c->local_max.size() > capacity) return fail(XB_E_ARG, "xb_assign_local_table: capacity too small");
+    for (size_t i = 0; i < c->local_max.size(); i++) { max_idx[i] = c->local_max[i]; first_idx[i] = c->local_first[i]; }
+    return XB_OK;
+}
+
+int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global) {
+    NEED_GRID("xb_assign_finish");
+    if (n_global > c->max_cap) return fail(XB_E_LIMIT, "xb_assign_finish: too many maxima");
+    c->maxima_sorted.resize(n_global);
+    for (int64_t i = 0; i < n_global; i++) c->maxima_sorted[i] = (int)max_idx_sorted[i];
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    if (n_global) {
+        HIPCHK(hipMemcpyAsync(c->max_aux, c->maxima_sorted.data(), n_global * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        k_set_rank<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
+        HIPCHK(hipGetLastError());
+    }
+    k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first);
+    HIPCHK(hipGetLastError());
+    if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
+        k_reset_first<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->first_clean = true;
+    return XB_OK;
+}
+
+int xb_assign(xb_ctx *c, int method, int64_t *n_maxima) {
+    int64_t n = 0;
+    if (int rc = xb_assign_trace(c, method, &n)) return rc;
+    // numbering: rank of the smallest voxel index reaching each maximum (thread_handlers.py:59-65
+    // numbers maxima in the order the C-order scan discovers them)
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return c->local_first[a] < c->local_first[b]; });
+    std::vector<int64_t> sorted(n);
+    for (int i = 0; i < n; i++) sorted[i] = c->local_max[order[i]];
+    if (int rc = xb_assign_finish(c, sorted.data(), n)) return rc;
+    if (n_maxima) *n_maxima = n;
+    return XB_OK;
+}
+
+int xb_get_maxima(xb_ctx *c, int64_t *maxima_out, int64_t capacity) {
+    NEED_GRID("xb_get_maxima");
+    if ((int64_t)c->maxima_sorted.size() > capacity) return fail(XB_E_ARG, "xb_get_maxima: capacity too small");
+    const Grid &g = c->g;
+    for (size_t i = 0; i < c->maxima_sorted.size(); i++) {
+        const int m = c->maxima_sorted[i];
+        const int x = m / g.nyz, r = m - x * g.nyz;
+        maxima_out[3 * i] = x; maxima_out[3 * i + 1] = r / g.nz; maxima_out[3 * i + 2] = r % g.nz;
+    }
+    return XB_OK;
+}
+
+// planes [x0-ext, x1+ext) clipped to the grid size; returns start plane (mod nx) and count
+static void plane_range(const Grid &g, int ext, int &xa, int &np) {
+    const int own = g.x1 - g.x0;
+    if (own + 2 * ext >= g.nx) { xa = 0; np = g.nx; }
+    else { xa = ((g.x0 - ext) % g.nx + g.nx) % g.nx; np = own + 2 * ext; }
+}
+
+int xb_edge_find(xb_ctx *c, int64_t *edges) {
+    NEED_GRID("xb_edge_find");
+    const Grid &g = c->g;
+    const bool whole = (g.x1 - g.x0 == g.nx);
+    if (!whole && c->halo < 2) return fail(XB_E_STATE, "xb_edge_find: slab needs a label halo (xb_set_halo)");
+    int xa, np, xb_, npd;
+    plane_range(g, whole ? 0 : c->halo - 1, xa, np);   // flags need labels one plane further out
+    plane_range(g, whole ? 0 : c->halo - 2, xb_, npd);  // dilation needs flags one plane further out
+    HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
+    {
+        ScopedTimer t(c, 2);
+        k_edge_flag<<<nblocks((long long)np * g.nyz), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, xa, np, c->counters64);
+        k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
+    }
+    HIPCHK(hipGetLastError());
+    unsigned long long n;
+    HIPCHK(hipMemcpyAsync(&n, c->counters64, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (edges) *edges = (int64_t)n;
+    return XB_OK;
+}
+
+static int compact(xb_ctx *c, int value, int *n_out) {
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
+    k_compact_known<<<nblocks(own), TPB, 0, c->stream>>>(g, c->known, value, c->list, c->counters + 5, (int)std::min<long long>(c->N, 2147483647LL));
+    HIPCHK(hipGetLastError());
+    return read_counter(c, 5, n_out);
+}
+
+int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) {
+    NEED_GRID("xb_refine_trace");
+    const Grid &g = c->g;
+    int n = 0;
+    if (int rc = compact(c, -2, &n)) return rc;
+    HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
+    if (n) {
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        {
+            ScopedTimer t(c, 3);
+            k_refine_trace<4><<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n,
+                                                                c->counters + 2, c->counters + 3, c->ovf_list,
+                                                                c->counters + 1, c->ovf_cap, maxsteps);
+        }
+        HIPCHK(hipGetLastError());
+        int novf = 0;
+        if (int rc = read_counter(c, 1, &novf)) return rc;
+        if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
+        if (novf > 0)
+            if (int rc = run_slow(c, novf, 1)) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (changed) *changed = c->host_ints[0];
+    if (escaped) *escaped = c->host_ints[1];
+    return XB_OK;
+}
+
+int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
+    NEED_GRID("xb_edge_check");
+    const Grid &g = c->g;
+    if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: 'changed' mode is single-slab only; slabs use mode 'all'");
+    int n = 0;
+    if (int rc = compact(c, -2, &n)) return rc;
+    if (checked) *checked = 0;
+    if (edges) *edges = 0;
+    if (!n) return XB_OK;
+    HIPCHK(hipMemsetAsync(c->st, 0, n, c->stream));
+    for (int round = 0;; round++) {
+        HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+        k_ec_decide<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters + 6);
+        HIPCHK(hipGetLastError());
+        int und = 0;
+        if (int rc = read_counter(c, 6, &und)) return rc;
+        if (!und) break;
+        if (round > n + 4 || round > 20000) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
+    }
+    HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
+    k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1);
+    k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
+    k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
+    k_ec_finish<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, c->counters64);
+    HIPCHK(hipGetLastError());
+    unsigned long long r[2];
+    HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (edges) *edges = (int64_t)r[0];
+    if (checked) *checked = (int64_t)(r[1] + r[0]);  // refinement.py:479 + 504
+    return XB_OK;
+}
+
+int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
+    NEED_GRID("xb_refine");
+    if (n_iters) *n_iters = 0;
+    if (iters == 0) return XB_OK;  // thread_handlers.py:146-147
+    int64_t edges = 0, changed = 0, esc = 0, checked = 0;
+    if (int rc = xb_edge_find(c, &edges)) return rc;
+    if (edges == 0) return XB_OK;  // thread_handlers.py:151-153
+    int64_t k = 0;
+    auto put = [&](int64_t e, int64_t ch) {
+        if (log && 2 * k + 1 < log_capacity) { log[2 * k] = e; log[2 * k + 1] = ch; }
+        k++;
+        if (n_iters) *n_iters = k;
+    };
+    if (int rc = xb_refine_trace(c, &changed, &esc)) return rc;
+    if (esc) return fail(XB_E_STATE, "xb_refine: %lld traces left the valid slab", (long long)esc);
+    put(edges, changed);
+    for (int64_t it = 2; iters < 0 || it <= iters; it++) {  // thread_handlers.py:194-236
+        if (mode == XB_REFINE_ALL) {
+            if (int rc = xb_edge_find(c, &edges)) return rc;
+        } else {
+            if (int rc = xb_edge_check(c, &checked, &edges)) return rc;
+        }
+        if (int rc = xb_refine_trace(c, &changed, &esc)) return rc;
+        if (esc) return fail(XB_E_STATE, "xb_refine: %lld traces left the valid slab", (long long)esc);
+        put(edges, changed);
+        if (changed == 0) break;
+    }
+    return XB_OK;
+}
+
+int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *charge, double *volume) {
+    NEED_GRID("xb_charge_sum");
+    if (n_labels <= 0) return XB_OK;
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    double *dch = nullptr;
+    unsigned long long *dcn = nullptr;
+    HIPCHK(hipMalloc(&dch, n_labels * sizeof(double)));
+    HIPCHK(hipMalloc(&dcn, n_labels * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(dch, 0, n_labels * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(dcn, 0, n_labels * sizeof(unsigned long long), c->stream));
+    if (n_labels <= CS_BINS) {
+        const int per_thread = 16;
+        k_charge_sum_lds<<<nblocks((own + per_thread - 1) / per_thread), TPB, 0, c->stream>>>(g, c->rho, c->labels, (int)n_labels, dch, dcn, per_thread);
+    } else {
+        k_charge_sum_glb<<<nblocks(own), TPB, 0, c->stream>>>(g, c->rho, c->labels, (int)n_labels, dch, dcn);
+    }
+    hipError_t e = hipGetLastError();
+    std::vector<unsigned long long> cn(n_labels);
+    if (e == hipSuccess) e = hipMemcpyAsync(charge, dch, n_labels * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cn.data(), dcn, n_labels * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dch);
+    hipFree(dcn);
+    if (e != hipSuccess) return fail(XB_E_HIP, "xb_charge_sum: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < n_labels; i++) {
+        charge[i] *= voxel_volume;  // utils.py:251-252
+        volume[i] = (double)cn[i] * voxel_volume;
+    }
+    return XB_OK;
+}
+
+int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap) {
+    NEED_GRID("xb_volume_assign");
+    if (n_swap <= 0) return XB_OK;
+    if (n_swap > c->max_cap) return fail(XB_E_LIMIT, "xb_volume_assign: swap table too long");
+    std::vector<int> s(n_swap);
+    for (int64_t i = 0; i < n_swap; i++) s[i] = (int)swap[i];
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    HIPCHK(hipMemcpyAsync(c->max_aux, s.data(), n_swap * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    k_volume_assign<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->max_aux, (int)n_swap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+// utils.atom_assign (utils.py:185-232), host side: N_maxima x N_atoms x 27 -- tiny.
+int xb_atom_assign(const double *b_max, int64_t n_max, const double *atoms, int64_t n_atoms, const double lattice[9],
+                   int64_t *atom_out, double *dist_out) {
+    if (n_atoms <= 0) return fail(XB_E_ARG, "xb_atom_assign: no atoms");
+    double pbc[3] = {0., 0., 0.};  // utils.py:199: persists across maxima (206-208 read it before the loops)
+    for (int64_t i = 0; i < n_max; i++) {
+        const double *b = b_max + 3 * i;
+        double e0 = b[0] - (atoms[0] + pbc[0]), e1 = b[1] - (atoms[1] + pbc[1]), e2 = b[2] - (atoms[2] + pbc[2]);
+        double best = (e0 * e0 + e1 * e1) + e2 * e2;
+        int64_t who = 0;
+        for (int64_t j = 0; j < n_atoms; j++) {
+            const double *a = atoms + 3 * j;
+            for (int x = -1; x < 2; x++)
+                for (int y = -1; y < 2; y++)
+                    for (int z = -1; z < 2; z++) {
+                        for (int k = 0; k < 3; k++) pbc[k] = (lattice[k] * x + lattice[3 + k] * y) + lattice[6 + k] * z;
+                        e0 = b[0] - (a[0] + pbc[0]); e1 = b[1] - (a[1] + pbc[1]); e2 = b[2] - (a[2] + pbc[2]);
+                        const double d = (e0 * e0 + e1 * e1) + e2 * e2;
+                        if (d < best) { best = d; who = j; }
+                    }
+        }
+        atom_out[i] = who;
+        dist_out[i] = std::sqrt(best);
+    }
+    return XB_OK;
+}
+
+void *xb_labels_ptr(xb_ctx *c) { return c ? (void *)c->labels : nullptr; }
+void *xb_known_ptr(xb_ctx *c) { return c ? (void *)c->known : nullptr; }
+void *xb_density_ptr(xb_ctx *c) { return c ? (void *)c->rho : nullptr; }
+int64_t xb_plane_elems(xb_ctx *c) { return c ? c->g.nyz : 0; }
+
+int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, int64_t xb) {
+    NEED_GRID("xb_copy_planes");
+    if (xa < 0 || xb > c->g.nx || xa > xb) return fail(XB_E_ARG, "xb_copy_planes: bad plane range");
+    const size_t es = which == 0 ? 4 : 1;
+    char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
+    const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
+    if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+int xb_enable_timing(xb_ctx *c, int on) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    c->timing = on != 0;
+    return XB_OK;
+}
+int xb_kernel_time_reset(xb_ctx *c) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &t : c->tk) {
+        for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+        t.pending.clear();
+        t.ms = 0.;
+        t.launches = 0;
+    }
+    return XB_OK;
+}
+int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches) {
+    if (!c || which < 0 || which > 3) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    TimedKernel &t = c->tk[which];
+    for (auto &p : t.pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        t.ms += ms;
+        t.launches++;
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    t.pending.clear();
+    if (ms_total) *ms_total = t.ms;
+    if (launches) *launches = t.launches;
+    return XB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Slab scheduler: the multi-GPU replacement of pybader/thread_handlers.py's block split
+(thread_handlers.py:28-47, 154-174), one process per GPU.
+
+Decomposition: contiguous slabs of axis 0 (the slow axis of the C-order
+arrays, so a slab and its halo planes are contiguous memory).  The float64 density is replicated on
+every GPU (8 GiB at 1024^3 of 288 GB): every trajectory step is a local read and the remainder `dr`
+is carried exactly, which keeps the N-slab result identical to the 1-GPU result.  Labels / known
+flags are full-size arrays on every rank of which only the owned planes + `halo` planes each side
+are kept valid; halos are refreshed by point-to-point plane exchange (RCCL send/recv through
+torch.distributed when the arrays are device tensors, gloo when they are host tensors in the CPU
+tests) before every edge sweep.  Collectives: only tiny ones (maxima tables, counters).
+
+The scheduler is written against a small backend interface so that the CPU tests can drive it with a
+host backend; the product backend is `GpuBackend` (libbader_hip.so)."""
+import numpy as np
+
+
+def slab_ranges(nx, nranks):
+    """np.array_split semantics along axis 0 (thread_handlers.py:35): first nx % n slabs get one more."""
+    base, extra = divmod(int(nx), int(nranks))
+    out, x = [], 0
+    for r in range(nranks):
+        w = base + (1 if r < extra else 0)
+        out.append((x, x + w))
+        x += w
+    return out
+
+
+def merge_maxima_tables(tables):
+    """Global basin numbering from per-rank (maximum index, smallest owned voxel reaching it) tables:
+    min over ranks, then rank by that smallest voxel index -- the order the reference's C-order scan
+    discovers maxima (thread_handlers.py:59-65 for one block)."""
+    best = {}
+    for m, f in tables:
+        for mi, fi in zip(np.asarray(m).tolist(), np.asarray(f).tolist()):
+            if mi not in best or fi < best[mi]:
+                best[mi] = fi
+    order = sorted(best, key=lambda k: best[k])
+    return np.array(order, dtype=np.int64)
+
+
+def halo_plan(ranges, rank, halo, nx):
+    """Plane runs this rank must receive: list of (peer, xa, xb) covering [x0-halo, x0) and
+    [x1, x1+halo) modulo nx, split by owner; and the mirror list of runs it must send."""
+    def owner(p):
+        for r, (a, b) in enumerate(ranges):
+            if a <= p < b:
+                return r
+        raise ValueError(p)
+
+    def runs(planes):
+        out = []
+        for p in planes:
+            o = owner(p)
+            if out and out[-1][0] == o and out[-1][2] == p:
+                out[-1][2] = p + 1
+            else:
+                out.append([o, p, p + 1])
+        return [tuple(r) for r in out]
+
+    def wanted(r):
+        a, b = ranges[r]
+        if (b - a) + 2 * halo >= nx:
+            need = [p for p in range(nx) if not (a <= p < b)]
+        else:
+            need = [(a - halo + k) % nx for k in range(halo)] + [(b + k) % nx for k in range(halo)]
+        return runs(need)
+
+    recvs = [r for r in wanted(rank) if r[0] != rank]
+    sends = []
+    for peer in range(len(ranges)):
+        if peer == rank:
+            continue
+        for o, xa, xb in wanted(peer):
+            if o == rank:
+                sends.append((peer, xa, xb))
+    return sends, recvs
+
+
+class TorchComm:
+    """torch.distributed plumbing: backend 'nccl' is RCCL over xGMI on the GPU box, 'gloo' in CPU tests."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+
+    def allgather(self, obj):
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def sum(self, *vals):
+        got = self.allgather([int(v) for v in vals])
+        return [sum(g[i] for g in got) for i in range(len(vals))]
+
+    def exchange(self, tensor, sends, recvs):
+        """tensor: (nx, plane) view aliasing the array; moves whole planes between ranks."""
+        import torch
+        ops = []
+        for peer, xa, xb in recvs:
+            ops.append(self.dist.P2POp(self.dist.irecv, tensor[xa:xb], peer))
+        for peer, xa, xb in sends:
+            ops.append(self.dist.P2POp(self.dist.isend, tensor[xa:xb], peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+            if tensor.is_cuda:
+                torch.cuda.synchronize(tensor.device)
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+class _DevArray:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+class GpuBackend:
+    """libbader_hip.so context + zero-copy torch views of its label / known arrays for RCCL."""
+
+    def __init__(self, ctx, device_index):
+        self.ctx = ctx
+        self.device_index = device_index
+        self._views = None
+
+    def set_grid(self, shape, dist_mat, T_grad, x_range, halo):
+        self.ctx.set_grid(shape, dist_mat, T_grad, x_range)
+        if x_range != (0, shape[0]):
+            self.ctx.set_halo(halo)
+        self._views = None
+
+    def tensors(self):
+        if self._views is None:
+            import torch
+            lib, h = self.ctx.lib, self.ctx.h
+            nx = self.ctx.shape[0]
+            plane = int(lib.xb_plane_elems(h))
+            dev = f'cuda:{self.device_index}'
+            lab = torch.as_tensor(_DevArray(lib.xb_labels_ptr(h), (nx, plane), '<i4'), device=dev)
+            kn = torch.as_tensor(_DevArray(lib.xb_known_ptr(h), (nx, plane), '|i1'), device=dev)
+            self._views = (lab, kn)
+        return self._views
+
+    def __getattr__(self, name):          # assign_trace, assign_finish, edge_find, refine_trace, sync ...
+        return getattr(self.ctx, name)
+
+
+class SlabRunner:
+    """bader_calc + refine over slabs; with one rank it degenerates to the single-GPU calls."""
+
+    def __init__(self, backend, comm, shape, dist_mat, T_grad, halo=8):
+        self.be, self.comm = backend, comm
+        self.shape = tuple(int(s) for s in shape)
+        self.ranges = slab_ranges(self.shape[0], comm.size)
+        self.x_range = self.ranges[comm.rank]
+        self.halo = max(2, min(int(halo), self.shape[0]))
+        self.be.set_grid(self.shape, dist_mat, T_grad, self.x_range, self.halo)
+        self.sends, self.recvs = halo_plan(self.ranges, comm.rank, self.halo, self.shape[0])
+        self.n_maxima = 0
+
+    def assign(self, method):
+        """thread_handlers.bader_calc: per-slab trajectories, then one tiny table merge for numbering."""
+        m, f = self.be.assign_trace(method)
+        if self.comm.size == 1:
+            order = np.argsort(f, kind='stable')
+            maxima = np.asarray(m)[order]
+        else:
+            maxima = merge_maxima_tables(self.comm.allgather((np.asarray(m), np.asarray(f))))
+        self.be.assign_finish(maxima)
+        self.n_maxima = int(maxima.shape[0])
+        self.maxima = maxima
+        return self.n_maxima
+
+    def exchange_label_halo(self):
+        if self.comm.size > 1:
+            self.be.sync()
+            self.comm.exchange(self.be.tensors()[0], self.sends, self.recvs)
+
+    def _trace(self):
+        changed, escaped = self.be.refine_trace()
+        changed, escaped = self.comm.sum(changed, escaped) if self.comm.size > 1 else (changed, escaped)
+        if escaped:
+            raise RuntimeError(f"{escaped} refinement traces left the slab halo ({self.halo} planes); "
+                               "re-run with a wider halo")
+        return changed
+
+    def refine(self, mode, iters):
+        """thread_handlers.refine (thread_handlers.py:128-236) across slabs.  Returns [(edges, changed)]."""
+        log = []
+        if iters == 0:
+            return log
+        self.exchange_label_halo()
+        edges = self.be.edge_find()
+        if self.comm.size > 1:
+            edges, = self.comm.sum(edges)
+        if edges == 0:
+            return log
+        changed = self._trace()
+        log.append((edges, changed))
+        it = 2
+        while iters < 0 or it <= iters:
+            if mode.lower() == 'all':
+                self.exchange_label_halo()
+                edges = self.be.edge_find()
+                if self.comm.size > 1:
+                    edges, = self.comm.sum(edges)
+            elif self.comm.size == 1:
+                _, edges = self.be.edge_check()
+            elif changed == 0:
+                edges = 0                      # no voxel is flagged -2: edge_check is the identity
+            else:
+                raise NotImplementedError("'changed' refinement with relabelled voxels across slabs: "
+                                          "use mode 'all' or one GPU")
+            changed = self._trace()
+            log.append((edges, changed))
+            if changed == 0:
+                break
+            it += 1
+        return log

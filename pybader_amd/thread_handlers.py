@@ -1,0 +1,74 @@
+"""Host-side mirror of pybader/thread_handlers.py for the hot path: same function names,
+argument order, return values and silent-return cases, backed by libbader_hip.so.
+
+`threads` is accepted for signature compatibility and ignored: the reference splits the grid into
+thread blocks (thread_handlers.py:28-47); here the GPU library owns the decomposition."""
+import numpy as np
+
+from . import _lib, methods, refinement
+from .utils import atom_assign, dtype_calc, ensure_density
+
+__all__ = ['bader_calc', 'refine', 'assign_to_atoms', 'dtype_calc']
+
+VERBOSE = True
+
+
+def _say(*a):
+    if VERBOSE:
+        print(*a)
+
+
+def bader_calc(method, density, volumes, dist_mat, T_grad, threads):
+    """thread_handlers.bader_calc (thread_handlers.py:15-75).
+
+    returns (bader_max int64[N,3] voxel indices, volumes narrowed to dtype_calc(-N))."""
+    if method not in methods.__contains__:
+        raise AttributeError(f"module 'pybader.methods' has no attribute '{method}'")   # getattr, line 26
+    ctx = _lib.default_context()
+    ctx.set_grid(density.shape, dist_mat, T_grad)
+    ensure_density(ctx, density)
+    ctx.upload_labels(volumes)
+    n = ctx.assign(method)
+    bader_max = ctx.maxima()
+    dtype = np.dtype(dtype_calc(-n))                                                   # lines 70-74
+    if volumes.dtype == dtype and volumes.flags.c_contiguous:
+        ctx.download_labels(out=volumes)
+    else:
+        volumes = ctx.download_labels(dtype)
+    return bader_max, volumes
+
+
+def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads):
+    """thread_handlers.refine (thread_handlers.py:128-236): in place on `volumes`, returns None."""
+    if method not in refinement.__contains__:      # getattr AttributeError -> silent return (140-143)
+        return
+    check_mode, iters = tuple(refine_mode)
+    if iters == 0:                                 # lines 146-147
+        return
+    _say(f"\n  Refining {check_mode} edges:")
+    ctx = _lib.default_context()
+    ctx.set_grid(density.shape, dist_mat, T_grad)
+    ensure_density(ctx, density)
+    ctx.upload_labels(volumes)
+    log = ctx.refine(check_mode, iters)
+    if not log:
+        _say("  No edges found.")                  # lines 151-153
+        return
+    for k, (edges, changed) in enumerate(log):
+        _say(f"  Iteration {k + 1}:\n  Refining {edges} edges: {changed} points changed.")
+    ctx.download_labels(out=volumes) if volumes.flags.c_contiguous else volumes.__setitem__(
+        Ellipsis, ctx.download_labels(volumes.dtype))
+    refine.last_log = log
+
+
+def assign_to_atoms(bader_max, atoms, lattice, volumes, threads):
+    """thread_handlers.assign_to_atoms (thread_handlers.py:78-125)
+    -> (bader_atoms int64[N], bader_distance f64[N], atoms_volumes narrowed to dtype_calc(-n_atoms))."""
+    bader_atoms, bader_distance = atom_assign(bader_max, atoms, lattice)
+    ctx = _lib.default_context()
+    if ctx.shape != tuple(volumes.shape):
+        ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
+    ctx.upload_labels(volumes)
+    ctx.volume_assign(bader_atoms)
+    atom_volumes = ctx.download_labels(np.dtype(dtype_calc(-atoms.shape[0])))
+    return bader_atoms, bader_distance, atom_volumes

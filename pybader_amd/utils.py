@@ -1,0 +1,91 @@
+"""Host-side mirror of the njit half of pybader/utils.py that sits on the hot path.
+
+Same names, argument order and in-place behaviour as the reference; the sweeps run in
+libbader_hip.so on the GPU (no CPU fallback)."""
+import numpy as np
+
+from . import _lib
+
+_fingerprints = {}
+
+
+def dtype_calc(max_val):
+    """utils.dtype_calc (utils.py:15-37): smallest dtype holding max_val; a negative argument asks
+    for a signed type able to hold 2*|max_val|."""
+    signed = max_val < 0
+    if signed:
+        max_val *= -2
+    width = 0 if max_val <= 255 else 1 if max_val <= 65535 else 2 if max_val <= 4294967295 else 3
+    return ('int8', 'int16', 'int32', 'int64')[width] if signed else ('uint8', 'uint16', 'uint32', 'uint64')[width]
+
+
+def _fingerprint(a):
+    flat = a.reshape(-1)
+    step = max(1, flat.shape[0] // 65536)
+    s = flat[::step]
+    return (a.ctypes.data, a.shape, a.strides, float(s.sum()), float(flat[0]), float(flat[-1]))
+
+
+def ensure_density(ctx, density):
+    """Upload `density` unless this very array (same memory, same sampled content) is resident."""
+    density = np.ascontiguousarray(density, dtype=np.float64)
+    fp = _fingerprint(density)
+    if _fingerprints.get(id(ctx)) != fp:
+        ctx.upload_density(density)
+        _fingerprints[id(ctx)] = fp
+    return density
+
+
+def forget_density(ctx):
+    _fingerprints.pop(id(ctx), None)
+
+
+def vacuum_assign(reference, volumes, vac_tol, density, voxel_volume):
+    """utils.vacuum_assign (utils.py:382-401): volumes[reference <= vac_tol] = -1; returns
+    (volumes, vacuum charge, vacuum volume).  `volumes` is updated in place."""
+    ctx = _lib.default_context()
+    if ctx.shape != tuple(volumes.shape):
+        ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
+    same = reference is density or (reference.shape == density.shape and np.shares_memory(reference, density))
+    if not same:
+        raise NotImplementedError("vacuum_assign with a separate reference density (bader -ref) is not "
+                                  "on the GPU path yet")
+    ensure_density(ctx, reference)
+    charge, volume = ctx.vacuum_assign(vac_tol, voxel_volume)
+    # the device sets non-vacuum voxels to 0; the reference leaves them untouched
+    if np.any(volumes):
+        keep = volumes.copy()
+        ctx.download_labels(out=volumes)
+        np.copyto(volumes, keep, where=volumes != -1)
+    else:
+        ctx.download_labels(out=volumes)
+    return volumes, charge, volume
+
+
+def charge_sum(charge, volume, voxel_volume, density, volumes):
+    """utils.charge_sum (utils.py:235-252): in place on `charge` / `volume` like the reference."""
+    ctx = _lib.default_context()
+    if ctx.shape != tuple(volumes.shape):
+        ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
+    ensure_density(ctx, density)
+    ctx.upload_labels(volumes)
+    ch, vo = ctx.charge_sum(voxel_volume, charge.shape[0])
+    # utils.py:251-252 scales the accumulated charge (whatever it held on entry) by voxel_volume
+    charge *= voxel_volume
+    charge += ch
+    volume += vo
+
+
+def atom_assign(bader_max, atoms, lattice, i_c=None):
+    """utils.atom_assign (utils.py:185-232) -> (assigned_atom int64[N], assigned_distance f64[N])."""
+    return _lib.atom_assign(bader_max, atoms, lattice)
+
+
+def volume_assign(volumes, swap, i_c=None):
+    """utils.volume_assign (utils.py:404-421): volumes[v] = swap[volumes[v]] for labels >= 0, in place."""
+    ctx = _lib.default_context()
+    if ctx.shape != tuple(volumes.shape):
+        ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
+    ctx.upload_labels(volumes)
+    ctx.volume_assign(swap)
+    ctx.download_labels(out=volumes)

@@ -1,0 +1,298 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against (a) golden vectors
+captured from the reference and (b) the CPU oracle on seeded inputs.  Integer maps bit-exact;
+charges/volumes to 1e-9 relative (north_star asks 1e-6)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import case_density, load_golden
+from pybader_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+FULL = ['c12_cubic', 'c64_cubic', 'c40x48x56_tric', 'c48_cubic_vac']
+MODES = {'ng_changed_2': ('changed', 2), 'ng_changed_inf': ('changed', -1), 'ng_all_inf': ('all', -1),
+         'ng_all_2': ('all', 2)}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def setup_case(ctx, name):
+    g = load_golden(name)
+    rho = case_density(g)
+    ctx.set_grid(rho.shape, g['dist_mat'], g['T_grad'])
+    ctx.upload_density(rho)
+    return g, rho
+
+
+def vac_tol(g):
+    t = float(g['vacuum_tol'])
+    return None if np.isnan(t) else t
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_device_synth_is_bit_identical(ctx, name):
+    g = load_golden(name)
+    rho = case_density(g)
+    ctx.set_grid(rho.shape, g['dist_mat'], g['T_grad'])
+    ctx.synth_density(g['lattice'], g['atoms'], float(g['background']))
+    assert np.array_equal(ctx.download_density(), rho)
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_vacuum_assign(ctx, name):
+    g, rho = setup_case(ctx, name)
+    vc, vv = ctx.vacuum_assign(vac_tol(g), float(g['voxel_volume']))
+    assert np.array_equal(ctx.download_labels(np.int8), g['ng_init'])
+    np.testing.assert_allclose([vc, vv], [float(g['vacuum_charge']), float(g['vacuum_volume'])], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_neargrid_assign_is_the_post_refinement_map(ctx, name):
+    """xb_assign(neargrid) == the reference's map after refinement (== its own-trajectory map F),
+    including the basin numbering and the maxima list."""
+    g, rho = setup_case(ctx, name)
+    ctx.vacuum_assign(vac_tol(g), float(g['voxel_volume']))
+    n = ctx.assign('neargrid')
+    assert n == g['ng_bader_max'].shape[0]
+    assert np.array_equal(ctx.maxima(), g['ng_bader_max'])
+    lab = ctx.download_labels(g['ng_F'].dtype)
+    assert np.array_equal(lab, g['ng_F'])
+    for key in MODES:
+        assert np.array_equal(lab, g[key]), key
+    # pre-refinement map of the sequential reference differs only where its refinement changes it
+    ndiff = int((lab != g['ng_main']).sum())
+    assert ndiff == int(g['ng_changed_2_log'][0, 1])
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_edge_find_on_reference_main_map(ctx, name):
+    g, rho = setup_case(ctx, name)
+    ctx.upload_labels(g['ng_main'])
+    edges = ctx.edge_find()
+    assert edges == int(g['ng_changed_2_log'][0, 0])
+    assert np.array_equal(ctx.download_known(), g['ng_known0'])
+
+
+@pytest.mark.parametrize('name', FULL)
+@pytest.mark.parametrize('key', list(MODES))
+def test_refine_from_reference_main_map(ctx, name, key):
+    """Start from the reference's sequential (order dependent) main-pass map and refine on the GPU:
+    per-iteration (edges, changed) counts and the final map must equal the reference's."""
+    g, rho = setup_case(ctx, name)
+    ctx.upload_labels(g['ng_main'])
+    log = ctx.refine(*MODES[key])
+    assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g[key + '_log'])
+    assert np.array_equal(ctx.download_labels(g[key].dtype), g[key])
+    if key == 'ng_changed_2':
+        assert np.array_equal(ctx.download_known(), g['ng_changed_2_known_last'])
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_full_pipeline_assign_refine_sums_atoms(ctx, name):
+    g, rho = setup_case(ctx, name)
+    vv = float(g['voxel_volume'])
+    ctx.vacuum_assign(vac_tol(g), vv)
+    n = ctx.assign('neargrid')
+    log = ctx.refine('changed', 2)
+    assert all(ch == 0 for _, ch in log)                # F is a fixed point of the refinement
+    lab = ctx.download_labels(g['ng_changed_2'].dtype)
+    assert np.array_equal(lab, g['ng_changed_2'])
+    ch, vo = ctx.charge_sum(vv, n)
+    np.testing.assert_allclose(ch, g['ng_bader_charge'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(vo, g['ng_bader_volume'], rtol=1e-9, atol=1e-12)
+    atoms_cart = synth.atoms_cartesian(g['atoms'], g['lattice'])
+    ba, bd = _lib.atom_assign(g['bader_maxima_cart'], atoms_cart, g['lattice'])
+    assert np.array_equal(ba, g['ng_bader_atoms'])
+    np.testing.assert_allclose(bd, g['ng_bader_distance'], rtol=1e-12, atol=1e-12)
+    ctx.volume_assign(ba)
+    assert np.array_equal(ctx.download_labels(g['ng_atoms_volumes'].dtype), g['ng_atoms_volumes'])
+    ach, avo = ctx.charge_sum(vv, atoms_cart.shape[0])
+    np.testing.assert_allclose(ach, g['ng_atoms_charge'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(avo, g['ng_atoms_volume'], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_ongrid_and_speed_profile(ctx, name):
+    g, rho = setup_case(ctx, name)
+    ctx.vacuum_assign(vac_tol(g), float(g['voxel_volume']))
+    n = ctx.assign('ongrid')
+    assert np.array_equal(ctx.maxima(), g['og_bader_max'])
+    assert np.array_equal(ctx.download_labels(g['og_main'].dtype), g['og_main'])
+    # BASELINE config 5: ongrid assign + neargrid edge refinement
+    log = ctx.refine('changed', 2)
+    assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['og_ngrefine_changed_2_log'])
+    assert np.array_equal(ctx.download_labels(g['og_main'].dtype), g['og_ngrefine_changed_2'])
+    # speed profile (entry_points.py:340-345): refine the int8 atom map with ('changed', 3)
+    ctx.upload_labels(g['og_atoms_volumes_pre'])
+    ctx.refine('changed', 3)
+    assert np.array_equal(ctx.download_labels(np.int8), g['og_atoms_volumes_speed'])
+
+
+@pytest.mark.parametrize('name', ['c128_tric', 'c256_cubic'])
+def test_large_golden_hashes(ctx, name):
+    g = load_golden(name)
+    shape = tuple(int(s) for s in g['shape'])
+    ctx.set_grid(shape, g['dist_mat'], g['T_grad'])
+    ctx.synth_density(g['lattice'], g['atoms'], float(g['background']))
+    vv = float(g['voxel_volume'])
+    ctx.vacuum_assign(None, vv)
+    n = ctx.assign('neargrid')
+    assert np.array_equal(ctx.maxima(), g['ng_bader_max'])
+    dt = np.int8
+    assert sha(ctx.download_labels(dt)) == str(g['ng_F_sha256'])
+    log = ctx.refine('changed', 2)
+    assert all(ch == 0 for _, ch in log)
+    assert sha(ctx.download_labels(dt)) == str(g['ng_changed_2_sha256'])
+    ch, vo = ctx.charge_sum(vv, n)
+    np.testing.assert_allclose(ch, g['ng_bader_charge'], rtol=1e-9)
+    np.testing.assert_allclose(vo, g['ng_bader_volume'], rtol=1e-9)
+    ctx.vacuum_assign(None, vv)
+    ctx.assign('ongrid')
+    assert sha(ctx.download_labels(dt)) == str(g['og_main_sha256'])
+    log = ctx.refine('changed', 2)
+    assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['og_ngrefine_changed_2_log'])
+    assert sha(ctx.download_labels(dt)) == str(g['og_ngrefine_changed_2_sha256'])
+
+
+# ---- seeded inputs against the CPU oracle ------------------------------------------------------
+def random_case(seed, shape):
+    rng = np.random.default_rng(seed)
+    lat = synth.CUBIC6 * (0.8 + 0.4 * rng.random()) + 0.8 * (rng.random((3, 3)) - 0.5)
+    na = int(rng.integers(3, 12))
+    atoms = np.concatenate([rng.random((na, 3)), 0.3 + 0.3 * rng.random((na, 1)), 1 + 7 * rng.random((na, 1))], axis=1)
+    rho = synth.synth_density(shape, lat, atoms)
+    from pybader_amd.interface import distance_matrix, gradient_transform
+    vl = np.divide(lat, shape)
+    return rho, lat, atoms, distance_matrix(vl), gradient_transform(vl)
+
+
+def rank_labels(F):
+    """labels from the own-trajectory map: rank of the smallest voxel index of each basin"""
+    flat = F.reshape(-1)
+    nv = flat >= 0
+    maxima, first = np.unique(flat[nv], return_index=True)
+    first = np.flatnonzero(nv)[first]
+    order = np.argsort(first)
+    rank = np.empty(maxima.shape[0], np.int64)
+    rank[order] = np.arange(maxima.shape[0])
+    lab = np.full(flat.shape, -1, np.int64)
+    lab[nv] = rank[np.searchsorted(maxima, flat[nv])]
+    return lab.reshape(F.shape), maxima[order]
+
+
+@pytest.mark.parametrize('seed,shape,tol', [(1, (24, 20, 28), None), (2, (33, 17, 19), None), (3, (30, 30, 30), 0.05),
+                                            (4, (48, 40, 36), None), (5, (16, 64, 9), 0.04)])
+def test_against_oracle_seeded(ctx, seed, shape, tol):
+    import oracle
+    rho, lat, atoms, dm, tg = random_case(seed, shape)
+    ctx.set_grid(shape, dm, tg)
+    ctx.upload_density(rho)
+    vol0 = np.zeros(shape, np.int32)
+    vol0, _, _ = oracle.vacuum_assign(rho, vol0, float('nan') if tol is None else tol, rho, 1.0)
+    ctx.vacuum_assign(tol, 1.0)
+    assert np.array_equal(ctx.download_labels(np.int32), vol0)
+    # neargrid: own-trajectory map
+    F = oracle.own_trajectory_map(rho, vol0, dm, tg)
+    want, maxima = rank_labels(F)
+    n = ctx.assign('neargrid')
+    got = ctx.download_labels(np.int64)
+    assert n == maxima.shape[0]
+    assert np.array_equal(np.ravel_multi_index(tuple(ctx.maxima().T), shape), maxima)
+    assert np.array_equal(got, want)
+    # the sequential reference path ends on the same map
+    bmax, main = oracle.bader_calc('neargrid', rho, vol0, dm, tg, 1)
+    v = main.copy()
+    oracle.refine('neargrid', ('all', -1), rho, v, dm, tg, 1)
+    assert np.array_equal(v.astype(np.int64), want), "oracle: sequential main+refine != own-trajectory map"
+    # refinement kernels from the order-dependent sequential main map, all modes
+    for mode in (('changed', 2), ('changed', -1), ('all', -1), ('all', 1), ('changed', 3)):
+        v = main.copy()
+        olog = []
+        oracle.refine('neargrid', mode, rho, v, dm, tg, 1, log=olog)
+        ctx.upload_labels(main)
+        glog = ctx.refine(*mode)
+        assert glog == [tuple(x) for x in olog], mode
+        assert np.array_equal(ctx.download_labels(main.dtype), v), mode
+    # ongrid + refinement from the ongrid map (many changed voxels: exercises edge_check)
+    bmax, omain = oracle.bader_calc('ongrid', rho, vol0, dm, tg, 1)
+    ctx.upload_labels(vol0)
+    ctx.assign('ongrid')
+    assert np.array_equal(ctx.maxima(), bmax)
+    assert np.array_equal(ctx.download_labels(omain.dtype), omain)
+    for mode in (('changed', 4), ('all', 3), ('changed', -1)):
+        v = omain.copy()
+        olog = []
+        oracle.refine('neargrid', mode, rho, v, dm, tg, 1, log=olog)
+        ctx.upload_labels(omain)
+        glog = ctx.refine(*mode)
+        assert glog == [tuple(x) for x in olog], mode
+        assert np.array_equal(ctx.download_labels(omain.dtype), v), mode
+
+
+def test_edge_check_kernel_level(ctx):
+    """edge_check alone on a hand-made `known`: every voxel of a random subset flagged changed."""
+    import oracle
+    rho, lat, atoms, dm, tg = random_case(11, (20, 22, 18))
+    vol0 = np.zeros(rho.shape, np.int32)
+    _, main = oracle.bader_calc('ongrid', rho, vol0, dm, tg, 1)
+    known = np.zeros(rho.shape, np.int8)
+    oracle.edge_find(known, rho, main)
+    rng = np.random.default_rng(5)
+    known[(known == -1) & (rng.random(rho.shape) < 0.3)] = -2     # pretend these changed
+    ctx.set_grid(rho.shape, dm, tg)
+    ctx.upload_density(rho)
+    ctx.upload_labels(main)
+    ctx.upload_known(known)
+    got = ctx.edge_check()
+    k2 = known.copy()
+    want = oracle.edge_check(k2, rho, main)
+    assert got == want
+    assert np.array_equal(ctx.download_known(), k2)
+
+
+def test_python_mirror_api(ctx):
+    """The reference-named Python layer (thread_handlers / interface) end to end on one golden case."""
+    from pybader_amd import thread_handlers
+    from pybader_amd.interface import Bader
+    thread_handlers.VERBOSE = False
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    atoms_cart = synth.atoms_cartesian(g['atoms'], g['lattice'])
+    b = Bader({'charge': rho}, g['lattice'], atoms_cart)
+    assert np.array_equal(b.distance_matrix, g['dist_mat']) and np.array_equal(b.T_grad, g['T_grad'])
+    b()
+    assert b.bader_volumes.dtype == g['ng_changed_2'].dtype
+    assert np.array_equal(b.bader_volumes, g['ng_changed_2'])
+    assert np.array_equal(b.atoms_volumes, g['ng_atoms_volumes'])
+    assert np.array_equal(b.bader_atoms, g['ng_bader_atoms'])
+    np.testing.assert_allclose(b.bader_maxima, g['bader_maxima_cart'], rtol=1e-14)
+    np.testing.assert_allclose(b.bader_charge, g['ng_bader_charge'], rtol=1e-9)
+    np.testing.assert_allclose(b.atoms_charge, g['ng_atoms_charge'], rtol=1e-9)
+    np.testing.assert_allclose(b.atoms_volume, g['ng_atoms_volume'], rtol=1e-9)
+    # kernel-level plugin signatures
+    from pybader_amd import methods, refinement
+    vol = np.zeros(rho.shape, np.int32)
+    vol, bmax, emax = methods.neargrid(rho, vol, np.zeros(3, np.int64), g['dist_mat'], g['T_grad'], np.zeros(1, np.int64))
+    assert np.array_equal(vol - 1, g['ng_F']) and np.array_equal(bmax, g['ng_bader_max']) and emax.shape == (0, 3)
+    known = np.zeros(rho.shape, np.int8)
+    main = g['ng_main'].copy()
+    assert refinement.edge_find(known, rho, main) == int(g['ng_changed_2_log'][0, 0])
+    known, changed = refinement.neargrid(known, known.copy(), rho, main, np.zeros(3, np.int64), g['dist_mat'],
+                                         g['T_grad'], np.zeros(1, np.int64))
+    assert changed == int(g['ng_changed_2_log'][0, 1])
+    # the reference's silent-return cases (thread_handlers.py:140-147)
+    v = g['ng_main'].copy()
+    assert thread_handlers.refine('ongrid', ('changed', 2), rho, v, g['dist_mat'], g['T_grad'], 1) is None
+    assert thread_handlers.refine('neargrid', ('changed', 0), rho, v, g['dist_mat'], g['T_grad'], 1) is None
+    assert np.array_equal(v, g['ng_main'])
