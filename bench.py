@@ -130,6 +130,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     which = 0 if args.method == 'neargrid' else 1
     k_ms, k_n = ctx.kernel_time(which)
+    gf_ms, gf_n = ctx.kernel_time(4)
     ef_ms, ef_n = ctx.kernel_time(2)
     rt_ms, rt_n = ctx.kernel_time(3)
     own_vox = nvox * (runner.x_range[1] - runner.x_range[0]) / shape[0]
@@ -162,7 +163,8 @@ def main():
                      'whole_path': {'bytes_per_voxel': BYTES_PATH,
                                     'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
                                     'frac': BYTES_PATH * nvox / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
-                     'other_kernels_ms_avg': {'edge_find': ef_ms / max(ef_n, 1), 'refine_trace': rt_ms / max(rt_n, 1)}},
+                     'other_kernels_ms_avg': {'grad_field': gf_ms / max(gf_n, 1), 'edge_find': ef_ms / max(ef_n, 1),
+                                              'refine_trace': rt_ms / max(rt_n, 1)}},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -121,7 +121,7 @@ int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that ho
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel, measured on the context's stream: accumulated
  * milliseconds and launch count since the last reset.  which: 0 neargrid trace, 1 ongrid pointer,
- * 2 edge_find, 3 refine trace. */
+ * 2 edge_find, 3 refine trace, 4 gradient-field table. */
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);

@@ -113,13 +113,37 @@ __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Gradient-field table: the normalised direction of the neargrid step at every voxel
+// (refinement.py:89-137) plus the density, 32 B per voxel.  One streaming stencil pass; the
+// direction does not depend on the carried remainder `dr`, so every trajectory step afterwards is
+// ONE 32-byte gather instead of seven 8-byte gathers and three float64 divisions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__restrict__ rho,
+                                                    GradRec *__restrict__ G) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= N) return;
+    const int v = (int)vv;
+    const int px = v / g.nyz;
+    const int r = v - px * g.nyz;
+    const int py = r / g.nz, pz = r - py * g.nz;
+    const double c = rho[v];
+    GradRec o;
+    const bool stay = ng_dir(rho, g, px, py, pz, v, c, o.d0, o.d1, o.d2);
+    if (stay) o.d0 = __builtin_nan("");
+    o.rho = c;
+    G[v] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
 // neargrid assignment: every owned non-vacuum voxel follows its own dr=0 trajectory
 // (refinement.py:17-322 stepping rules without the early stop) to the maximum it reaches.
 // One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
 // of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const double *__restrict__ rho, int *labels, int *first,
+__global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const GradRec *__restrict__ G,
+                                                  const double *__restrict__ rho, int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
                                                   int *ovf_count, int ovf_cap, int maxsteps) {
     const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
@@ -128,7 +152,8 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const double *__restri
     const int v = valid ? (int)vv : 0;
     int mode = TR_DONE, result = -1;
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0;
-    double c = 0., dr0 = 0., dr1 = 0., dr2 = 0.;
+    double dr0 = 0., dr1 = 0., dr2 = 0.;
+    GradRec rec = {0., 0., 0., 0.};
     PathWindow<K> w;
     w.init(0, 0.);
     if (valid && labels[v] != -1) {
@@ -137,25 +162,29 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const double *__restri
         py = r / g.nz;
         pz = r - py * g.nz;
         lp = v;
-        c = rho[v];
-        w.init(v, c);
+        rec = G[v];
+        w.init(v, rec.rho);
         mode = TR_STEP;
     }
     for (;;) {
         if (mode == TR_STEP) {
-            int qx, qy, qz;
-            const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
-            const int lq = lin3(g, qx, qy, qz);
-            if (stay || w.contains(lq)) {
-                mode = TR_NEED_OG;  // refinement.py:200: already been here on this path
+            if (rec.d0 != rec.d0) {
+                mode = TR_NEED_OG;  // max_grad < 1E-14: stays on p, which is on the path
             } else {
-                const double cq = rho[lq];
-                if (cq <= w.m_old || ++steps > maxsteps) {
-                    result = -2;  // membership undecidable from the window: exact slow kernel
-                    mode = TR_DONE;
+                int qx, qy, qz;
+                ng_move(g, px, py, pz, rec.d0, rec.d1, rec.d2, dr0, dr1, dr2, qx, qy, qz);
+                const int lq = lin3(g, qx, qy, qz);
+                if (w.contains(lq)) {
+                    mode = TR_NEED_OG;  // refinement.py:200: already been here on this path
                 } else {
-                    w.push(lq, cq);
-                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                    const GradRec nr = G[lq];
+                    if (nr.rho <= w.m_old || ++steps > maxsteps) {
+                        result = -2;  // membership undecidable from the window: exact slow kernel
+                        mode = TR_DONE;
+                    } else {
+                        w.push(lq, nr.rho);
+                        px = qx; py = qy; pz = qz; lp = lq; rec = nr;
+                    }
                 }
             }
         }
@@ -164,7 +193,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const double *__restri
             if (mode == TR_NEED_OG) {  // refinement.py:201-235: dr = 0, one ongrid step from p
                 int qx, qy, qz;
                 dr0 = dr1 = dr2 = 0.;
-                og_step(rho, g, px, py, pz, c, qx, qy, qz);
+                og_step(rho, g, px, py, pz, rec.rho, qx, qy, qz);
                 if (qx == px && qy == py && qz == pz) {
                     result = lp;  // break_flag: p is the maximum
                     mode = TR_DONE;
@@ -173,9 +202,9 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const double *__restri
                     mode = TR_DONE;
                 } else {  // refinement.py:305-315: appended without a membership test
                     const int lq = lin3(g, qx, qy, qz);
-                    const double cq = rho[lq];
-                    w.push(lq, cq);
-                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                    rec = G[lq];
+                    w.push(lq, rec.rho);
+                    px = qx; py = qy; pz = qz; lp = lq;
                     mode = TR_STEP;
                 }
             }
@@ -427,7 +456,8 @@ __global__ __launch_bounds__(TPB) void k_compact_known(Grid g, const int8_t *__r
 // +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const double *__restrict__ rho, int *labels,
+__global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const GradRec *__restrict__ G,
+                                                      const double *__restrict__ rho, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n,
                                                       int *changed, int *escaped, int *ovf_list, int *ovf_count,
                                                       int ovf_cap, int maxsteps) {
@@ -436,7 +466,8 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const double *__re
     const int v = valid ? list[t] : 0;
     int mode = TR_DONE, result = -3;  // result: terminal voxel index; -2 overflow; -4 escaped
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
-    double c = 0., dr0 = 0., dr1 = 0., dr2 = 0.;
+    double dr0 = 0., dr1 = 0., dr2 = 0.;
+    GradRec rec = {0., 0., 0., 0.};
     PathWindow<K> w;
     w.init(0, 0.);
     if (valid) {
@@ -445,26 +476,30 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const double *__re
         py = r / g.nz;
         pz = r - py * g.nz;
         lp = v;
-        c = rho[v];
+        rec = G[v];
         vol_num = labels[v];
-        w.init(v, c);
+        w.init(v, rec.rho);
         mode = TR_STEP;
     }
     for (;;) {
         if (mode == TR_STEP) {
-            int qx, qy, qz;
-            const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
-            const int lq = lin3(g, qx, qy, qz);
-            if (stay || w.contains(lq)) {
+            if (rec.d0 != rec.d0) {
                 mode = TR_NEED_OG;
             } else {
-                const double cq = rho[lq];
-                if (cq <= w.m_old || ++steps > maxsteps) { result = -2; mode = TR_DONE; }
-                else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
-                else if (known[lq] == 2) { result = lq; mode = TR_DONE; }  // refinement.py:294-303
-                else {
-                    w.push(lq, cq);
-                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                int qx, qy, qz;
+                ng_move(g, px, py, pz, rec.d0, rec.d1, rec.d2, dr0, dr1, dr2, qx, qy, qz);
+                const int lq = lin3(g, qx, qy, qz);
+                if (w.contains(lq)) {
+                    mode = TR_NEED_OG;
+                } else {
+                    const GradRec nr = G[lq];
+                    if (nr.rho <= w.m_old || ++steps > maxsteps) { result = -2; mode = TR_DONE; }
+                    else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
+                    else if (known[lq] == 2) { result = lq; mode = TR_DONE; }  // refinement.py:294-303
+                    else {
+                        w.push(lq, nr.rho);
+                        px = qx; py = qy; pz = qz; lp = lq; rec = nr;
+                    }
                 }
             }
         }
@@ -473,16 +508,16 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const double *__re
             if (mode == TR_NEED_OG) {
                 int qx, qy, qz;
                 dr0 = dr1 = dr2 = 0.;
-                og_step(rho, g, px, py, pz, c, qx, qy, qz);
+                og_step(rho, g, px, py, pz, rec.rho, qx, qy, qz);
                 const int lq = lin3(g, qx, qy, qz);
                 if (qx == px && qy == py && qz == pz) { result = lp; mode = TR_DONE; }  // refinement.py:283-292
                 else if (++steps > maxsteps) { result = -2; mode = TR_DONE; }
                 else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
                 else if (known[lq] == 2) { result = lq; mode = TR_DONE; }
                 else {
-                    const double cq = rho[lq];
-                    w.push(lq, cq);
-                    px = qx; py = qy; pz = qz; lp = lq; c = cq;
+                    rec = G[lq];
+                    w.push(lq, rec.rho);
+                    px = qx; py = qy; pz = qz; lp = lq;
                     mode = TR_STEP;
                 }
             }
@@ -698,6 +733,8 @@ struct xb_ctx {
     long long N = 0;
     int halo = 0;
     double *rho = nullptr;
+    GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
+    bool grad_valid = false;
     int *labels = nullptr;
     int8_t *known = nullptr;
     int *first = nullptr;      // n^3: min voxel per maximum, then rank per maximum
@@ -718,7 +755,7 @@ struct xb_ctx {
     std::vector<int> local_max, local_first;
     bool first_clean = false;
     bool timing = false;
-    TimedKernel tk[4];
+    TimedKernel tk[5];
     long long n_alloc = 0;
 };
 
@@ -774,9 +811,9 @@ int xb_create(int device, xb_ctx **out) {
 }
 
 static void free_grid(xb_ctx *c) {
-    hipFree(c->rho); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
+    hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
     hipFree(c->st); hipFree(c->stage); hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
-    c->rho = nullptr; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
+    c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
 }
@@ -825,6 +862,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     if (N != c->n_alloc) {
         free_grid(c);
         HIPCHK(hipMalloc(&c->rho, N * sizeof(double)));
+        HIPCHK(hipMalloc(&c->grad, N * sizeof(GradRec)));
         HIPCHK(hipMalloc(&c->labels, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->known, N));
         HIPCHK(hipMalloc(&c->first, N * sizeof(int)));
@@ -841,11 +879,12 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
         c->first_clean = false;
     }
     Grid &g = c->g;
+    if (g.nx != (int)shape[0] || g.ny != (int)shape[1] || g.nz != (int)shape[2]) c->grad_valid = false;
     g.nx = (int)shape[0]; g.ny = (int)shape[1]; g.nz = (int)shape[2];
     g.nyz = g.ny * g.nz;
     g.x0 = (int)x0; g.x1 = (int)x1;
     if (dist_mat) memcpy(g.dist, dist_mat, sizeof g.dist);
-    if (T_grad) memcpy(g.T, T_grad, sizeof g.T);
+    if (T_grad && memcmp(g.T, T_grad, sizeof g.T) != 0) { memcpy(g.T, T_grad, sizeof g.T); c->grad_valid = false; }
     c->N = N;
     c->halo = (x0 == 0 && x1 == shape[0]) ? g.nx : 0;
     set_valid_range(c);
@@ -873,6 +912,7 @@ int xb_set_halo(xb_ctx *c, int64_t halo) {
 
 int xb_upload_density(xb_ctx *c, const double *rho_host) {
     NEED_GRID("xb_upload_density");
+    c->grad_valid = false;
     HIPCHK(hipMemcpyAsync(c->rho, rho_host, c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;
@@ -887,6 +927,7 @@ int xb_download_density(xb_ctx *c, double *rho_host) {
 int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, int64_t n_atoms, double background) {
     NEED_GRID("xb_synth_density");
     if (n_atoms < 0 || n_atoms > 4096) return fail(XB_E_ARG, "xb_synth_density: bad atom count");
+    c->grad_valid = false;
     double *tmp = (double *)c->stage;
     HIPCHK(hipMemcpyAsync(tmp, lattice, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(tmp + 16, atoms5, n_atoms * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -959,6 +1000,18 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
     return XB_OK;
 }
 
+// (re)build the gradient-field table from the resident density
+static int ensure_grad(xb_ctx *c, bool force) {
+    if (c->grad_valid && !force) return XB_OK;
+    {
+        ScopedTimer t(c, 4);
+        k_grad_field<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, c->rho, c->grad);
+    }
+    HIPCHK(hipGetLastError());
+    c->grad_valid = true;
+    return XB_OK;
+}
+
 static int read_counter(xb_ctx *c, int idx, int *out) {
     HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1001,9 +1054,12 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     c->first_clean = false;
     if (method == XB_METHOD_NEARGRID) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        // the table is a pure function of the resident density, but it is part of the assignment
+        // work: rebuilt on every call, never carried over from a previous assignment
+        if (int rc = ensure_grad(c, true)) return rc;
         {
             ScopedTimer t(c, 0);
-            k_ng_trace<4><<<nblocks(own), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->first, c->max_list,
+            k_ng_trace<2><<<nblocks(own), TPB, 0, c->stream>>>(g, c->grad, c->rho, c->labels, c->first, c->max_list,
                                                                c->counters + 0, c->max_cap, c->ovf_list,
                                                                c->counters + 1, c->ovf_cap, maxsteps);
         }
@@ -1151,9 +1207,10 @@ int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) {
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        if (int rc = ensure_grad(c, false)) return rc;
         {
             ScopedTimer t(c, 3);
-            k_refine_trace<4><<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n,
+            k_refine_trace<2><<<nblocks(n), TPB, 0, c->stream>>>(g, c->grad, c->rho, c->labels, c->known, c->list, n,
                                                                 c->counters + 2, c->counters + 3, c->ovf_list,
                                                                 c->counters + 1, c->ovf_cap, maxsteps);
         }
@@ -1343,7 +1400,7 @@ int xb_kernel_time_reset(xb_ctx *c) {
     return XB_OK;
 }
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches) {
-    if (!c || which < 0 || which > 3) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
+    if (!c || which < 0 || which > 4) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     TimedKernel &t = c->tk[which];

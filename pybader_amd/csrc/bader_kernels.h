@@ -29,12 +29,12 @@ __device__ __forceinline__ bool plane_valid(const Grid &g, int x) {
 // round-half-away-from-zero by a truncating cast: methods.py:347-350 / refinement.py:138-141
 __device__ __forceinline__ int rha(double x) { return x > 0 ? (int)(x + .5) : (int)(x - .5); }
 
-// One neargrid step (refinement.py:89-154, the strict tie test `<  >` of line 111) from voxel
-// (px,py,pz) whose density is c, carrying the remainder dr.  Returns true when
-// max_grad < 1E-14 (refinement.py:132-134: no move, dr untouched); else q/dr hold the new state.
-__device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Grid &g, int px, int py, int pz,
-                                        int lp, double c, double &dr0, double &dr1, double &dr2, int &qx,
-                                        int &qy, int &qz) {
+// Direction part of one neargrid step (refinement.py:89-137, the strict tie test `<  >` of line
+// 111): the normalised gradient direction grad_dir / max_grad at voxel p.  It depends on rho only
+// (not on the carried remainder dr), so it is precomputed once per voxel by k_grad_field.
+// Returns true when max_grad < 1E-14 (refinement.py:132-134: the trajectory does not move).
+__device__ __forceinline__ bool ng_dir(const double *__restrict__ rho, const Grid &g, int px, int py, int pz,
+                                       int lp, double c, double &d0, double &d1, double &d2) {
     const int xp = wrapi(px + 1, g.nx), xm = wrapi(px - 1, g.nx);
     const int yp = wrapi(py + 1, g.ny), ym = wrapi(py - 1, g.ny);
     const int zp = wrapi(pz + 1, g.nz), zm = wrapi(pz - 1, g.nz);
@@ -46,25 +46,43 @@ __device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Gr
     const double g1 = (hy < c && c > ly) ? 0. : (hy - ly) / 2.;
     const double g2 = (hz < c && c > lz) ? 0. : (hz - lz) / 2.;
     // refinement.py:123-130: grad_dir = T_grad . grad with (a+b)+c association
-    double d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
-    double d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
-    double d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
+    d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
+    d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
+    d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
     double mg = 0.;
     if (d0 > mg) mg = d0; else if (-d0 > mg) mg = -d0;
     if (d1 > mg) mg = d1; else if (-d1 > mg) mg = -d1;
     if (d2 > mg) mg = d2; else if (-d2 > mg) mg = -d2;
-    if (mg < 1E-14) { qx = px; qy = py; qz = pz; return true; }
-    // refinement.py:136-154
-    d0 /= mg; d1 /= mg; d2 /= mg;
-    int ig, id;
-    ig = rha(d0); qx = px + ig; dr0 += d0 - (double)ig; id = rha(dr0); qx += id; dr0 -= (double)id;
-    ig = rha(d1); qy = py + ig; dr1 += d1 - (double)ig; id = rha(dr1); qy += id; dr1 -= (double)id;
-    ig = rha(d2); qz = pz + ig; dr2 += d2 - (double)ig; id = rha(dr2); qz += id; dr2 -= (double)id;
-    if (qx >= g.nx) qx -= g.nx; else if (qx < 0) qx += g.nx;
-    if (qy >= g.ny) qy -= g.ny; else if (qy < 0) qy += g.ny;
-    if (qz >= g.nz) qz -= g.nz; else if (qz < 0) qz += g.nz;
+    if (mg < 1E-14) return true;
+    d0 /= mg; d1 /= mg; d2 /= mg;  // refinement.py:137, true division
     return false;
 }
+
+// Move part (refinement.py:138-154): step = rha(dir), dr += dir - step, corr = rha(dr),
+// q = p + step + corr (wrapped), dr -= corr.  rha(x) == (int)(x + copysign(.5, x)) for every x.
+__device__ __forceinline__ int rha_cs(double x) { return (int)(x + __builtin_copysign(0.5, x)); }
+__device__ __forceinline__ void ng_move(const Grid &g, int px, int py, int pz, double d0, double d1, double d2,
+                                        double &dr0, double &dr1, double &dr2, int &qx, int &qy, int &qz) {
+    int ig, id;
+    ig = rha_cs(d0); dr0 += d0 - (double)ig; id = rha_cs(dr0); qx = px + ig + id; dr0 -= (double)id;
+    ig = rha_cs(d1); dr1 += d1 - (double)ig; id = rha_cs(dr1); qy = py + ig + id; dr1 -= (double)id;
+    ig = rha_cs(d2); dr2 += d2 - (double)ig; id = rha_cs(dr2); qz = pz + ig + id; dr2 -= (double)id;
+    qx = wrapi(qx, g.nx); qy = wrapi(qy, g.ny); qz = wrapi(qz, g.nz);
+}
+
+// One whole neargrid step computed from rho directly (used by the exact slow kernel).
+__device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Grid &g, int px, int py, int pz,
+                                        int lp, double c, double &dr0, double &dr1, double &dr2, int &qx,
+                                        int &qy, int &qz) {
+    double d0, d1, d2;
+    if (ng_dir(rho, g, px, py, pz, lp, c, d0, d1, d2)) { qx = px; qy = py; qz = pz; return true; }
+    ng_move(g, px, py, pz, d0, d1, d2, dr0, dr1, dr2, qx, qy, qz);
+    return false;
+}
+
+// Per-voxel record of the gradient-field table: normalised direction + the density itself.
+// dir.x is NaN when the trajectory does not move from this voxel (max_grad < 1E-14).
+struct __attribute__((aligned(32))) GradRec { double d0, d1, d2, rho; };
 
 // One ongrid step (methods.py:84-117; refinement.py:204-235): the best of the 27 neighbours by
 // (rho(n)-rho(p))*dist_mat + rho(p), strict '>', first wins in (ix,iy,iz) ascending order.
