@@ -125,6 +125,8 @@ int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that ho
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);
+/* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order) */
+int xb_set_option(xb_ctx *c, int key, int value);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ SYMBOLS = {
     'xb_kernel_time': (_int, [_vp, _int, _pdbl, _pi64]),
     'xb_kernel_time_reset': (_int, [_vp]),
     'xb_enable_timing': (_int, [_vp, _int]),
+    'xb_set_option': (_int, [_vp, _int, _int]),
 }
 
 _lib = None
@@ -241,6 +242,9 @@ class Context:
 
     def kernel_time_reset(self):
         check(self.lib.xb_kernel_time_reset(self.h))
+
+    def set_option(self, key, value):
+        check(self.lib.xb_set_option(self.h, int(key), int(value)))
 
     def sync(self):
         check(self.lib.xb_sync(self.h))

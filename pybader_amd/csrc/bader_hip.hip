@@ -97,8 +97,8 @@ __device__ __forceinline__ void note_maximum(int m, int v, int *first, int *max_
     }
 }
 
-// Wave-aggregated note_maximum: lanes are consecutive voxel indices, so per distinct maximum only
-// the lowest lane needs to touch memory.
+// Wave-aggregated note_maximum: per distinct maximum in the wave, one lane reports the smallest
+// voxel index of the lanes that reached it.
 __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *first, int *max_list,
                                                   int *max_count, int max_cap) {
     unsigned long long todo = __ballot(has);
@@ -106,9 +106,12 @@ __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *f
     while (todo) {
         const int leader = __ffsll((unsigned long long)todo) - 1;
         const int lm = __shfl(m, leader);
-        const unsigned long long grp = __ballot(has && m == lm);
-        if (lane == leader) note_maximum(m, v, first, max_list, max_count, max_cap);
-        todo &= ~grp;
+        const bool mine = has && m == lm;
+        int vmin = mine ? v : XB_INT_MAX;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmin = min(vmin, __shfl_xor(vmin, o));
+        if (lane == leader) note_maximum(lm, vmin, first, max_list, max_count, max_cap);
+        todo &= ~__ballot(mine);
     }
 }
 
@@ -129,9 +132,28 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
     const int py = r / g.nz, pz = r - py * g.nz;
     const double c = rho[v];
     GradRec o;
-    const bool stay = ng_dir(rho, g, px, py, pz, v, c, o.d0, o.d1, o.d2);
-    if (stay) o.d0 = __builtin_nan("");
-    o.rho = c;
+    double d0, d1, d2;
+    int code;
+    if (ng_dir(rho, g, px, py, pz, v, c, d0, d1, d2)) {
+        // the trajectory stays on p, p is on its path, so the reference resets dr and takes one
+        // ongrid step from p (refinement.py:200-235).  That step is memoryless: tabulate its target
+        // (== p itself when p is a maximum).
+        int qx, qy, qz;
+        og_step(rho, g, g.dist, px, py, pz, c, qx, qy, qz);
+        o.r0 = (double)lin3(g, qx, qy, qz);
+        o.r1 = 0.;
+        o.r2 = 0.;
+        code = XB_STAY_CODE;
+    } else {
+        // refinement.py:138-143: int_grad = rha(grad_dir); the remainder grad_dir - int_grad is what
+        // every trajectory through p adds to its dr
+        const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
+        o.r0 = d0 - (double)i0;
+        o.r1 = d1 - (double)i1;
+        o.r2 = d2 - (double)i2;
+        code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
+    }
+    o.key = pack_key(c, code);
     G[v] = o;
 }
 
@@ -142,14 +164,37 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
 // of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const GradRec *__restrict__ G,
-                                                  const double *__restrict__ rho, int *labels, int *first,
+__global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
+                                                  const double *__restrict__ rho,
+                                                  const double *__restrict__ dist, int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
-                                                  int *ovf_count, int ovf_cap, int maxsteps) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    const bool valid = vv < vend;
-    const int v = valid ? (int)vv : 0;
+                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt) {
+    // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
+    // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
+    // whose trajectories read the same table lines -- share one L2.
+    int blk = blockIdx.x;
+    if (opt & 2) {
+        const int per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
+    }
+    const int wave = blk * (TPB / XB_WAVE) + threadIdx.x / XB_WAVE;
+    const int lane = threadIdx.x % XB_WAVE;
+    int sx, sy, sz;
+    if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
+        const int bz_n = (g.nz + 3) >> 2, by_n = (g.ny + 3) >> 2;
+        const int bx = wave / (by_n * bz_n);
+        const int brem = wave - bx * (by_n * bz_n);
+        const int by = brem / bz_n, bz = brem - by * bz_n;
+        sx = g.x0 + bx * 4 + (lane >> 4); sy = by * 4 + ((lane >> 2) & 3); sz = bz * 4 + (lane & 3);
+    } else {        // one wave = a run of 64 voxels along z
+        const int rz_n = (g.nz + 63) >> 6;
+        const int row = wave / rz_n;
+        sz = (wave - row * rz_n) * 64 + lane;
+        sx = g.x0 + row / g.ny;
+        sy = row - (row / g.ny) * g.ny;
+    }
+    const bool valid = sx < g.x1 && sy < g.ny && sz < g.nz;
+    const int v = valid ? (sx * g.ny + sy) * g.nz + sz : 0;
     int mode = TR_DONE, result = -1;
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0;
     double dr0 = 0., dr1 = 0., dr2 = 0.;
@@ -157,32 +202,48 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const GradRec *__restr
     PathWindow<K> w;
     w.init(0, 0.);
     if (valid && labels[v] != -1) {
-        px = v / g.nyz;
-        const int r = v - px * g.nyz;
-        py = r / g.nz;
-        pz = r - py * g.nz;
+        px = sx; py = sy; pz = sz;
         lp = v;
         rec = G[v];
-        w.init(v, rec.rho);
+        w.init(v, rec.key);
         mode = TR_STEP;
     }
     for (;;) {
         if (mode == TR_STEP) {
-            if (rec.d0 != rec.d0) {
-                mode = TR_NEED_OG;  // max_grad < 1E-14: stays on p, which is on the path
+            const int code = key_code(rec.key);
+            if (code == XB_STAY_CODE) {
+                // max_grad < 1E-14: the trajectory stays on p, which is on its path => dr = 0 and
+                // one ongrid step (refinement.py:200-235), tabulated by k_grad_field
+                const int lq = (int)rec.r0;
+                if (lq == lp) {
+                    result = lp;  // break_flag: p is the maximum
+                    mode = TR_DONE;
+                } else if (++steps > maxsteps) {
+                    result = -2;
+                    mode = TR_DONE;
+                } else {  // refinement.py:305-315: appended without a membership test
+                    dr0 = dr1 = dr2 = 0.;
+                    px = lq / g.nyz;
+                    const int r = lq - px * g.nyz;
+                    py = r / g.nz;
+                    pz = r - py * g.nz;
+                    lp = lq;
+                    rec = G[lq];
+                    w.push(lq, rec.key);
+                }
             } else {
                 int qx, qy, qz;
-                ng_move(g, px, py, pz, rec.d0, rec.d1, rec.d2, dr0, dr1, dr2, qx, qy, qz);
-                const int lq = lin3(g, qx, qy, qz);
+                ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
+                const int lq = lin3f(g, qx, qy, qz);
                 if (w.contains(lq)) {
                     mode = TR_NEED_OG;  // refinement.py:200: already been here on this path
                 } else {
                     const GradRec nr = G[lq];
-                    if (nr.rho <= w.m_old || ++steps > maxsteps) {
+                    if (nr.key <= w.m_old || ++steps > maxsteps) {
                         result = -2;  // membership undecidable from the window: exact slow kernel
                         mode = TR_DONE;
                     } else {
-                        w.push(lq, nr.rho);
+                        w.push(lq, nr.key);
                         px = qx; py = qy; pz = qz; lp = lq; rec = nr;
                     }
                 }
@@ -193,17 +254,17 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(Grid g, const GradRec *__restr
             if (mode == TR_NEED_OG) {  // refinement.py:201-235: dr = 0, one ongrid step from p
                 int qx, qy, qz;
                 dr0 = dr1 = dr2 = 0.;
-                og_step(rho, g, px, py, pz, rec.rho, qx, qy, qz);
+                og_step(rho, g, dist, px, py, pz, rho[lp], qx, qy, qz);
                 if (qx == px && qy == py && qz == pz) {
-                    result = lp;  // break_flag: p is the maximum
+                    result = lp;
                     mode = TR_DONE;
                 } else if (++steps > maxsteps) {
                     result = -2;
                     mode = TR_DONE;
-                } else {  // refinement.py:305-315: appended without a membership test
-                    const int lq = lin3(g, qx, qy, qz);
+                } else {
+                    const int lq = lin3f(g, qx, qy, qz);
                     rec = G[lq];
-                    w.push(lq, rec.rho);
+                    w.push(lq, rec.key);
                     px = qx; py = qy; pz = qz; lp = lq;
                     mode = TR_STEP;
                 }
@@ -246,7 +307,7 @@ __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels
         for (int k = np - 1; k >= 0 && !on_path; k--) on_path = (P[k] == lq);
         if (on_path) {
             dr0 = dr1 = dr2 = 0.;
-            og_step(rho, g, px, py, pz, c, qx, qy, qz);
+            og_step(rho, g, g.dist, px, py, pz, c, qx, qy, qz);
             lq = lin3(g, qx, qy, qz);
             if (qx == px && qy == py && qz == pz) { result = lp; break; }
         }
@@ -283,7 +344,7 @@ __global__ __launch_bounds__(TPB) void k_og_pointer(Grid g, const double *__rest
     const int r = v - px * g.nyz;
     const int py = r / g.nz, pz = r - py * g.nz;
     int qx, qy, qz;
-    og_step(rho, g, px, py, pz, rho[v], qx, qy, qz);
+    og_step(rho, g, g.dist, px, py, pz, rho[v], qx, qy, qz);
     labels[v] = lin3(g, qx, qy, qz);
 }
 // A chain that steps onto a vacuum voxel inherits -1 (methods.py:166-168).  In-place and
@@ -456,8 +517,9 @@ __global__ __launch_bounds__(TPB) void k_compact_known(Grid g, const int8_t *__r
 // +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const GradRec *__restrict__ G,
-                                                      const double *__restrict__ rho, int *labels,
+__global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G,
+                                                      const double *__restrict__ rho,
+                                                      const double *__restrict__ dist, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n,
                                                       int *changed, int *escaped, int *ovf_list, int *ovf_count,
                                                       int ovf_cap, int maxsteps) {
@@ -478,26 +540,43 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const GradRec *__r
         lp = v;
         rec = G[v];
         vol_num = labels[v];
-        w.init(v, rec.rho);
+        w.init(v, rec.key);
         mode = TR_STEP;
     }
     for (;;) {
         if (mode == TR_STEP) {
-            if (rec.d0 != rec.d0) {
-                mode = TR_NEED_OG;
+            const int code = key_code(rec.key);
+            if (code == XB_STAY_CODE) {
+                // stays on p (on its path): dr = 0 + the tabulated ongrid step (refinement.py:200-235)
+                const int lq = (int)rec.r0;
+                if (lq == lp) { result = lp; mode = TR_DONE; }  // a maximum: refinement.py:283-292
+                else {
+                    const int qx = lq / g.nyz;
+                    if (++steps > maxsteps) { result = -2; mode = TR_DONE; }
+                    else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
+                    else if (known[lq] == 2) { result = lq; mode = TR_DONE; }
+                    else {
+                        dr0 = dr1 = dr2 = 0.;
+                        const int r = lq - qx * g.nyz;
+                        px = qx; py = r / g.nz; pz = r - py * g.nz;
+                        lp = lq;
+                        rec = G[lq];
+                        w.push(lq, rec.key);
+                    }
+                }
             } else {
                 int qx, qy, qz;
-                ng_move(g, px, py, pz, rec.d0, rec.d1, rec.d2, dr0, dr1, dr2, qx, qy, qz);
-                const int lq = lin3(g, qx, qy, qz);
+                ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
+                const int lq = lin3f(g, qx, qy, qz);
                 if (w.contains(lq)) {
                     mode = TR_NEED_OG;
                 } else {
                     const GradRec nr = G[lq];
-                    if (nr.rho <= w.m_old || ++steps > maxsteps) { result = -2; mode = TR_DONE; }
+                    if (nr.key <= w.m_old || ++steps > maxsteps) { result = -2; mode = TR_DONE; }
                     else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
                     else if (known[lq] == 2) { result = lq; mode = TR_DONE; }  // refinement.py:294-303
                     else {
-                        w.push(lq, nr.rho);
+                        w.push(lq, nr.key);
                         px = qx; py = qy; pz = qz; lp = lq; rec = nr;
                     }
                 }
@@ -508,15 +587,15 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(Grid g, const GradRec *__r
             if (mode == TR_NEED_OG) {
                 int qx, qy, qz;
                 dr0 = dr1 = dr2 = 0.;
-                og_step(rho, g, px, py, pz, rec.rho, qx, qy, qz);
-                const int lq = lin3(g, qx, qy, qz);
+                og_step(rho, g, dist, px, py, pz, rho[lp], qx, qy, qz);
+                const int lq = lin3f(g, qx, qy, qz);
                 if (qx == px && qy == py && qz == pz) { result = lp; mode = TR_DONE; }  // refinement.py:283-292
                 else if (++steps > maxsteps) { result = -2; mode = TR_DONE; }
                 else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
                 else if (known[lq] == 2) { result = lq; mode = TR_DONE; }
                 else {
                     rec = G[lq];
-                    w.push(lq, rec.rho);
+                    w.push(lq, rec.key);
                     px = qx; py = qy; pz = qz; lp = lq;
                     mode = TR_STEP;
                 }
@@ -734,6 +813,7 @@ struct xb_ctx {
     int halo = 0;
     double *rho = nullptr;
     GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
+    double *dist_dev = nullptr; // dist_mat on the device (rare ongrid steps inside the trace kernels)
     bool grad_valid = false;
     int *labels = nullptr;
     int8_t *known = nullptr;
@@ -755,11 +835,19 @@ struct xb_ctx {
     std::vector<int> local_max, local_first;
     bool first_clean = false;
     bool timing = false;
+    int opt_trace = 3;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
     TimedKernel tk[5];
     long long n_alloc = 0;
 };
 
 static inline unsigned nblocks(long long n) { return (unsigned)((n + TPB - 1) / TPB); }
+static GridL light(const Grid &g) {
+    GridL l;
+    l.nx = g.nx; l.ny = g.ny; l.nz = g.nz; l.nyz = g.nyz;
+    l.x0 = g.x0; l.x1 = g.x1; l.vx0 = g.vx0; l.vlen = g.vlen;
+    l.use24 = ((long long)g.nx * g.ny < (1 << 24)) && g.nz < (1 << 24);
+    return l;
+}
 
 struct ScopedTimer {
     xb_ctx *c;
@@ -805,6 +893,7 @@ int xb_create(int device, xb_ctx **out) {
     HIPCHK(hipMalloc(&c->counters, 64 * sizeof(int)));
     HIPCHK(hipMalloc(&c->counters64, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->dsum, 16 * sizeof(double)));
+    HIPCHK(hipMalloc(&c->dist_dev, 27 * sizeof(double)));
     HIPCHK(hipHostMalloc(&c->host_ints, 64 * sizeof(long long)));
     *out = c;
     return XB_OK;
@@ -825,7 +914,7 @@ void xb_destroy(xb_ctx *c) {
     for (auto &t : c->tk)
         for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     free_grid(c);
-    hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum);
+    hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum); hipFree(c->dist_dev);
     hipHostFree(c->host_ints);
     hipStreamDestroy(c->stream);
     delete c;
@@ -883,7 +972,11 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     g.nx = (int)shape[0]; g.ny = (int)shape[1]; g.nz = (int)shape[2];
     g.nyz = g.ny * g.nz;
     g.x0 = (int)x0; g.x1 = (int)x1;
-    if (dist_mat) memcpy(g.dist, dist_mat, sizeof g.dist);
+    if (dist_mat) {
+        memcpy(g.dist, dist_mat, sizeof g.dist);
+        HIPCHK(hipMemcpyAsync(c->dist_dev, dist_mat, sizeof g.dist, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (T_grad && memcmp(g.T, T_grad, sizeof g.T) != 0) { memcpy(g.T, T_grad, sizeof g.T); c->grad_valid = false; }
     c->N = N;
     c->halo = (x0 == 0 && x1 == shape[0]) ? g.nx : 0;
@@ -1059,9 +1152,13 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         if (int rc = ensure_grad(c, true)) return rc;
         {
             ScopedTimer t(c, 0);
-            k_ng_trace<2><<<nblocks(own), TPB, 0, c->stream>>>(g, c->grad, c->rho, c->labels, c->first, c->max_list,
-                                                               c->counters + 0, c->max_cap, c->ovf_list,
-                                                               c->counters + 1, c->ovf_cap, maxsteps);
+            const int opt = c->opt_trace;
+            const long long waves = (opt & 1)
+                ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
+                : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
+            k_ng_trace<2><<<(unsigned)((waves + TPB / XB_WAVE - 1) / (TPB / XB_WAVE)), TPB, 0, c->stream>>>(
+                light(g), c->grad, c->rho, c->dist_dev, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
+                c->counters + 1, c->ovf_cap, maxsteps, opt);
         }
         HIPCHK(hipGetLastError());
         int novf = 0;
@@ -1210,7 +1307,7 @@ int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) {
         if (int rc = ensure_grad(c, false)) return rc;
         {
             ScopedTimer t(c, 3);
-            k_refine_trace<2><<<nblocks(n), TPB, 0, c->stream>>>(g, c->grad, c->rho, c->labels, c->known, c->list, n,
+            k_refine_trace<2><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->rho, c->dist_dev, c->labels, c->known, c->list, n,
                                                                 c->counters + 2, c->counters + 3, c->ovf_list,
                                                                 c->counters + 1, c->ovf_cap, maxsteps);
         }
@@ -1382,6 +1479,12 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     return XB_OK;
 }
 
+int xb_set_option(xb_ctx *c, int key, int value) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    if (key == 0) c->opt_trace = value;
+    else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
+    return XB_OK;
+}
 int xb_enable_timing(xb_ctx *c, int on) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     c->timing = on != 0;

@@ -16,12 +16,20 @@ struct Grid {
     double dist[27];  // dist_mat [3][3][3], index 2 == -1 (interface.py:242-259)
 };
 
+// What the trace kernels need of Grid (keeps their SGPR count low: more waves per SIMD).
+struct GridL {
+    int nx, ny, nz, nyz;
+    int x0, x1, vx0, vlen;
+    int use24;        // nx*ny < 2^24 and nz < 2^24: linear indices via 24-bit multiplies
+};
+
 #define XB_INT_MAX 0x7fffffff
 #define XB_WAVE 64
 
 __device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 __device__ __forceinline__ int lin3(const Grid &g, int x, int y, int z) { return (x * g.ny + y) * g.nz + z; }
-__device__ __forceinline__ bool plane_valid(const Grid &g, int x) {
+template <typename GT>
+__device__ __forceinline__ bool plane_valid(const GT &g, int x) {
     int d = x - g.vx0;
     if (d < 0) d += g.nx;
     return d < g.vlen;
@@ -80,14 +88,46 @@ __device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Gr
     return false;
 }
 
-// Per-voxel record of the gradient-field table: normalised direction + the density itself.
-// dir.x is NaN when the trajectory does not move from this voxel (max_grad < 1E-14).
-struct __attribute__((aligned(32))) GradRec { double d0, d1, d2, rho; };
+// Per-voxel record of the gradient-field table (32 B, one aligned gather per trajectory step):
+//   r0,r1,r2  remainder part of the normalised direction, grad_dir - int_grad (refinement.py:143),
+//             exactly as the reference forms it (one float64 subtraction)
+//   key       the density with its 6 lowest mantissa bits replaced by the packed integer step
+//             int_grad+1 (2 bits per axis); all ones (63) flags a voxel the trajectory does not
+//             leave (max_grad < 1E-14), whose tabulated ongrid successor index is then in r0.
+// `key` orders path voxels for the window test only (any fixed per-voxel function keeps that test
+// sound, see PathWindow); the exact density for the ongrid step is read from rho itself.
+struct __attribute__((aligned(32))) GradRec { double r0, r1, r2, key; };
+#define XB_STAY_CODE 63
+
+__device__ __forceinline__ double pack_key(double rho, int code) {
+    return __longlong_as_double((__double_as_longlong(rho) & ~63LL) | (long long)code);
+}
+__device__ __forceinline__ int key_code(double key) { return (int)(__double_as_longlong(key) & 63LL); }
+
+// wrap q in [-n, 2n) into [0, n) with two unsigned minima
+__device__ __forceinline__ int wrap_u(int q, int n) {
+    unsigned u = min((unsigned)q, (unsigned)(q + n));
+    return (int)min(u, u - (unsigned)n);
+}
+__device__ __forceinline__ int lin3f(const GridL &g, int x, int y, int z) {
+    if (g.use24) return (int)__umul24(__umul24(x, g.ny) + y, g.nz) + z;
+    return (x * g.ny + y) * g.nz + z;
+}
+// Table-driven move (refinement.py:142-154): dr += r; corr = rha(dr); q = p + step + corr; dr -= corr.
+__device__ __forceinline__ void ng_move_t(const GridL &g, int px, int py, int pz, const GradRec &rec, int code,
+                                          double &dr0, double &dr1, double &dr2, int &qx, int &qy, int &qz) {
+    int id;
+    dr0 += rec.r0; id = rha_cs(dr0); qx = px + ((code & 3) - 1) + id; dr0 -= (double)id;
+    dr1 += rec.r1; id = rha_cs(dr1); qy = py + (((code >> 2) & 3) - 1) + id; dr1 -= (double)id;
+    dr2 += rec.r2; id = rha_cs(dr2); qz = pz + ((code >> 4) - 1) + id; dr2 -= (double)id;
+    qx = wrap_u(qx, g.nx); qy = wrap_u(qy, g.ny); qz = wrap_u(qz, g.nz);
+}
 
 // One ongrid step (methods.py:84-117; refinement.py:204-235): the best of the 27 neighbours by
 // (rho(n)-rho(p))*dist_mat + rho(p), strict '>', first wins in (ix,iy,iz) ascending order.
-__device__ __forceinline__ void og_step(const double *__restrict__ rho, const Grid &g, int px, int py, int pz,
-                                        double ctr, int &qx, int &qy, int &qz) {
+template <typename GT>
+__device__ __forceinline__ void og_step(const double *__restrict__ rho, const GT &g, const double *__restrict__ dist,
+                                        int px, int py, int pz, double ctr, int &qx, int &qy, int &qz) {
     double max_val = ctr;
     qx = px; qy = py; qz = pz;
 #pragma unroll
@@ -99,8 +139,8 @@ __device__ __forceinline__ void og_step(const double *__restrict__ rho, const Gr
 #pragma unroll
             for (int iz = -1; iz < 2; iz++) {
                 const int tz = wrapi(pz + iz, g.nz);
-                double v = rho[lin3(g, tx, ty, tz)];
-                v = (v - ctr) * g.dist[((ix + 3) % 3) * 9 + ((iy + 3) % 3) * 3 + ((iz + 3) % 3)];
+                double v = rho[(tx * g.ny + ty) * g.nz + tz];
+                v = (v - ctr) * dist[((ix + 3) % 3) * 9 + ((iy + 3) % 3) * 3 + ((iz + 3) % 3)];
                 v += ctr;
                 if (v > max_val) { max_val = v; qx = tx; qy = ty; qz = tz; }
             }
@@ -120,7 +160,7 @@ struct PathWindow {
     double m_old;
     __device__ __forceinline__ void init(int l, double c) {
 #pragma unroll
-        for (int k = 0; k < K; k++) { idx[k] = -1; val[k] = -1.; }
+        for (int k = 0; k < K; k++) { idx[k] = -1; val[k] = -1.7976931348623157e308; }
         idx[0] = l; val[0] = c;
         m_old = -1.7976931348623157e308;
     }
@@ -131,7 +171,7 @@ struct PathWindow {
         return f;
     }
     __device__ __forceinline__ void push(int l, double c) {
-        if (idx[K - 1] >= 0 && val[K - 1] > m_old) m_old = val[K - 1];
+        m_old = fmax(m_old, val[K - 1]);
 #pragma unroll
         for (int k = K - 1; k > 0; k--) { idx[k] = idx[k - 1]; val[k] = val[k - 1]; }
         idx[0] = l; val[0] = c;
