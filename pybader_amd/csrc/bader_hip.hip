@@ -436,31 +436,145 @@ __device__ __forceinline__ void classify27(const Grid &g, const double *__restri
         if (nb[k] >= 0 && rho[nb[k]] > max_val) is_max = false;
 }
 
-__global__ __launch_bounds__(TPB) void k_edge_flag(Grid g, const double *__restrict__ rho,
-                                                   const int *__restrict__ labels, int8_t *__restrict__ known,
-                                                   int xa, int nplanes, unsigned long long *edges) {
-    // planes xa .. xa+nplanes-1 (modulo nx); edges counted on owned planes only
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
-    unsigned int cnt = 0;
-    if (vv < (long long)nplanes * g.nyz) {
-        const int xr = (int)(vv / g.nyz);
-        const int r = (int)(vv - (long long)xr * g.nyz);
-        int x = xa + xr;
-        if (x >= g.nx) x -= g.nx;
-        const int y = r / g.nz, z = r - y * g.nz;
-        const int v = lin3(g, x, y, z);
-        int8_t out;
-        if (labels[v] == -1) out = 0;
-        else {
-            bool is_edge, is_max;
-            classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-            out = (is_edge && !is_max) ? -2 : 2;
-            if (out == -2 && x >= g.x0 && x < g.x1) cnt = 1;
-        }
-        known[v] = out;
+// Block-wide exclusive scan of a small per-thread count (TPB threads); returns the offset of this
+// thread and the block total.
+__device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
+    __shared__ int wsum[TPB / XB_WAVE];
+    const int lane = threadIdx.x % XB_WAVE, w = threadIdx.x / XB_WAVE;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < XB_WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
     }
-    const unsigned long long b = __ballot(cnt);
-    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(edges, (unsigned long long)__popcll(b));
+    if (lane == XB_WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int q = 0; q < TPB / XB_WAVE; q++) {
+        if (q < w) base += wsum[q];
+        total += wsum[q];
+    }
+    __syncthreads();
+    return base + incl - cnt;
+}
+
+// LDS-tiled edge_find pass 1: a block stages the labels of a 4x8x64 tile plus a one-voxel periodic
+// halo (6x10x66 ints) in LDS, every thread classifies 8 voxels from the staged 3x3x3
+// neighbourhoods, and the block appends its owned edge voxels to the edge list with ONE atomic
+// (the list length is the edge count edge_find returns).  rho is only read for the few voxels
+// that have a foreign neighbour (the is_max test, refinement.py:374-375).
+#define ET_X 4
+#define ET_Y 8
+#define ET_Z 64
+__global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *__restrict__ rho,
+                                                         const int *__restrict__ labels,
+                                                         int8_t *__restrict__ known, int xa, int nplanes,
+                                                         int *__restrict__ list, int *list_count, int small) {
+    __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
+    const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
+    for (int i = threadIdx.x; i < (ET_X + 2) * (ET_Y + 2) * (ET_Z + 2); i += TPB) {
+        const int ez = i % (ET_Z + 2);
+        const int r = i / (ET_Z + 2);
+        const int ey = r % (ET_Y + 2), ex = r / (ET_Y + 2);
+        int X = xa + tx0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
+        if (small) {
+            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
+        } else {
+            X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+        }
+        tile[ex][ey][ez] = labels[(X * g.ny + Y) * g.nz + Z];
+    }
+    __syncthreads();
+    const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+    int8_t out[8];
+    int vidx[8];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+        const int xr = tx0 + tx, y = y0 + ty, z = z0 + tz;
+        out[k] = 1;  // 1 = outside the grid / the plane range: nothing to store
+        vidx[k] = -1;
+        if (xr < nplanes && y < g.ny && z < g.nz) {
+            int x = xa + xr;
+            if (x >= g.nx) x -= g.nx;
+            const int v = (x * g.ny + y) * g.nz + z;
+            const int lab = tile[tx + 1][ty + 1][tz + 1];
+            int8_t o = 0;  // vacuum voxels are not classified (refinement.py:342-343)
+            if (lab != -1) {
+                bool is_edge = false;
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                        for (int dz = 0; dz < 3; dz++) {
+                            const int nv = tile[tx + dx][ty + dy][tz + dz];
+                            is_edge |= (nv != -1) & (nv != lab);
+                        }
+                o = 2;
+                if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
+                    const double c = rho[v];
+                    bool is_max = true;
+                    for (int dx = -1; dx < 2; dx++) {
+                        const int X = wrapi(x + dx, g.nx);
+                        for (int dy = -1; dy < 2; dy++) {
+                            const int Y = wrapi(y + dy, g.ny);
+                            for (int dz = -1; dz < 2; dz++) {
+                                const int Z = wrapi(z + dz, g.nz);
+                                if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 &&
+                                    rho[(X * g.ny + Y) * g.nz + Z] > c)
+                                    is_max = false;
+                            }
+                        }
+                    }
+                    if (!is_max) {
+                        o = -2;
+                        if (x >= g.x0 && x < g.x1) { vidx[k] = v; cnt++; }
+                    }
+                }
+            }
+            out[k] = o;
+            known[v] = o;
+        }
+    }
+    int total;
+    const int off = block_scan_excl(cnt, total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(list_count, total) : 0;
+    __syncthreads();
+    int w = base_s + off;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (vidx[k] >= 0) list[w++] = vidx[k];
+}
+
+// compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block
+__global__ __launch_bounds__(TPB) void k_compact_known16(GridL g, const int8_t *__restrict__ known, int value,
+                                                         int *__restrict__ list, int *count) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long base = vbeg + ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
+    int8_t b[16];
+    if (base + 16 <= vend && ((vbeg & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(known + base);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = (base + k < vend) ? known[base + k] : (int8_t)(value + 1);
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cnt += (b[k] == value);
+    int total;
+    const int off = block_scan_excl(cnt, total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(count, total) : 0;
+    __syncthreads();
+    int w = base_s + off;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (b[k] == value) list[w++] = (int)(base + k);
 }
 
 // known >= 0 with a `flag` voxel in the 27-box -> -1.  Used by edge_find (flag=-2) and edge_check
@@ -490,24 +604,6 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int 
         }
     }
     if (near) known[v] = -1;
-}
-
-// compaction of owned voxels with known == value into a list (order arbitrary)
-__global__ __launch_bounds__(TPB) void k_compact_known(Grid g, const int8_t *__restrict__ known, int value,
-                                                       int *list, int *count, int cap) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    const bool hit = v < vend && known[v] == value;
-    const unsigned long long b = __ballot(hit);
-    if (!b) return;
-    const int lane = threadIdx.x % XB_WAVE;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(count, __popcll(b));
-    base = __shfl(base, 0);
-    if (hit) {
-        const int k = base + __popcll(b & ((1ull << lane) - 1ull));
-        if (k < cap) list[k] = (int)v;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -834,6 +930,8 @@ struct xb_ctx {
     std::vector<int> maxima_sorted;  // global, label order
     std::vector<int> local_max, local_first;
     bool first_clean = false;
+    int list_n = 0;            // entries of `list` that hold the owned known == -2 voxels ...
+    bool list_valid = false;   // ... when this is set (by xb_edge_find)
     bool timing = false;
     int opt_trace = 3;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
     TimedKernel tk[5];
@@ -1034,6 +1132,7 @@ static size_t dtype_size(int dtype) { return (dtype == XB_I8 || dtype == XB_I16 
 
 int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     NEED_GRID("xb_upload_labels");
+    c->list_valid = false;
     const size_t sz = dtype_size(dtype);
     if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
     if (dtype == XB_I32) {
@@ -1066,6 +1165,7 @@ int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {
 }
 int xb_upload_known(xb_ctx *c, const int8_t *known_host) {
     NEED_GRID("xb_upload_known");
+    c->list_valid = false;
     HIPCHK(hipMemcpyAsync(c->known, known_host, c->N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;
@@ -1273,16 +1373,21 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
     int xa, np, xb_, npd;
     plane_range(g, whole ? 0 : c->halo - 1, xa, np);   // flags need labels one plane further out
     plane_range(g, whole ? 0 : c->halo - 2, xb_, npd);  // dilation needs flags one plane further out
-    HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
     {
         ScopedTimer t(c, 2);
-        k_edge_flag<<<nblocks((long long)np * g.nyz), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, xa, np, c->counters64);
+        const GridL gl = light(g);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
+        k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
+                                                       c->counters + 5, small);
         k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
     }
     HIPCHK(hipGetLastError());
-    unsigned long long n;
-    HIPCHK(hipMemcpyAsync(&n, c->counters64, sizeof n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    int n = 0;
+    if (int rc = read_counter(c, 5, &n)) return rc;
+    c->list_n = n;           // the edge list stays valid until `known` changes
+    c->list_valid = true;
     if (edges) *edges = (int64_t)n;
     return XB_OK;
 }
@@ -1291,7 +1396,7 @@ static int compact(xb_ctx *c, int value, int *n_out) {
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
-    k_compact_known<<<nblocks(own), TPB, 0, c->stream>>>(g, c->known, value, c->list, c->counters + 5, (int)std::min<long long>(c->N, 2147483647LL));
+    k_compact_known16<<<nblocks((own + 15) / 16), TPB, 0, c->stream>>>(light(g), c->known, value, c->list, c->counters + 5);
     HIPCHK(hipGetLastError());
     return read_counter(c, 5, n_out);
 }
@@ -1300,7 +1405,9 @@ int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) {
     NEED_GRID("xb_refine_trace");
     const Grid &g = c->g;
     int n = 0;
-    if (int rc = compact(c, -2, &n)) return rc;
+    if (c->list_valid) n = c->list_n;
+    else if (int rc = compact(c, -2, &n)) return rc;
+    c->list_valid = false;  // the retrace rewrites known
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
@@ -1328,6 +1435,7 @@ int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) {
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     NEED_GRID("xb_edge_check");
     const Grid &g = c->g;
+    c->list_valid = false;
     if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: 'changed' mode is single-slab only; slabs use mode 'all'");
     int n = 0;
     if (int rc = compact(c, -2, &n)) return rc;
@@ -1473,6 +1581,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     const size_t es = which == 0 ? 4 : 1;
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
+    if (to_device) c->list_valid = false;
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
