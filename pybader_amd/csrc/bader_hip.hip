@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     if (valid && labels[v] != -1) {
         px = sx; py = sy; pz = sz;
         lp = v;
-        rec = G[v];
+        rec = fetch_rec(G, v);
         w.init(v, rec.key);
         mode = TR_STEP;
     }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
                     py = r / g.nz;
                     pz = r - py * g.nz;
                     lp = lq;
-                    rec = G[lq];
+                    rec = fetch_rec(G, lq);
                     w.push(lq, rec.key);
                 }
             } else {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
                 if (w.contains(lq)) {
                     mode = TR_NEED_OG;  // refinement.py:200: already been here on this path
                 } else {
-                    const GradRec nr = G[lq];
+                    const GradRec nr = fetch_rec(G, lq);
                     if (nr.key <= w.m_old || ++steps > maxsteps) {
                         result = -2;  // membership undecidable from the window: exact slow kernel
                         mode = TR_DONE;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
                     mode = TR_DONE;
                 } else {
                     const int lq = lin3f(g, qx, qy, qz);
-                    rec = G[lq];
+                    rec = fetch_rec(G, lq);
                     w.push(lq, rec.key);
                     px = qx; py = qy; pz = qz; lp = lq;
                     mode = TR_STEP;

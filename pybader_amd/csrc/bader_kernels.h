@@ -98,6 +98,9 @@ __device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Gr
 // sound, see PathWindow); the exact density for the ongrid step is read from rho itself.
 struct __attribute__((aligned(32))) GradRec { double r0, r1, r2, key; };
 #define XB_STAY_CODE 63
+__device__ __forceinline__ GradRec fetch_rec(const GradRec *__restrict__ G, int l) {
+    return *reinterpret_cast<const GradRec *>(reinterpret_cast<const char *>(G) + ((unsigned long long)(unsigned)l << 5));
+}
 
 __device__ __forceinline__ double pack_key(double rho, int code) {
     return __longlong_as_double((__double_as_longlong(rho) & ~63LL) | (long long)code);
@@ -171,7 +174,7 @@ struct PathWindow {
         return f;
     }
     __device__ __forceinline__ void push(int l, double c) {
-        m_old = fmax(m_old, val[K - 1]);
+        m_old = (val[K - 1] > m_old) ? val[K - 1] : m_old;
 #pragma unroll
         for (int k = K - 1; k > 0; k--) { idx[k] = idx[k - 1]; val[k] = val[k - 1]; }
         idx[0] = l; val[0] = c;
