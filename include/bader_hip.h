@@ -92,6 +92,9 @@ int xb_edge_find(xb_ctx *c, int64_t *edges);
  * until a known==2 voxel or a maximum; relabel the start voxel if the label differs.
  * escaped: traces that left the valid x-range [x0-halo, x1+halo) (slabs only; 0 on one GPU). */
 int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped);
+/* slab fallback: escaped traces are parked as known == -6; after the scheduler made the whole grid
+ * valid on this rank (all-gather of labels + known, xb_set_halo(nx)) this call retraces exactly them. */
+int xb_refine_trace_escaped(xb_ctx *c, int64_t *changed, int64_t *escaped);
 /* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels) */
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
 /* thread_handlers.refine (thread_handlers.py:128-236): the iteration driver on one GPU.

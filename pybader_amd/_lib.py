@@ -38,6 +38,7 @@ SYMBOLS = {
     'xb_assign_finish': (_int, [_vp, _vp, _i64]),
     'xb_edge_find': (_int, [_vp, _pi64]),
     'xb_refine_trace': (_int, [_vp, _pi64, _pi64]),
+    'xb_refine_trace_escaped': (_int, [_vp, _pi64, _pi64]),
     'xb_edge_check': (_int, [_vp, _pi64, _pi64]),
     'xb_refine': (_int, [_vp, _int, _i64, _vp, _i64, _pi64]),
     'xb_charge_sum': (_int, [_vp, _dbl, _i64, _vp, _vp]),
@@ -204,6 +205,11 @@ class Context:
     def refine_trace(self):
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_refine_trace(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def refine_trace_escaped(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_refine_trace_escaped(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def edge_check(self):

@@ -312,7 +312,7 @@ __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels
             if (qx == px && qy == py && qz == pz) { result = lp; break; }
         }
         if (refine) {
-            if (!plane_valid(g, qx)) { atomicAdd(escaped, 1); return; }
+            if (!plane_valid(g, qx)) { known[v] = -6; atomicAdd(escaped, 1); return; }
             if (known_ro[lq] == 2) { result = lq; break; }
         }
         if (np >= lmax) { atomicExch(err, 1); return; }
@@ -321,7 +321,7 @@ __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels
     }
     if (refine) {
         const int nv = labels[result];
-        if (nv != vol_num) { labels[v] = nv; atomicAdd(changed, 1); }
+        if (nv != vol_num) { labels[v] = nv; known[v] = -2; atomicAdd(changed, 1); }
         else known[v] = -1;
     } else {
         if (result != v && labels[result] == -1) result = -1;
@@ -702,12 +702,12 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     if (valid) {
         if (result >= 0) {
             const int nv = labels[result];
-            if (nv != vol_num) { labels[v] = nv; ch = 1; }  // known stays -2 (refinement.py:288-289)
-            else known[v] = -1;                              // refinement.py:291 (+5 +1 -5)
+            if (nv != vol_num) { labels[v] = nv; known[v] = -2; ch = 1; }  // refinement.py:288-289
+            else known[v] = -1;                                             // refinement.py:291 (+5 +1 -5)
         } else if (result == -2) {
             const int k = atomicAdd(ovf_count, 1);
             if (k < ovf_cap) ovf_list[k] = v;
-        } else if (result == -4) es = 1;
+        } else if (result == -4) { known[v] = -6; es = 1; }  // left the valid slab: parked for the fallback
     }
     const unsigned long long bc = __ballot(ch), be = __ballot(es);
     if (threadIdx.x % XB_WAVE == 0) {
@@ -1371,8 +1371,11 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
     const bool whole = (g.x1 - g.x0 == g.nx);
     if (!whole && c->halo < 2) return fail(XB_E_STATE, "xb_edge_find: slab needs a label halo (xb_set_halo)");
     int xa, np, xb_, npd;
-    plane_range(g, whole ? 0 : c->halo - 1, xa, np);   // flags need labels one plane further out
-    plane_range(g, whole ? 0 : c->halo - 2, xb_, npd);  // dilation needs flags one plane further out
+    // flags need labels one plane further out, the dilation needs flags one plane further out;
+    // a halo that wraps the whole grid makes every plane valid
+    const bool all = whole || (g.x1 - g.x0) + 2 * c->halo >= g.nx;
+    plane_range(g, all ? g.nx : c->halo - 1, xa, np);
+    plane_range(g, all ? g.nx : c->halo - 2, xb_, npd);
     HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
     {
         ScopedTimer t(c, 2);
@@ -1401,12 +1404,15 @@ static int compact(xb_ctx *c, int value, int *n_out) {
     return read_counter(c, 5, n_out);
 }
 
-int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) {
+static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *escaped);
+int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) { return refine_trace_impl(c, -2, changed, escaped); }
+int xb_refine_trace_escaped(xb_ctx *c, int64_t *changed, int64_t *escaped) { return refine_trace_impl(c, -6, changed, escaped); }
+static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *escaped) {
     NEED_GRID("xb_refine_trace");
     const Grid &g = c->g;
     int n = 0;
-    if (c->list_valid) n = c->list_n;
-    else if (int rc = compact(c, -2, &n)) return rc;
+    if (c->list_valid && flag == -2) n = c->list_n;
+    else if (int rc = compact(c, flag, &n)) return rc;
     c->list_valid = false;  // the retrace rewrites known
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {

@@ -122,15 +122,22 @@ class GpuBackend:
     """libbader_hip.so context + zero-copy torch views of its label / known arrays for RCCL."""
 
     def __init__(self, ctx, device_index):
+        # NB torch (only needed for N > 1: RCCL plumbing) must have been imported before the first
+        # _lib.Context() of the process: PyTorch-ROCm bundles its HIP runtime and has to load first.
         self.ctx = ctx
         self.device_index = device_index
         self._views = None
 
     def set_grid(self, shape, dist_mat, T_grad, x_range, halo):
         self.ctx.set_grid(shape, dist_mat, T_grad, x_range)
-        if x_range != (0, shape[0]):
+        self.sliced = tuple(x_range) != (0, shape[0])
+        if self.sliced:
             self.ctx.set_halo(halo)
         self._views = None
+
+    def set_halo(self, halo):
+        if self.sliced:
+            self.ctx.set_halo(halo)
 
     def tensors(self):
         if self._views is None:
@@ -160,6 +167,7 @@ class SlabRunner:
         self.be.set_grid(self.shape, dist_mat, T_grad, self.x_range, self.halo)
         self.sends, self.recvs = halo_plan(self.ranges, comm.rank, self.halo, self.shape[0])
         self.n_maxima = 0
+        self.n_fallbacks = 0
 
     def assign(self, method):
         """thread_handlers.bader_calc: per-slab trajectories, then one tiny table merge for numbering."""
@@ -179,12 +187,33 @@ class SlabRunner:
             self.be.sync()
             self.comm.exchange(self.be.tensors()[0], self.sends, self.recvs)
 
+    def gather_all_planes(self):
+        """Fallback exchange: every rank receives every other rank's owned label and known planes."""
+        sends = [(peer, self.x_range[0], self.x_range[1]) for peer in range(self.comm.size) if peer != self.comm.rank]
+        recvs = [(peer, a, b) for peer, (a, b) in enumerate(self.ranges) if peer != self.comm.rank]
+        self.be.sync()
+        for t in self.be.tensors():
+            self.comm.exchange(t, sends, recvs)
+
     def _trace(self):
         changed, escaped = self.be.refine_trace()
-        changed, escaped = self.comm.sum(changed, escaped) if self.comm.size > 1 else (changed, escaped)
+        if self.comm.size == 1:
+            assert escaped == 0
+            return changed
+        changed, escaped = self.comm.sum(changed, escaped)
         if escaped:
-            raise RuntimeError(f"{escaped} refinement traces left the slab halo ({self.halo} planes); "
-                               "re-run with a wider halo")
+            # Some retraces walked out of [x0-halo+2, x1+halo-2) before meeting a known==2 voxel.
+            # They were parked (known == -6) untouched.  Make the whole grid valid on every rank --
+            # traces only read labels at known==2 voxels / maxima, which no retrace rewrites, so the
+            # exchange is safe in the middle of an iteration -- and retrace exactly those voxels.
+            self.n_fallbacks += 1
+            self.gather_all_planes()
+            self.be.set_halo(self.shape[0])
+            ch2, es2 = self.be.refine_trace_escaped()
+            self.be.set_halo(self.halo)
+            ch2, es2 = self.comm.sum(ch2, es2)
+            assert es2 == 0
+            changed += ch2
         return changed
 
     def refine(self, mode, iters):

@@ -1,4 +1,17 @@
-mkdir -p gpurun_out; rm -f gpurun_out/sweep.log
-(timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -5) > gpurun_out/test6.log 2>&1
-for i in 1 2; do timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['other_kernels_ms_avg'])" >> gpurun_out/sweep.log; done
-cat gpurun_out/test6.log gpurun_out/sweep.log
+python - <<'PY' 2>&1 | grep -v amdgpu.ids
+import torch
+print('torch alone', torch.cuda.is_available(), torch.cuda.device_count())
+import sys; sys.path.insert(0,'.')
+from pybader_amd import _lib
+c = _lib.Context(0); print('ctx after torch ok')
+import numpy as np
+t = torch.zeros(4, device='cuda:0'); print(t.sum().item())
+PY
+python - <<'PY' 2>&1 | grep -v amdgpu.ids
+import sys; sys.path.insert(0,'.')
+from pybader_amd import _lib
+c = _lib.Context(0); print('ctx first ok')
+import torch
+print('torch after lib', torch.cuda.is_available(), torch.cuda.device_count())
+PY
+env | grep -i -E "HIP|ROCR|CUDA|HSA" 

@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# The slab tests move halo planes through torch views of the library's device arrays.  PyTorch-ROCm
+# bundles its own HIP runtime: it must be loaded BEFORE libbader_hip.so (then both share it); the
+# other order leaves torch without a usable device.  The product itself never imports torch.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

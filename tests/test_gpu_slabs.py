@@ -1,0 +1,129 @@
+"""GPU slab path on ONE GPU: N contexts (one per logical rank) on the same device, driven by N Python
+threads through the product's SlabRunner + GpuBackend; halo planes move between the contexts through
+the same zero-copy torch views of the device arrays that the RCCL transport uses on a multi-GPU node.
+The assembled map must equal the 1-GPU result bit for bit (multi-GPU row)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import case_density, load_golden
+from pybader_amd import _lib, slab
+
+pytestmark = pytest.mark.gpu
+
+
+class Shared:
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+        self.cur = [None] * n
+        self.errors = []
+
+
+class ThreadComm:
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.size = shared, rank, shared.n
+
+    def allgather(self, obj):
+        self.sh.slots[self.rank] = obj
+        self.sh.barrier.wait()
+        out = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return out
+
+    def sum(self, *vals):
+        got = self.allgather([int(v) for v in vals])
+        return [sum(g[i] for g in got) for i in range(len(vals))]
+
+    def exchange(self, tensor, sends, recvs):
+        import torch
+        self.sh.cur[self.rank] = tensor
+        self.sh.barrier.wait()
+        for peer, xa, xb in recvs:
+            tensor[xa:xb].copy_(self.sh.cur[peer][xa:xb])
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
+
+    def barrier(self):
+        self.sh.barrier.wait()
+
+
+def run_slabs(n, g, rho, method, mode, iters, halo, tol):
+    sh = Shared(n)
+    res = [None] * n
+
+    def work(rank):
+        try:
+            ctx = _lib.Context(0)
+            comm = ThreadComm(sh, rank)
+            runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), comm, rho.shape, g['dist_mat'], g['T_grad'], halo=halo)
+            ctx.upload_density(rho)
+            ctx.vacuum_assign(tol, 1.0)
+            nb = runner.assign(method)
+            x0, x1 = runner.x_range
+            pre = ctx.download_labels(np.int32)[x0:x1].copy()
+            log = runner.refine(mode, iters)
+            post = ctx.download_labels(np.int32)[x0:x1].copy()
+            ch, vo = ctx.charge_sum(1.0, nb)
+            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks)
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            sh.errors.append(repr(e))
+            sh.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not sh.errors, sh.errors
+    res.sort(key=lambda r: r[0])
+    pre = np.concatenate([r[1] for r in res])
+    post = np.concatenate([r[2] for r in res])
+    ch = sum(r[5] for r in res)
+    vo = sum(r[6] for r in res)
+    return pre, post, res[0][3], res[0][4], ch, vo, max(r[7] for r in res)
+
+
+def tol_of(g):
+    t = float(g['vacuum_tol'])
+    return None if np.isnan(t) else t
+
+
+@pytest.mark.parametrize('n,name,mode,iters,halo', [
+    (2, 'c64_cubic', 'changed', 2, 8),
+    (4, 'c64_cubic', 'all', -1, 8),
+    (3, 'c40x48x56_tric', 'changed', 2, 8),
+    (2, 'c48_cubic_vac', 'all', 2, 6),
+    (8, 'c64_cubic', 'changed', 2, 4),
+])
+def test_neargrid_slabs_equal_one_gpu(n, name, mode, iters, halo):
+    g = load_golden(name)
+    rho = case_density(g)
+    pre, post, log, maxima, ch, vo, fb = run_slabs(n, g, rho, 'neargrid', mode, iters, halo, tol_of(g))
+    assert np.array_equal(pre, g['ng_F'].astype(np.int32))
+    key = f"ng_{mode}_{'inf' if iters < 0 else iters}"
+    assert np.array_equal(post, g[key].astype(np.int32))
+    assert np.array_equal(np.array(np.unravel_index(maxima, rho.shape)).T, g['ng_bader_max'])
+    np.testing.assert_allclose(ch * float(g['voxel_volume']), g['ng_bader_charge'], rtol=1e-9)
+    assert all(c == 0 for _, c in log)
+
+
+@pytest.mark.parametrize('n,name,halo', [(2, 'c64_cubic', 8), (3, 'c40x48x56_tric', 3), (4, 'c40x48x56_tric', 8)])
+def test_ongrid_plus_refine_all_slabs_equal_oracle(n, name, halo):
+    """ongrid start => many voxels change during refinement (exercises halo refresh between
+    iterations and, with the 3-plane halo, the escape fallback)."""
+    import oracle
+    g = load_golden(name)
+    rho = case_density(g)
+    pre, post, log, maxima, ch, vo, fb = run_slabs(n, g, rho, 'ongrid', 'all', 3, halo, tol_of(g))
+    assert np.array_equal(pre, g['og_main'].astype(np.int32))
+    v = g['og_main'].astype(np.int32)
+    olog = []
+    oracle.refine('neargrid', ('all', 3), rho, v, g['dist_mat'], g['T_grad'], 1, log=olog)
+    assert log == [tuple(x) for x in olog]
+    assert np.array_equal(post, v)
+    if halo == 3:
+        assert fb > 0, 'the narrow halo is meant to exercise the escape fallback'

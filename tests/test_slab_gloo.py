@@ -1,0 +1,80 @@
+"""N>1 path on CPU: world_size-2/3 gloo groups run the product's slab scheduler (slab.py: slab
+ranges, halo plan, plane exchange, maxima-table merge, iteration driver) over a host backend built on
+the oracle; the assembled map must equal the single-rank result and the reference's golden map."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from pybader_amd import slab
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(n, args, tmp_path, port, halo=4):
+    out = str(tmp_path / 'out.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'slab_worker.py')] + args + [out, str(halo)],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-3000:]
+    return np.load(out)
+
+
+def test_slab_ranges_and_halo_plan():
+    assert slab.slab_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert slab.slab_ranges(8, 8) == [(k, k + 1) for k in range(8)]
+    rngs = slab.slab_ranges(16, 4)
+    for r in range(4):
+        sends, recvs = slab.halo_plan(rngs, r, 2, 16)
+        got = sorted(p for _, a, b in recvs for p in range(a, b))
+        x0, x1 = rngs[r]
+        assert got == sorted({(x0 - 2) % 16, (x0 - 1) % 16, x1 % 16, (x1 + 1) % 16})
+        # every send of r is a recv of the peer
+        for peer, a, b in sends:
+            _, precv = slab.halo_plan(rngs, peer, 2, 16)
+            assert (r, a, b) in precv
+    # halo wider than a slab: planes come from several owners
+    sends, recvs = slab.halo_plan(slab.slab_ranges(12, 6), 0, 3, 12)
+    assert sorted(p for _, a, b in recvs for p in range(a, b)) == [2, 3, 4, 9, 10, 11]
+
+
+def test_merge_maxima_tables():
+    t = [(np.array([50, 7]), np.array([40, 3])), (np.array([7, 90]), np.array([1, 60]))]
+    assert slab.merge_maxima_tables(t).tolist() == [7, 50, 90]
+
+
+@pytest.mark.parametrize('n,case,method,mode,iters,port,halo', [
+    (2, 'c12_cubic', 'neargrid', 'changed', 2, 29611, 4),
+    (3, 'c40x48x56_tric', 'neargrid', 'all', -1, 29612, 4),
+    (2, 'c48_cubic_vac', 'neargrid', 'changed', 2, 29613, 4),
+    (2, 'c40x48x56_tric', 'ongrid', 'all', 3, 29614, 6),
+    (3, 'c40x48x56_tric', 'ongrid', 'all', 3, 29615, 3),      # narrow halo: traces escape -> fallback
+])
+def test_slabs_equal_single_rank_and_golden(n, case, method, mode, iters, port, halo, tmp_path):
+    import oracle
+    from conftest import case_density
+    r = run_world(n, [case, method, mode, str(iters)], tmp_path, port, halo)
+    if halo == 3:
+        assert int(r['fallbacks']) > 0, "the narrow-halo case is meant to exercise the escape fallback"
+    g = load_golden(case)
+    if method == 'neargrid':
+        assert np.array_equal(r['pre'], g['ng_F'].astype(np.int32))
+        key = f"ng_{mode}_{'inf' if iters < 0 else iters}"
+        assert np.array_equal(r['post'], g[key].astype(np.int32))
+        assert np.array_equal(np.array(np.unravel_index(r['maxima'], g['ng_F'].shape)).T, g['ng_bader_max'])
+    else:
+        assert np.array_equal(r['pre'], g['og_main'].astype(np.int32))
+        rho = case_density(g)
+        v = g['og_main'].astype(np.int32)
+        log = []
+        oracle.refine('neargrid', (mode, iters), rho, v, g['dist_mat'], g['T_grad'], 1, log=log)
+        assert np.array_equal(r['post'], v)
+        assert np.array_equal(r['log'], np.array(log, np.int64).reshape(-1, 2))
