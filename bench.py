@@ -77,16 +77,23 @@ def main():
 
     dist = None
     if world > 1:
+        # torch first: PyTorch-ROCm bundles its HIP runtime, libbader_hip.so must load after it
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
-        comm = slab.TorchComm(dist)
+        dev_index = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a full node
+        torch.cuda.set_device(dev_index)
+        try:
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{dev_index}'))
+        except Exception:  # noqa: BLE001  (no RCCL: fall back to gloo + host-staged planes)
+            dist.init_process_group('gloo')
+        comm = slab.TorchComm(dist, device=torch.device(f'cuda:{dev_index}'))
     else:
         class _Solo:
-            rank, size = 0, 1
+            rank, size, transport = 0, 1, 'none'
             def barrier(self):
                 pass
+            def max_float(self, x):
+                return x
         comm = _Solo()
 
     shape = (args.size,) * 3
@@ -95,8 +102,9 @@ def main():
     dm, tg = distance_matrix(vl), gradient_transform(vl)
     voxel_volume = abs(np.linalg.det(lattice)) / float(np.prod(shape))
 
-    ctx = _lib.Context(local_rank if world > 1 else 0)
-    runner = slab.SlabRunner(slab.GpuBackend(ctx, local_rank), comm, shape, dm, tg, halo=args.halo)
+    dev_index = dev_index if world > 1 else 0
+    ctx = _lib.Context(dev_index)
+    runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=args.halo)
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
     ctx.enable_timing(True)
     if 'XB_OPT_TRACE' in os.environ:
@@ -110,6 +118,8 @@ def main():
 
     def fence():
         ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
         comm.barrier()
         ctx.sync()
 
@@ -121,12 +131,7 @@ def main():
     for _ in range(args.steps):
         n_basins, log = step()
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = comm.max_float(time.perf_counter() - t0)       # max over ranks
 
     nvox = float(np.prod(shape))
     ms_per_step = dt / args.steps * 1e3
@@ -156,7 +161,7 @@ def main():
                                f'{args.method} assign + neargrid edge refinement {mode}:{iters}, '
                                'density resident in HBM',
                    'grid': list(shape), 'method': args.method, 'refine_mode': [mode, iters],
-                   'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}',
+                   'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}, transport {comm.transport}',
                    'basins': int(n_basins), 'refine_log': log},
         'roofline': {'bound': 'hbm', 'kernel': 'k_ng_trace' if which == 0 else 'k_og_pointer',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -78,38 +78,89 @@ def halo_plan(ranges, rank, halo, nx):
 
 
 class TorchComm:
-    """torch.distributed plumbing: backend 'nccl' is RCCL over xGMI on the GPU box, 'gloo' in CPU tests."""
+    """torch.distributed plumbing.  Default group: backend 'nccl' (= RCCL over xGMI) on the GPU box,
+    'gloo' in the CPU tests.  Device planes go rank-to-rank with batched isend/irecv on zero-copy
+    views of the library's arrays; if that transport fails its start-up self-test (or the default
+    group is gloo while the arrays live on the device) planes are staged through pinned host memory
+    over a gloo group instead -- slower, same result."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, device=None):
         self.dist = dist
         self.rank = dist.get_rank()
         self.size = dist.get_world_size()
+        self.device = device
+        self.backend = dist.get_backend()
+        self.host_group = None
+        self.device_p2p = False
+        if device is not None:
+            if self.backend != 'gloo':
+                self.host_group = dist.new_group(backend='gloo')
+                self.device_p2p = self._selftest()
+        self.transport = 'rccl-p2p' if self.device_p2p else ('gloo' if device is None else 'host-staged-gloo')
+
+    def _selftest(self):
+        """ring exchange of a small device tensor; every rank must see the right payload"""
+        import torch
+        ok = True
+        try:
+            if self.size > 1:
+                src = torch.full((256,), float(self.rank), device=self.device)
+                dst = torch.full((256,), -1.0, device=self.device)
+                nxt, prv = (self.rank + 1) % self.size, (self.rank - 1) % self.size
+                ops = [self.dist.P2POp(self.dist.irecv, dst, prv), self.dist.P2POp(self.dist.isend, src, nxt)]
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+                torch.cuda.synchronize(self.device)
+                ok = bool((dst == float(prv)).all().item())
+        except Exception:  # noqa: BLE001
+            ok = False
+        flags = [None] * self.size
+        self.dist.all_gather_object(flags, ok, group=self.host_group)
+        return all(flags)
 
     def allgather(self, obj):
         out = [None] * self.size
-        self.dist.all_gather_object(out, obj)
+        self.dist.all_gather_object(out, obj, group=self.host_group)
         return out
 
     def sum(self, *vals):
         got = self.allgather([int(v) for v in vals])
         return [sum(g[i] for g in got) for i in range(len(vals))]
 
+    def max_float(self, x):
+        return max(self.allgather(float(x)))
+
     def exchange(self, tensor, sends, recvs):
         """tensor: (nx, plane) view aliasing the array; moves whole planes between ranks."""
         import torch
+        if not sends and not recvs:
+            return
+        if tensor.is_cuda and not self.device_p2p:
+            return self._exchange_staged(tensor, sends, recvs)
         ops = []
         for peer, xa, xb in recvs:
             ops.append(self.dist.P2POp(self.dist.irecv, tensor[xa:xb], peer))
         for peer, xa, xb in sends:
             ops.append(self.dist.P2POp(self.dist.isend, tensor[xa:xb], peer))
-        if ops:
-            for w in self.dist.batch_isend_irecv(ops):
-                w.wait()
-            if tensor.is_cuda:
-                torch.cuda.synchronize(tensor.device)
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        if tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+
+    def _exchange_staged(self, tensor, sends, recvs):
+        import torch
+        outs = [(peer, tensor[xa:xb].cpu()) for peer, xa, xb in sends]
+        ins = [(peer, xa, xb, torch.empty((xb - xa, tensor.shape[1]), dtype=tensor.dtype)) for peer, xa, xb in recvs]
+        ops = [self.dist.P2POp(self.dist.irecv, buf, peer, group=self.host_group) for peer, _, _, buf in ins]
+        ops += [self.dist.P2POp(self.dist.isend, buf, peer, group=self.host_group) for peer, buf in outs]
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        for _, xa, xb, buf in ins:
+            tensor[xa:xb].copy_(buf)
+        torch.cuda.synchronize(tensor.device)
 
     def barrier(self):
-        self.dist.barrier()
+        self.dist.barrier(group=self.host_group)
 
 
 class _DevArray:

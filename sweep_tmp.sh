@@ -1,17 +1,3 @@
-python - <<'PY' 2>&1 | grep -v amdgpu.ids
-import torch
-print('torch alone', torch.cuda.is_available(), torch.cuda.device_count())
-import sys; sys.path.insert(0,'.')
-from pybader_amd import _lib
-c = _lib.Context(0); print('ctx after torch ok')
-import numpy as np
-t = torch.zeros(4, device='cuda:0'); print(t.sum().item())
-PY
-python - <<'PY' 2>&1 | grep -v amdgpu.ids
-import sys; sys.path.insert(0,'.')
-from pybader_amd import _lib
-c = _lib.Context(0); print('ctx first ok')
-import torch
-print('torch after lib', torch.cuda.is_available(), torch.cuda.device_count())
-PY
-env | grep -i -E "HIP|ROCR|CUDA|HSA" 
+mkdir -p gpurun_out
+(timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --size 128 --steps 2 --warmup 1 2>&1 | grep -v amdgpu.ids | tail -12) > gpurun_out/bench_n2.log 2>&1
+cat gpurun_out/bench_n2.log | cut -c1-1200
