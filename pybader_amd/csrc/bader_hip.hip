@@ -726,44 +726,63 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 // the final `known` is then a pure function of P and the static classes.
 // temp codes in `known`: -2 undecided, -4 processed, -5 skipped.
 // ---------------------------------------------------------------------------------------------
+// One round: every still-undecided entry looks at its (at most 13) earlier neighbours.  Work
+// lists live on the device (`in` -> survivors appended to `out`), so rounds are queued
+// back-to-back without a host round trip; the host only polls the survivor count now and then.
+//   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
+//   an earlier neighbour is P -> skipped
+//   no earlier neighbour left undecided -> processed
 __global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
                                                    const int *__restrict__ labels, int8_t *known,
-                                                   const int *__restrict__ list, int n, int8_t *st, int *undecided) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n || st[t] != 0) return;
-    const int v = list[t];
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-    bool blocked = false, has_proc = false;
+                                                   const int *__restrict__ list, int8_t *st,
+                                                   const int *__restrict__ in, const int *n_in, int *out,
+                                                   int *n_out, int first_round) {
+    const int n = *n_in;
+    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        const int t = first_round ? e : in[e];
+        const int v = list[t];
+        const int x = v / g.nyz;
+        const int r = v - x * g.nyz;
+        const int y = r / g.nz, z = r - y * g.nz;
+        bool blocked = false, has_proc = false;
 #pragma unroll
-    for (int ix = -1; ix < 2; ix++) {
-        const int tx = wrapi(x + ix, g.nx);
+        for (int ix = -1; ix < 2; ix++) {
+            const int tx = wrapi(x + ix, g.nx);
 #pragma unroll
-        for (int iy = -1; iy < 2; iy++) {
-            const int ty = wrapi(y + iy, g.ny);
+            for (int iy = -1; iy < 2; iy++) {
+                const int ty = wrapi(y + iy, g.ny);
 #pragma unroll
-            for (int iz = -1; iz < 2; iz++) {
-                const int tz = wrapi(z + iz, g.nz);
-                const int l = lin3(g, tx, ty, tz);
-                if (l < v) {
-                    const int8_t k = __builtin_nontemporal_load(&known[l]);
-                    blocked |= (k == -2);
-                    has_proc |= (k == -4);
+                for (int iz = -1; iz < 2; iz++) {
+                    const int tz = wrapi(z + iz, g.nz);
+                    const int l = lin3(g, tx, ty, tz);
+                    if (l < v) {
+                        const int8_t k = __builtin_nontemporal_load(&known[l]);
+                        blocked |= (k == -2);
+                        has_proc |= (k == -4);
+                    }
                 }
             }
         }
+        int decision = 0;  // 0 wait, 1 processed, 2 skipped
+        if (!blocked && !has_proc) decision = 1;
+        else {
+            int8_t cls = st[t] >> 2;  // cached class: 1 = edge&max, 2 = other
+            if (cls == 0) {
+                bool is_edge, is_max;
+                classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+                cls = (is_edge && is_max) ? 1 : 2;
+            }
+            if (cls == 1) decision = 1;
+            else if (has_proc) decision = 2;
+            else st[t] = (int8_t)(cls << 2);  // still waiting: remember the class
+        }
+        if (decision) {
+            st[t] = (int8_t)decision;
+            known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
+        } else {
+            out[atomicAdd(n_out, 1)] = t;
+        }
     }
-    if (blocked) { atomicAdd(undecided, 1); return; }
-    bool proc = true;
-    if (has_proc) {
-        bool is_edge, is_max;
-        classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-        // classify27 leaves is_max=true when !is_edge; edge&max is the only class left untouched
-        proc = is_edge && is_max;
-    }
-    st[t] = proc ? 1 : 2;
-    known[v] = proc ? -4 : -5;
 }
 // apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
 __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
@@ -801,23 +820,23 @@ __global__ void k_ec_restore(int8_t *known, const int *list, int n) {
     const int8_t k = known[list[t]];
     if (k == -4 || k == -5) known[list[t]] = -2;
 }
-// count -3 on owned planes and turn them into -2 (refinement.py:505-507)
-__global__ __launch_bounds__(TPB) void k_ec_finish(Grid g, int8_t *known, int xa, int nplanes,
-                                                   unsigned long long *edges) {
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+// count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread
+__global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges) {
+    const long long base = ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
     unsigned int cnt = 0;
-    if (vv < (long long)nplanes * g.nyz) {
-        const int xr = (int)(vv / g.nyz);
-        int x = xa + xr;
-        if (x >= g.nx) x -= g.nx;
-        const long long v = (long long)x * g.nyz + (vv - (long long)xr * g.nyz);
-        if (known[v] == -3) {
-            known[v] = -2;
-            if (x >= g.x0 && x < g.x1) cnt = 1;
-        }
+    if (base + 16 <= N) {
+        uint4 w = *reinterpret_cast<const uint4 *>(known + base);
+        int8_t *b = reinterpret_cast<int8_t *>(&w);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (b[k] == -3) { b[k] = -2; cnt++; }
+        if (cnt) *reinterpret_cast<uint4 *>(known + base) = w;
+    } else {
+        for (long long k = base; k < N; k++)
+            if (known[k] == -3) { known[k] = -2; cnt++; }
     }
-    const unsigned long long b = __ballot(cnt);
-    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(edges, (unsigned long long)__popcll(b));
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (threadIdx.x % XB_WAVE == 0 && cnt) atomicAdd(edges, (unsigned long long)cnt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1449,20 +1468,33 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (edges) *edges = 0;
     if (!n) return XB_OK;
     HIPCHK(hipMemsetAsync(c->st, 0, n, c->stream));
-    for (int round = 0;; round++) {
-        HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-        k_ec_decide<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters + 6);
-        HIPCHK(hipGetLastError());
-        int und = 0;
-        if (int rc = read_counter(c, 6, &und)) return rc;
-        if (!und) break;
-        if (round > n + 4 || round > 20000) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
+    {
+        // work lists: two halves of `first` would clash with the numbering table, so borrow the
+        // dtype staging buffer (N*8 bytes >= 2 lists of n ints); counters 6/7 ping-pong
+        int *wl[2] = {(int *)c->stage, (int *)c->stage + n};
+        HIPCHK(hipMemcpyAsync(c->counters + 6, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        int cur = 0;
+        const unsigned grid = (unsigned)std::min<long long>(nblocks(n), 2048);
+        for (int round = 0;; round++) {
+            HIPCHK(hipMemsetAsync(c->counters + 6 + (1 - cur), 0, sizeof(int), c->stream));
+            k_ec_decide<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, c->st, wl[cur],
+                                                     c->counters + 6 + cur, wl[1 - cur], c->counters + 6 + (1 - cur),
+                                                     round == 0);
+            cur = 1 - cur;
+            if ((round & 31) == 31 || round < 2) {
+                HIPCHK(hipGetLastError());
+                int und = 0;
+                if (int rc = read_counter(c, 6 + cur, &und)) return rc;
+                if (!und) break;
+            }
+            if (round > n + 64 || round > 200000) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
+        }
     }
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1);
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
     k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
-    k_ec_finish<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, c->counters64);
+    k_ec_finish<<<nblocks((c->N + 15) / 16), TPB, 0, c->stream>>>(c->known, c->N, c->counters64);
     HIPCHK(hipGetLastError());
     unsigned long long r[2];
     HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));

@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-(timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --size 128 --steps 2 --warmup 1 2>&1 | grep -v amdgpu.ids | tail -12) > gpurun_out/bench_n2.log 2>&1
-cat gpurun_out/bench_n2.log | cut -c1-1200
+(timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8) > gpurun_out/test9.log 2>&1
+cat gpurun_out/test9.log
+timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --method ongrid 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ongrid:', d['value'], d['ms_per_step'], d['config']['refine_log'])"

@@ -1,0 +1,91 @@
+"""Size-independent properties at BASELINE.json's full sizes (no CPU oracle can follow there):
+conservation, maxima consistency, idempotence of refinement, translation invariance of the
+partition, and N-slab == 1-GPU."""
+import numpy as np
+import pytest
+
+import torch  # noqa: F401  (before the library: see conftest)
+from pybader_amd import _lib, synth
+from pybader_amd.interface import distance_matrix, gradient_transform
+
+pytestmark = pytest.mark.gpu
+
+
+def matrices(shape, lattice):
+    vl = np.divide(lattice, shape)
+    return distance_matrix(vl), gradient_transform(vl)
+
+
+def run(ctx, shape, lattice, rho=None, method='neargrid'):
+    dm, tg = matrices(shape, lattice)
+    ctx.set_grid(shape, dm, tg)
+    if rho is None:
+        ctx.synth_density(lattice, synth.ATOMS8, synth.BACKGROUND)
+    else:
+        ctx.upload_density(rho)
+    ctx.vacuum_assign(None, 1.0)
+    n = ctx.assign(method)
+    return n, ctx.maxima(), ctx.download_labels(np.int32)
+
+
+@pytest.mark.parametrize('size,method', [(512, 'neargrid'), (512, 'ongrid'), (384, 'neargrid')])
+def test_full_size_invariants(size, method):
+    ctx = _lib.Context(0)
+    shape = (size,) * 3
+    n, maxima, lab = run(ctx, shape, synth.CUBIC6, method=method)
+    assert n == 8 and lab.min() == 0 and lab.max() == n - 1
+    # every maximum carries its own label, and labels are numbered by first appearance in C order
+    assert np.array_equal(lab[tuple(maxima.T)], np.arange(n))
+    flat = lab.reshape(-1)
+    first = np.array([np.argmax(flat == k) for k in range(n)])
+    assert np.all(np.diff(first) > 0)
+    # conservation: basin charges/volumes add up to the whole cell
+    ch, vo = ctx.charge_sum(1.0, n)
+    rho_sum = float(ctx.download_density().sum(dtype=np.float64))
+    assert abs(ch.sum() - rho_sum) <= 1e-9 * rho_sum
+    assert vo.sum() == float(size) ** 3
+    hist = np.bincount(flat, minlength=n)
+    assert np.array_equal(hist.astype(np.float64), vo)
+    # refinement: the neargrid own-trajectory map is a fixed point; ongrid maps do change
+    log = ctx.refine('changed', 2)
+    after = ctx.download_labels(np.int32)
+    if method == 'neargrid':
+        assert all(c == 0 for _, c in log) and np.array_equal(after, lab)
+    else:
+        assert log[0][1] > 0
+        # a second full refinement pass from the refined map must not re-flag unchanged interior
+        assert int((after != lab).sum()) >= log[0][1]
+    ctx.close()
+
+
+@pytest.mark.parametrize('size', [256, 512])
+def test_translation_invariance(size):
+    """roll(rho) gives the rolled partition (holds for the reference's final map)."""
+    ctx = _lib.Context(0)
+    shape = (size,) * 3
+    n1, max1, lab1 = run(ctx, shape, synth.CUBIC6)
+    rho = ctx.download_density()
+    shift = (5, 3, 7)
+    n2, max2, lab2 = run(ctx, shape, synth.CUBIC6, rho=np.ascontiguousarray(np.roll(rho, shift, axis=(0, 1, 2))))
+    del rho
+    assert n1 == n2
+    moved = (max1 + np.array(shift)) % size
+    # basin k of the original is basin perm[k] of the rolled grid
+    key2 = {tuple(m): k for k, m in enumerate(max2.tolist())}
+    perm = np.array([key2[tuple(m)] for m in moved.tolist()], np.int32)
+    assert np.array_equal(perm[np.roll(lab1, shift, axis=(0, 1, 2))], lab2)
+    ctx.close()
+
+
+def test_slabs_equal_one_gpu_256():
+    from test_gpu_slabs import run_slabs
+    ctx = _lib.Context(0)
+    shape = (256,) * 3
+    n, maxima, lab = run(ctx, shape, synth.CUBIC6)
+    rho = ctx.download_density()
+    ctx.close()
+    dm, tg = matrices(shape, synth.CUBIC6)
+    g = {'dist_mat': dm, 'T_grad': tg}
+    pre, post, log, mx, ch, vo, fb = run_slabs(4, g, rho, 'neargrid', 'all', 2, 8, None)
+    assert np.array_equal(pre, lab) and np.array_equal(post, lab)
+    assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
