@@ -128,8 +128,11 @@ int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that ho
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);
-/* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order) */
+/* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order;
+ * key 1: trapping boxes on/off) */
 int xb_set_option(xb_ctx *c, int key, int value);
+/* statistics of the last assignment: trapping boxes found and voxels they cover */
+int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ SYMBOLS = {
     'xb_kernel_time_reset': (_int, [_vp]),
     'xb_enable_timing': (_int, [_vp, _int]),
     'xb_set_option': (_int, [_vp, _int, _int]),
+    'xb_box_stats': (_int, [_vp, _pi64, _pi64]),
 }
 
 _lib = None
@@ -251,6 +252,11 @@ class Context:
 
     def set_option(self, key, value):
         check(self.lib.xb_set_option(self.h, int(key), int(value)))
+
+    def box_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_box_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def sync(self):
         check(self.lib.xb_sync(self.h))

@@ -116,45 +116,139 @@ __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *f
 }
 
 // ---------------------------------------------------------------------------------------------
-// Gradient-field table: the normalised direction of the neargrid step at every voxel
-// (refinement.py:89-137) plus the density, 32 B per voxel.  One streaming stencil pass; the
-// direction does not depend on the carried remainder `dr`, so every trajectory step afterwards is
-// ONE 32-byte gather instead of seven 8-byte gathers and three float64 divisions.
+// Gradient-field table: per voxel the normalised neargrid step direction (refinement.py:89-143)
+// split into integer step + remainder, and the ongrid successor (methods.py:87-117), 32 B/voxel.
+// LDS-tiled: a block stages a 4x8x64 tile of rho plus a one-voxel periodic halo (6x10x66 doubles)
+// and every thread derives 8 records from the staged 3x3x3 neighbourhoods.  Neither quantity
+// depends on the carried remainder `dr`, so every trajectory step afterwards is ONE 32-byte gather.
+// 26-neighbour maxima (ongrid successor == self) are appended to `seeds`.
 // ---------------------------------------------------------------------------------------------
+#define GT_X 4
+#define GT_Y 8
+#define GT_Z 64
 __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__restrict__ rho,
-                                                    GradRec *__restrict__ G) {
+                                                    GradRec *__restrict__ G, int *seeds, int *seed_count,
+                                                    int seed_cap, int small) {
+    __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
+    const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
+    for (int i = threadIdx.x; i < (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2); i += TPB) {
+        const int ez = i % (GT_Z + 2);
+        const int r = i / (GT_Z + 2);
+        const int ey = r % (GT_Y + 2), ex = r / (GT_Y + 2);
+        int X = x0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
+        if (small) {
+            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
+        } else {
+            X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+        }
+        tile[ex][ey][ez] = rho[(X * g.ny + Y) * g.nz + Z];
+    }
+    __syncthreads();
+    const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+        const int x = x0 + tx, y = y0 + ty, z = z0 + tz;
+        if (x >= g.nx || y >= g.ny || z >= g.nz) continue;
+        const int v = (x * g.ny + y) * g.nz + z;
+        const double c = tile[tx + 1][ty + 1][tz + 1];
+        // ongrid successor: strict '>' first-wins scan in (ix,iy,iz) ascending order
+        double max_val = c;
+        int og = XB_OG_SELF;
+#pragma unroll
+        for (int ix = 0; ix < 3; ix++)
+#pragma unroll
+            for (int iy = 0; iy < 3; iy++)
+#pragma unroll
+                for (int iz = 0; iz < 3; iz++) {
+                    double w = tile[tx + ix][ty + iy][tz + iz];
+                    w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+                    w += c;
+                    if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
+                }
+        GradRec o;
+        double d0, d1, d2;
+        int code;
+        if (ng_dir_vals(g, c, tile[tx + 2][ty + 1][tz + 1], tile[tx][ty + 1][tz + 1], tile[tx + 1][ty + 2][tz + 1],
+                        tile[tx + 1][ty][tz + 1], tile[tx + 1][ty + 1][tz + 2], tile[tx + 1][ty + 1][tz], d0, d1, d2)) {
+            // max_grad < 1E-14: a trajectory stays on p, p is on its path, so the reference resets dr
+            // and takes the ongrid step (refinement.py:200-235) -- which is the tabulated successor
+            o.r0 = o.r1 = o.r2 = 0.;
+            code = XB_STAY_CODE;
+        } else {
+            // refinement.py:138-143: int_grad = rha(grad_dir); the remainder grad_dir - int_grad is what
+            // every trajectory through p adds to its dr
+            const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
+            o.r0 = d0 - (double)i0;
+            o.r1 = d1 - (double)i1;
+            o.r2 = d2 - (double)i2;
+            code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
+        }
+        o.key = pack_key(c, code, og);
+        G[v] = o;
+        if (og == XB_OG_SELF) {
+            const int q = atomicAdd(seed_count, 1);
+            if (q < seed_cap) seeds[q] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trapping boxes.  For a 26-neighbour maximum m let B_R = {v : |v - m|_inf <= R} (minimum image).
+// B_R is CLOSED when no voxel of B_R can be left by (a) a neargrid move, for ANY carried remainder dr,
+// or (b) an ongrid move.  (a): per axis the move is int_grad + corr with corr = rha(dr + r),
+// |dr| <= 0.5 (+1 ulp): corr can be +1 only if r >= 0 and -1 only if r <= 0 (both when |r| < 1e-12),
+// so the reachable offsets are a per-axis interval read off the table record.  If B_R is closed and
+// m is its only 26-neighbour maximum, every trajectory that arrives at a voxel of B_R ends at m --
+// exactly, whatever its dr -- so the trace may stop there.  Moves are at most 2 voxels long, so a
+// voxel at distance d whose farthest successor is at distance D only violates the boxes d <= R < D.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int min_image_abs(int t, int n) {
+    int a = t < 0 ? -t : t;
+    if (a >= n) a -= n;
+    return min(a, n - a);
+}
+__global__ __launch_bounds__(TPB) void k_box_scan(GridL g, const GradRec *__restrict__ G, int n_max,
+                                                  const int *__restrict__ mxyz, const int *__restrict__ rcap,
+                                                  int *bad, int stride) {
     const long long N = (long long)g.nx * g.nyz;
     const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
     if (vv >= N) return;
     const int v = (int)vv;
-    const int px = v / g.nyz;
-    const int r = v - px * g.nyz;
-    const int py = r / g.nz, pz = r - py * g.nz;
-    const double c = rho[v];
-    GradRec o;
-    double d0, d1, d2;
-    int code;
-    if (ng_dir(rho, g, px, py, pz, v, c, d0, d1, d2)) {
-        // the trajectory stays on p, p is on its path, so the reference resets dr and takes one
-        // ongrid step from p (refinement.py:200-235).  That step is memoryless: tabulate its target
-        // (== p itself when p is a maximum).
-        int qx, qy, qz;
-        og_step(rho, g, g.dist, px, py, pz, c, qx, qy, qz);
-        o.r0 = (double)lin3(g, qx, qy, qz);
-        o.r1 = 0.;
-        o.r2 = 0.;
-        code = XB_STAY_CODE;
-    } else {
-        // refinement.py:138-143: int_grad = rha(grad_dir); the remainder grad_dir - int_grad is what
-        // every trajectory through p adds to its dr
-        const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
-        o.r0 = d0 - (double)i0;
-        o.r1 = d1 - (double)i1;
-        o.r2 = d2 - (double)i2;
-        code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    const GradRec rec = fetch_rec(G, v);
+    const int code = key_code(rec.key), og = key_og(rec.key);
+    const int o0 = og / 9 - 1, o1 = (og / 3) % 3 - 1, o2 = og % 3 - 1;
+    int lo0 = o0, hi0 = o0, lo1 = o1, hi1 = o1, lo2 = o2, hi2 = o2;  // the ongrid move
+    if (code != XB_STAY_CODE) {
+        const int i0 = (code & 3) - 1, i1 = ((code >> 2) & 3) - 1, i2 = (code >> 4) - 1;
+        lo0 = min(lo0, i0 - (rec.r0 < 1e-12)); hi0 = max(hi0, i0 + (rec.r0 > -1e-12));
+        lo1 = min(lo1, i1 - (rec.r1 < 1e-12)); hi1 = max(hi1, i1 + (rec.r1 > -1e-12));
+        lo2 = min(lo2, i2 - (rec.r2 < 1e-12)); hi2 = max(hi2, i2 + (rec.r2 > -1e-12));
     }
-    o.key = pack_key(c, code);
-    G[v] = o;
+    for (int m = 0; m < n_max; m++) {
+        const int t0 = x - mxyz[3 * m], t1 = y - mxyz[3 * m + 1], t2 = z - mxyz[3 * m + 2];
+        const int d = max(max(min_image_abs(t0, g.nx), min_image_abs(t1, g.ny)), min_image_abs(t2, g.nz));
+        if (d > rcap[m]) continue;
+        int D = max(min_image_abs(t0 + lo0, g.nx), min_image_abs(t0 + hi0, g.nx));
+        D = max(D, max(min_image_abs(t1 + lo1, g.ny), min_image_abs(t1 + hi1, g.ny)));
+        D = max(D, max(min_image_abs(t2 + lo2, g.nz), min_image_abs(t2 + hi2, g.nz)));
+        for (int R = d; R < D; R++) bad[m * stride + R] = 1;
+    }
+}
+// stamp box id `id` into the key of every voxel of B_R(m)
+__global__ __launch_bounds__(TPB) void k_box_stamp(GridL g, GradRec *G, int mx, int my, int mz, int R, int id) {
+    const int w = 2 * R + 1;
+    const long long n = (long long)w * w * w;
+    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int dz = (int)(t % w), dy = (int)((t / w) % w), dx = (int)(t / ((long long)w * w));
+    const int x = ((mx + dx - R) % g.nx + g.nx) % g.nx, y = ((my + dy - R) % g.ny + g.ny) % g.ny,
+              z = ((mz + dz - R) % g.nz + g.nz) % g.nz;
+    long long *kp = reinterpret_cast<long long *>(&G[(x * g.ny + y) * g.nz + z].key);
+    *kp = (*kp & ~(0x3FFLL << 11)) | ((long long)id << 11);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -163,10 +257,13 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
 // One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
 // of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
+    ox = og / 9 - 1; oy = (og / 3) % 3 - 1; oz = og % 3 - 1;
+}
+
 template <int K>
 __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
-                                                  const double *__restrict__ rho,
-                                                  const double *__restrict__ dist, int *labels, int *first,
+                                                  const int *__restrict__ box_max, int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
                                                   int *ovf_count, int ovf_cap, int maxsteps, int opt) {
     // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
@@ -195,7 +292,8 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     }
     const bool valid = sx < g.x1 && sy < g.ny && sz < g.nz;
     const int v = valid ? (sx * g.ny + sy) * g.nz + sz : 0;
-    int mode = TR_DONE, result = -1;
+    bool moving = false;
+    int result = -1;
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0;
     double dr0 = 0., dr1 = 0., dr2 = 0.;
     GradRec rec = {0., 0., 0., 0.};
@@ -205,68 +303,45 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
         px = sx; py = sy; pz = sz;
         lp = v;
         rec = fetch_rec(G, v);
-        w.init(v, rec.key);
-        mode = TR_STEP;
+        const int b = key_box(rec.key);
+        if (b) result = box_max[b - 1];  // starts inside a trapping box: ends at its maximum
+        else { w.init(v, rec.key); moving = true; }
     }
-    for (;;) {
-        if (mode == TR_STEP) {
-            const int code = key_code(rec.key);
-            if (code == XB_STAY_CODE) {
-                // max_grad < 1E-14: the trajectory stays on p, which is on its path => dr = 0 and
-                // one ongrid step (refinement.py:200-235), tabulated by k_grad_field
-                const int lq = (int)rec.r0;
-                if (lq == lp) {
-                    result = lp;  // break_flag: p is the maximum
-                    mode = TR_DONE;
-                } else if (++steps > maxsteps) {
-                    result = -2;
-                    mode = TR_DONE;
-                } else {  // refinement.py:305-315: appended without a membership test
-                    dr0 = dr1 = dr2 = 0.;
-                    px = lq / g.nyz;
-                    const int r = lq - px * g.nyz;
-                    py = r / g.nz;
-                    pz = r - py * g.nz;
-                    lp = lq;
-                    rec = fetch_rec(G, lq);
-                    w.push(lq, rec.key);
-                }
-            } else {
-                int qx, qy, qz;
+    while (__any(moving)) {
+        if (moving) {
+            const int bits = key_bits(rec.key);
+            const int code = bits & 63;
+            int qx, qy, qz, lq = 0;
+            // refinement.py:132-154: the gradient move (if the voxel has one)
+            bool og_move = (code == XB_STAY_CODE);
+            if (!og_move) {
                 ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
-                const int lq = lin3f(g, qx, qy, qz);
-                if (w.contains(lq)) {
-                    mode = TR_NEED_OG;  // refinement.py:200: already been here on this path
-                } else {
-                    const GradRec nr = fetch_rec(G, lq);
-                    if (nr.key <= w.m_old || ++steps > maxsteps) {
-                        result = -2;  // membership undecidable from the window: exact slow kernel
-                        mode = TR_DONE;
-                    } else {
-                        w.push(lq, nr.key);
-                        px = qx; py = qy; pz = qz; lp = lq; rec = nr;
-                    }
+                lq = lin3f(g, qx, qy, qz);
+                og_move = w.contains(lq);  // refinement.py:200: already been here on this path
+            }
+            if (og_move) {  // refinement.py:201-235: dr = 0 and one ongrid step from p (tabulated)
+                const int og = (bits >> 6) & 31;
+                if (og == XB_OG_SELF) { result = lp; moving = false; }  // break_flag: p is the maximum
+                else {
+                    int ox, oy, oz;
+                    og_offsets(og, ox, oy, oz);
+                    dr0 = dr1 = dr2 = 0.;
+                    qx = wrap_u(px + ox, g.nx); qy = wrap_u(py + oy, g.ny); qz = wrap_u(pz + oz, g.nz);
+                    lq = lin3f(g, qx, qy, qz);
                 }
             }
-        }
-        if (!__any(mode == TR_STEP)) {
-            if (!__any(mode == TR_NEED_OG)) break;
-            if (mode == TR_NEED_OG) {  // refinement.py:201-235: dr = 0, one ongrid step from p
-                int qx, qy, qz;
-                dr0 = dr1 = dr2 = 0.;
-                og_step(rho, g, dist, px, py, pz, rho[lp], qx, qy, qz);
-                if (qx == px && qy == py && qz == pz) {
-                    result = lp;
-                    mode = TR_DONE;
-                } else if (++steps > maxsteps) {
-                    result = -2;
-                    mode = TR_DONE;
+            if (moving) {
+                const GradRec nr = fetch_rec(G, lq);
+                const int b = key_box(nr.key);
+                if (b) {  // arrived inside a trapping box (q cannot be an old path voxel: the
+                    result = box_max[b - 1];  // trajectory would have stopped there already)
+                    moving = false;
+                } else if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
+                    result = -2;  // membership undecidable from the window: exact slow kernel
+                    moving = false;  // (ongrid moves are appended without a membership test, 305-315)
                 } else {
-                    const int lq = lin3f(g, qx, qy, qz);
-                    rec = fetch_rec(G, lq);
-                    w.push(lq, rec.key);
-                    px = qx; py = qy; pz = qz; lp = lq;
-                    mode = TR_STEP;
+                    w.push(lq, nr.key);
+                    px = qx; py = qy; pz = qz; lp = lq; rec = nr;
                 }
             }
         }
@@ -613,16 +688,15 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int 
 // +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
 // ---------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G,
-                                                      const double *__restrict__ rho,
-                                                      const double *__restrict__ dist, int *labels,
+__global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n,
                                                       int *changed, int *escaped, int *ovf_list, int *ovf_count,
                                                       int ovf_cap, int maxsteps) {
     const int t = blockIdx.x * TPB + threadIdx.x;
     const bool valid = t < n;
     const int v = valid ? list[t] : 0;
-    int mode = TR_DONE, result = -3;  // result: terminal voxel index; -2 overflow; -4 escaped
+    bool moving = false;
+    int result = -3;  // terminal voxel index; -2 overflow; -4 escaped
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
     double dr0 = 0., dr1 = 0., dr2 = 0.;
     GradRec rec = {0., 0., 0., 0.};
@@ -634,66 +708,41 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         py = r / g.nz;
         pz = r - py * g.nz;
         lp = v;
-        rec = G[v];
+        rec = fetch_rec(G, v);
         vol_num = labels[v];
         w.init(v, rec.key);
-        mode = TR_STEP;
+        moving = true;
     }
-    for (;;) {
-        if (mode == TR_STEP) {
-            const int code = key_code(rec.key);
-            if (code == XB_STAY_CODE) {
-                // stays on p (on its path): dr = 0 + the tabulated ongrid step (refinement.py:200-235)
-                const int lq = (int)rec.r0;
-                if (lq == lp) { result = lp; mode = TR_DONE; }  // a maximum: refinement.py:283-292
-                else {
-                    const int qx = lq / g.nyz;
-                    if (++steps > maxsteps) { result = -2; mode = TR_DONE; }
-                    else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
-                    else if (known[lq] == 2) { result = lq; mode = TR_DONE; }
-                    else {
-                        dr0 = dr1 = dr2 = 0.;
-                        const int r = lq - qx * g.nyz;
-                        px = qx; py = r / g.nz; pz = r - py * g.nz;
-                        lp = lq;
-                        rec = G[lq];
-                        w.push(lq, rec.key);
-                    }
-                }
-            } else {
-                int qx, qy, qz;
+    while (__any(moving)) {
+        if (moving) {
+            const int bits = key_bits(rec.key);
+            const int code = bits & 63;
+            int qx, qy, qz, lq = 0;
+            bool og_move = (code == XB_STAY_CODE);
+            if (!og_move) {
                 ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
-                const int lq = lin3f(g, qx, qy, qz);
-                if (w.contains(lq)) {
-                    mode = TR_NEED_OG;
-                } else {
-                    const GradRec nr = G[lq];
-                    if (nr.key <= w.m_old || ++steps > maxsteps) { result = -2; mode = TR_DONE; }
-                    else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
-                    else if (known[lq] == 2) { result = lq; mode = TR_DONE; }  // refinement.py:294-303
-                    else {
-                        w.push(lq, nr.key);
-                        px = qx; py = qy; pz = qz; lp = lq; rec = nr;
-                    }
+                lq = lin3f(g, qx, qy, qz);
+                og_move = w.contains(lq);  // refinement.py:200
+            }
+            if (og_move) {  // refinement.py:201-235
+                const int og = (bits >> 6) & 31;
+                if (og == XB_OG_SELF) { result = lp; moving = false; }  // a maximum: refinement.py:283-292
+                else {
+                    int ox, oy, oz;
+                    og_offsets(og, ox, oy, oz);
+                    dr0 = dr1 = dr2 = 0.;
+                    qx = wrap_u(px + ox, g.nx); qy = wrap_u(py + oy, g.ny); qz = wrap_u(pz + oz, g.nz);
+                    lq = lin3f(g, qx, qy, qz);
                 }
             }
-        }
-        if (!__any(mode == TR_STEP)) {
-            if (!__any(mode == TR_NEED_OG)) break;
-            if (mode == TR_NEED_OG) {
-                int qx, qy, qz;
-                dr0 = dr1 = dr2 = 0.;
-                og_step(rho, g, dist, px, py, pz, rho[lp], qx, qy, qz);
-                const int lq = lin3f(g, qx, qy, qz);
-                if (qx == px && qy == py && qz == pz) { result = lp; mode = TR_DONE; }  // refinement.py:283-292
-                else if (++steps > maxsteps) { result = -2; mode = TR_DONE; }
-                else if (!plane_valid(g, qx)) { result = -4; mode = TR_DONE; }
-                else if (known[lq] == 2) { result = lq; mode = TR_DONE; }
+            if (moving) {
+                const GradRec nr = fetch_rec(G, lq);
+                if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
+                else if (!plane_valid(g, qx)) { result = -4; moving = false; }
+                else if (known[lq] == 2) { result = lq; moving = false; }  // refinement.py:294-303
                 else {
-                    rec = G[lq];
-                    w.push(lq, rec.key);
-                    px = qx; py = qy; pz = qz; lp = lq;
-                    mode = TR_STEP;
+                    w.push(lq, nr.key);
+                    px = qx; py = qy; pz = qz; lp = lq; rec = nr;
                 }
             }
         }
@@ -928,7 +977,11 @@ struct xb_ctx {
     int halo = 0;
     double *rho = nullptr;
     GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
-    double *dist_dev = nullptr; // dist_mat on the device (rare ongrid steps inside the trace kernels)
+    double *dist_dev = nullptr; // dist_mat on the device
+    int *boxbuf = nullptr;      // seeds / box tables of the table build (BB_* layout)
+    int n_boxes = 0;
+    long long box_voxels = 0;
+    int opt_boxes = 1;
     bool grad_valid = false;
     int *labels = nullptr;
     int8_t *known = nullptr;
@@ -1011,6 +1064,7 @@ int xb_create(int device, xb_ctx **out) {
     HIPCHK(hipMalloc(&c->counters64, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->dsum, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&c->dist_dev, 27 * sizeof(double)));
+    HIPCHK(hipMalloc(&c->boxbuf, (size_t)(1 << 20) * sizeof(int)));
     HIPCHK(hipHostMalloc(&c->host_ints, 64 * sizeof(long long)));
     *out = c;
     return XB_OK;
@@ -1031,7 +1085,7 @@ void xb_destroy(xb_ctx *c) {
     for (auto &t : c->tk)
         for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     free_grid(c);
-    hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum); hipFree(c->dist_dev);
+    hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum); hipFree(c->dist_dev); hipFree(c->boxbuf);
     hipHostFree(c->host_ints);
     hipStreamDestroy(c->stream);
     delete c;
@@ -1212,15 +1266,84 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
     return XB_OK;
 }
 
-// (re)build the gradient-field table from the resident density
-static int ensure_grad(xb_ctx *c, bool force) {
+static int read_counter(xb_ctx *c, int idx, int *out);
+static GridL light(const Grid &g);
+
+// layout of the small device int buffer used by the table build (c->boxbuf)
+enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 4352, BB_BOXMAX = 4608, BB_BAD = 8192,
+       BB_TOTAL = 1 << 20, XB_BOX_SEEDS_MAX = 64 };
+
+// (re)build the gradient-field table from the resident density; with `boxes`, also find and stamp
+// the trapping boxes around the 26-neighbour maxima (k_box_scan)
+static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     if (c->grad_valid && !force) return XB_OK;
+    const Grid &g = c->g;
+    ScopedTimer t(c, 4);
+    HIPCHK(hipMemsetAsync(c->counters + 9, 0, sizeof(int), c->stream));
     {
-        ScopedTimer t(c, 4);
-        k_grad_field<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, c->rho, c->grad);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+        k_grad_field<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
+                                                 BB_SEED_CAP, small);
     }
     HIPCHK(hipGetLastError());
     c->grad_valid = true;
+    c->n_boxes = 0;
+    c->box_voxels = 0;
+    if (!boxes || !c->opt_boxes) return XB_OK;
+    int ns = 0;
+    if (int rc = read_counter(c, 9, &ns)) return rc;
+    if (ns < 1 || ns > XB_BOX_SEEDS_MAX) return XB_OK;  // many maxima (noisy data): plain tracing
+    std::vector<int> seeds(ns), mxyz(3 * ns), rcap(ns);
+    HIPCHK(hipMemcpyAsync(seeds.data(), c->boxbuf + BB_SEEDS, ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::sort(seeds.begin(), seeds.end());  // atomic append order is arbitrary: make box ids deterministic
+    for (int m = 0; m < ns; m++) {
+        mxyz[3 * m] = seeds[m] / g.nyz;
+        mxyz[3 * m + 1] = (seeds[m] % g.nyz) / g.nz;
+        mxyz[3 * m + 2] = seeds[m] % g.nz;
+    }
+    auto mi = [](int t, int n) { int a = std::abs(t) % n; return std::min(a, n - a); };
+    const int rmax = std::min(std::min(g.nx, g.ny), g.nz) / 2 - 2;  // a box must not wrap onto itself
+    int stride = 4;
+    for (int m = 0; m < ns; m++) {
+        int cap = rmax;
+        for (int o = 0; o < ns; o++)
+            if (o != m) {  // exactly one maximum per box: stay clear of the nearest other maximum
+                const int d = std::max(std::max(mi(mxyz[3 * m] - mxyz[3 * o], g.nx), mi(mxyz[3 * m + 1] - mxyz[3 * o + 1], g.ny)),
+                                       mi(mxyz[3 * m + 2] - mxyz[3 * o + 2], g.nz));
+                cap = std::min(cap, d - 1);
+            }
+        rcap[m] = std::max(cap, 0);
+        stride = std::max(stride, rcap[m] + 4);
+    }
+    if ((long long)ns * stride > BB_TOTAL - BB_BAD) return XB_OK;
+    HIPCHK(hipMemcpyAsync(c->boxbuf + BB_MXYZ, mxyz.data(), 3 * ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, rcap.data(), ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->boxbuf + BB_BAD, 0, (size_t)ns * stride * sizeof(int), c->stream));
+    k_box_scan<<<nblocks(c->N), TPB, 0, c->stream>>>(light(g), c->grad, ns, c->boxbuf + BB_MXYZ, c->boxbuf + BB_RCAP,
+                                                    c->boxbuf + BB_BAD, stride);
+    HIPCHK(hipGetLastError());
+    std::vector<int> bad((size_t)ns * stride);
+    HIPCHK(hipMemcpyAsync(bad.data(), c->boxbuf + BB_BAD, bad.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<int> box_max;
+    for (int m = 0; m < ns; m++) {
+        int best = 0;
+        for (int R = 1; R <= rcap[m]; R++)
+            if (!bad[(size_t)m * stride + R]) best = R;
+        if (best < 1 || (int)box_max.size() >= XB_MAX_BOXES) continue;
+        box_max.push_back(seeds[m]);
+        const long long w = 2LL * best + 1, nvox = w * w * w;
+        k_box_stamp<<<nblocks(nvox), TPB, 0, c->stream>>>(light(g), c->grad, mxyz[3 * m], mxyz[3 * m + 1], mxyz[3 * m + 2],
+                                                         best, (int)box_max.size());
+        c->box_voxels += nvox;
+    }
+    HIPCHK(hipGetLastError());
+    if (!box_max.empty())
+        HIPCHK(hipMemcpyAsync(c->boxbuf + BB_BOXMAX, box_max.data(), box_max.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // box_max (host vector) must outlive the copy
+    c->n_boxes = (int)box_max.size();
     return XB_OK;
 }
 
@@ -1268,7 +1391,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
         // the table is a pure function of the resident density, but it is part of the assignment
         // work: rebuilt on every call, never carried over from a previous assignment
-        if (int rc = ensure_grad(c, true)) return rc;
+        if (int rc = ensure_grad(c, true, true)) return rc;
         {
             ScopedTimer t(c, 0);
             const int opt = c->opt_trace;
@@ -1276,7 +1399,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
                 : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
             k_ng_trace<2><<<(unsigned)((waves + TPB / XB_WAVE - 1) / (TPB / XB_WAVE)), TPB, 0, c->stream>>>(
-                light(g), c->grad, c->rho, c->dist_dev, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
+                light(g), c->grad, c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
                 c->counters + 1, c->ovf_cap, maxsteps, opt);
         }
         HIPCHK(hipGetLastError());
@@ -1436,10 +1559,10 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
-        if (int rc = ensure_grad(c, false)) return rc;
+        if (int rc = ensure_grad(c, false, false)) return rc;
         {
             ScopedTimer t(c, 3);
-            k_refine_trace<2><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->rho, c->dist_dev, c->labels, c->known, c->list, n,
+            k_refine_trace<2><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n,
                                                                 c->counters + 2, c->counters + 3, c->ovf_list,
                                                                 c->counters + 1, c->ovf_cap, maxsteps);
         }
@@ -1629,7 +1752,14 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
 int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (key == 0) c->opt_trace = value;
+    else if (key == 1) c->opt_boxes = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
+    return XB_OK;
+}
+int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    if (n_boxes) *n_boxes = c->n_boxes;
+    if (box_voxels) *box_voxels = c->box_voxels;
     return XB_OK;
 }
 int xb_enable_timing(xb_ctx *c, int on) {

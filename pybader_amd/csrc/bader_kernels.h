@@ -41,14 +41,9 @@ __device__ __forceinline__ int rha(double x) { return x > 0 ? (int)(x + .5) : (i
 // 111): the normalised gradient direction grad_dir / max_grad at voxel p.  It depends on rho only
 // (not on the carried remainder dr), so it is precomputed once per voxel by k_grad_field.
 // Returns true when max_grad < 1E-14 (refinement.py:132-134: the trajectory does not move).
-__device__ __forceinline__ bool ng_dir(const double *__restrict__ rho, const Grid &g, int px, int py, int pz,
-                                       int lp, double c, double &d0, double &d1, double &d2) {
-    const int xp = wrapi(px + 1, g.nx), xm = wrapi(px - 1, g.nx);
-    const int yp = wrapi(py + 1, g.ny), ym = wrapi(py - 1, g.ny);
-    const int zp = wrapi(pz + 1, g.nz), zm = wrapi(pz - 1, g.nz);
-    const double hx = rho[lp + (xp - px) * g.nyz], lx = rho[lp + (xm - px) * g.nyz];
-    const double hy = rho[lp + (yp - py) * g.nz], ly = rho[lp + (ym - py) * g.nz];
-    const double hz = rho[lp + (zp - pz)], lz = rho[lp + (zm - pz)];
+template <typename GT>
+__device__ __forceinline__ bool ng_dir_vals(const GT &g, double c, double hx, double lx, double hy, double ly,
+                                            double hz, double lz, double &d0, double &d1, double &d2) {
     // refinement.py:111-114: zero when p is a strict maximum along the axis, else central difference
     const double g0 = (hx < c && c > lx) ? 0. : (hx - lx) / 2.;
     const double g1 = (hy < c && c > ly) ? 0. : (hy - ly) / 2.;
@@ -64,6 +59,16 @@ __device__ __forceinline__ bool ng_dir(const double *__restrict__ rho, const Gri
     if (mg < 1E-14) return true;
     d0 /= mg; d1 /= mg; d2 /= mg;  // refinement.py:137, true division
     return false;
+}
+__device__ __forceinline__ bool ng_dir(const double *__restrict__ rho, const Grid &g, int px, int py, int pz,
+                                       int lp, double c, double &d0, double &d1, double &d2) {
+    const int xp = wrapi(px + 1, g.nx), xm = wrapi(px - 1, g.nx);
+    const int yp = wrapi(py + 1, g.ny), ym = wrapi(py - 1, g.ny);
+    const int zp = wrapi(pz + 1, g.nz), zm = wrapi(pz - 1, g.nz);
+    const double hx = rho[lp + (xp - px) * g.nyz], lx = rho[lp + (xm - px) * g.nyz];
+    const double hy = rho[lp + (yp - py) * g.nz], ly = rho[lp + (ym - py) * g.nz];
+    const double hz = rho[lp + (zp - pz)], lz = rho[lp + (zm - pz)];
+    return ng_dir_vals(g, c, hx, lx, hy, ly, hz, lz, d0, d1, d2);
 }
 
 // Move part (refinement.py:138-154): step = rha(dir), dr += dir - step, corr = rha(dr),
@@ -91,21 +96,29 @@ __device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Gr
 // Per-voxel record of the gradient-field table (32 B, one aligned gather per trajectory step):
 //   r0,r1,r2  remainder part of the normalised direction, grad_dir - int_grad (refinement.py:143),
 //             exactly as the reference forms it (one float64 subtraction)
-//   key       the density with its 6 lowest mantissa bits replaced by the packed integer step
-//             int_grad+1 (2 bits per axis); all ones (63) flags a voxel the trajectory does not
-//             leave (max_grad < 1E-14), whose tabulated ongrid successor index is then in r0.
+//   key       the density with its 21 lowest mantissa bits replaced by
+//               bits  0-5   packed integer step int_grad+1 (2 bits per axis); 63 = the trajectory does
+//                           not leave this voxel by a gradient step (max_grad < 1E-14)
+//               bits  6-10  the ongrid successor (methods.py:87-117) as (ix+1)*9+(iy+1)*3+(iz+1);
+//                           13 = the voxel itself, i.e. a 26-neighbour maximum
+//               bits 11-20  trapping-box id + 1 (0 = in no box), see k_box_scan
 // `key` orders path voxels for the window test only (any fixed per-voxel function keeps that test
-// sound, see PathWindow); the exact density for the ongrid step is read from rho itself.
+// sound, see PathWindow); exact densities are never taken from it.
 struct __attribute__((aligned(32))) GradRec { double r0, r1, r2, key; };
 #define XB_STAY_CODE 63
+#define XB_OG_SELF 13
+#define XB_MAX_BOXES 1023
 __device__ __forceinline__ GradRec fetch_rec(const GradRec *__restrict__ G, int l) {
     return *reinterpret_cast<const GradRec *>(reinterpret_cast<const char *>(G) + ((unsigned long long)(unsigned)l << 5));
 }
 
-__device__ __forceinline__ double pack_key(double rho, int code) {
-    return __longlong_as_double((__double_as_longlong(rho) & ~63LL) | (long long)code);
+__device__ __forceinline__ double pack_key(double rho, int code, int og) {
+    return __longlong_as_double((__double_as_longlong(rho) & ~0x1FFFFFLL) | (long long)(code | (og << 6)));
 }
-__device__ __forceinline__ int key_code(double key) { return (int)(__double_as_longlong(key) & 63LL); }
+__device__ __forceinline__ int key_bits(double key) { return (int)(__double_as_longlong(key) & 0x1FFFFFLL); }
+__device__ __forceinline__ int key_code(double key) { return key_bits(key) & 63; }
+__device__ __forceinline__ int key_og(double key) { return (key_bits(key) >> 6) & 31; }
+__device__ __forceinline__ int key_box(double key) { return key_bits(key) >> 11; }
 
 // wrap q in [-n, 2n) into [0, n) with two unsigned minima
 __device__ __forceinline__ int wrap_u(int q, int n) {

@@ -89,3 +89,20 @@ def test_slabs_equal_one_gpu_256():
     pre, post, log, mx, ch, vo, fb = run_slabs(4, g, rho, 'neargrid', 'all', 2, 8, None)
     assert np.array_equal(pre, lab) and np.array_equal(post, lab)
     assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
+
+
+@pytest.mark.parametrize('size,lattice', [(256, synth.CUBIC6), (192, synth.TRICLINIC), (512, synth.CUBIC6)])
+def test_trapping_boxes_do_not_change_the_map(size, lattice):
+    """The trapping-box early exit (k_box_scan) is exact by construction; check it anyway against the
+    plain full-trajectory trace at sizes the CPU oracle cannot reach."""
+    ctx = _lib.Context(0)
+    shape = (size,) * 3
+    ctx.set_option(1, 0)
+    n0, max0, lab0 = run(ctx, shape, lattice)
+    assert ctx.box_stats() == (0, 0)
+    ctx.set_option(1, 1)
+    n1, max1, lab1 = run(ctx, shape, lattice)
+    nb, nv = ctx.box_stats()
+    assert nb == n1 and nv > 0.05 * size ** 3
+    assert n0 == n1 and np.array_equal(max0, max1) and np.array_equal(lab0, lab1)
+    ctx.close()
