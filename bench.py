@@ -109,6 +109,8 @@ def main():
     ctx.enable_timing(True)
     if 'XB_OPT_TRACE' in os.environ:
         ctx.set_option(0, int(os.environ['XB_OPT_TRACE']))
+    if 'XB_OPT_TPB' in os.environ:
+        ctx.set_option(2, int(os.environ['XB_OPT_TPB']))
 
     def step():
         ctx.vacuum_assign(None, voxel_volume)           # Bader.volumes_init: labels := 0 (no vacuum)
@@ -162,7 +164,8 @@ def main():
                                'density resident in HBM',
                    'grid': list(shape), 'method': args.method, 'refine_mode': [mode, iters],
                    'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}, transport {comm.transport}',
-                   'basins': int(n_basins), 'refine_log': log},
+                   'basins': int(n_basins), 'refine_log': log,
+                   'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'kernel': 'k_ng_trace' if which == 0 else 'k_og_pointer',
                      'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
@@ -170,7 +173,7 @@ def main():
                      'whole_path': {'bytes_per_voxel': BYTES_PATH,
                                     'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
                                     'frac': BYTES_PATH * nvox / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
-                     'other_kernels_ms_avg': {'grad_field': gf_ms / max(gf_n, 1), 'edge_find': ef_ms / max(ef_n, 1),
+                     'other_kernels_ms_avg': {'table_build(grad_field+box_scan+stamp)': gf_ms / max(gf_n, 1), 'edge_find': ef_ms / max(ef_n, 1),
                                               'refine_trace': rt_ms / max(rt_n, 1)}},
     }
 

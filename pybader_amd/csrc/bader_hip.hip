@@ -274,7 +274,8 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
         const int per = gridDim.x >> 3;
         if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
     }
-    const int wave = blk * (TPB / XB_WAVE) + threadIdx.x / XB_WAVE;
+    const int wpb = blockDim.x / XB_WAVE;  // waves per block (launch-time choice)
+    const int wave = blk * wpb + threadIdx.x / XB_WAVE;
     const int lane = threadIdx.x % XB_WAVE;
     int sx, sy, sz;
     if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
@@ -982,6 +983,7 @@ struct xb_ctx {
     int n_boxes = 0;
     long long box_voxels = 0;
     int opt_boxes = 1;
+    int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
     bool grad_valid = false;
     int *labels = nullptr;
     int8_t *known = nullptr;
@@ -1005,7 +1007,7 @@ struct xb_ctx {
     int list_n = 0;            // entries of `list` that hold the owned known == -2 voxels ...
     bool list_valid = false;   // ... when this is set (by xb_edge_find)
     bool timing = false;
-    int opt_trace = 3;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
+    int opt_trace = 1;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
     TimedKernel tk[5];
     long long n_alloc = 0;
 };
@@ -1398,7 +1400,8 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
             const long long waves = (opt & 1)
                 ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
                 : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
-            k_ng_trace<2><<<(unsigned)((waves + TPB / XB_WAVE - 1) / (TPB / XB_WAVE)), TPB, 0, c->stream>>>(
+            const int tpb = c->opt_trace_tpb;
+            k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
                 light(g), c->grad, c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
                 c->counters + 1, c->ovf_cap, maxsteps, opt);
         }
@@ -1753,6 +1756,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (key == 0) c->opt_trace = value;
     else if (key == 1) c->opt_boxes = value;
+    else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
 }
