@@ -208,45 +208,54 @@ __device__ __forceinline__ int min_image_abs(int t, int n) {
     if (a >= n) a -= n;
     return min(a, n - a);
 }
-__global__ __launch_bounds__(TPB) void k_box_scan(GridL g, const GradRec *__restrict__ G, int n_max,
-                                                  const int *__restrict__ mxyz, const int *__restrict__ rcap,
-                                                  int *bad, int stride) {
-    const long long N = (long long)g.nx * g.nyz;
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (vv >= N) return;
-    const int v = (int)vv;
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-    const GradRec rec = fetch_rec(G, v);
+// Per-axis interval of the offsets any move from this voxel can have: the ongrid move plus the
+// conservative set of neargrid moves (see above).
+__device__ __forceinline__ void move_ranges(const GradRec &rec, int lo[3], int hi[3]) {
     const int code = key_code(rec.key), og = key_og(rec.key);
-    const int o0 = og / 9 - 1, o1 = (og / 3) % 3 - 1, o2 = og % 3 - 1;
-    int lo0 = o0, hi0 = o0, lo1 = o1, hi1 = o1, lo2 = o2, hi2 = o2;  // the ongrid move
+    lo[0] = hi[0] = og / 9 - 1; lo[1] = hi[1] = (og / 3) % 3 - 1; lo[2] = hi[2] = og % 3 - 1;
     if (code != XB_STAY_CODE) {
         const int i0 = (code & 3) - 1, i1 = ((code >> 2) & 3) - 1, i2 = (code >> 4) - 1;
-        lo0 = min(lo0, i0 - (rec.r0 < 1e-12)); hi0 = max(hi0, i0 + (rec.r0 > -1e-12));
-        lo1 = min(lo1, i1 - (rec.r1 < 1e-12)); hi1 = max(hi1, i1 + (rec.r1 > -1e-12));
-        lo2 = min(lo2, i2 - (rec.r2 < 1e-12)); hi2 = max(hi2, i2 + (rec.r2 > -1e-12));
-    }
-    for (int m = 0; m < n_max; m++) {
-        const int t0 = x - mxyz[3 * m], t1 = y - mxyz[3 * m + 1], t2 = z - mxyz[3 * m + 2];
-        const int d = max(max(min_image_abs(t0, g.nx), min_image_abs(t1, g.ny)), min_image_abs(t2, g.nz));
-        if (d > rcap[m]) continue;
-        int D = max(min_image_abs(t0 + lo0, g.nx), min_image_abs(t0 + hi0, g.nx));
-        D = max(D, max(min_image_abs(t1 + lo1, g.ny), min_image_abs(t1 + hi1, g.ny)));
-        D = max(D, max(min_image_abs(t2 + lo2, g.nz), min_image_abs(t2 + hi2, g.nz)));
-        for (int R = d; R < D; R++) bad[m * stride + R] = 1;
+        lo[0] = min(lo[0], i0 - (rec.r0 < 1e-12)); hi[0] = max(hi[0], i0 + (rec.r0 > -1e-12));
+        lo[1] = min(lo[1], i1 - (rec.r1 < 1e-12)); hi[1] = max(hi[1], i1 + (rec.r1 > -1e-12));
+        lo[2] = min(lo[2], i2 - (rec.r2 < 1e-12)); hi[2] = max(hi[2], i2 + (rec.r2 > -1e-12));
     }
 }
-// stamp box id `id` into the key of every voxel of B_R(m)
+__device__ __forceinline__ int wrap_any(int v, int n) { v %= n; return v < 0 ? v + n : v; }
+
+// Closed cubes around the maxima, found in batches of K shells: the launch visits, for box m, the
+// voxels at L-inf distance d in [rlo, rlo+K] of the maximum.  A voxel at distance d whose farthest
+// successor is at distance D violates the cubes d <= R < D (moves are at most 2 voxels long, so
+// only the two outer shells of a cube can violate it).
+__global__ __launch_bounds__(TPB) void k_box_shells(GridL g, const GradRec *__restrict__ G,
+                                                    const int *__restrict__ mxyz, const int *__restrict__ rcap,
+                                                    int rlo, int K, int *bad, int stride) {
+    const int m = blockIdx.y;
+    const int rhi = min(rlo + K, rcap[m]);
+    if (rhi < rlo) return;
+    const int w = 2 * rhi + 1;
+    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= (long long)w * w * w) return;
+    const int o[3] = {(int)(t / ((long long)w * w)) - rhi, (int)((t / w) % w) - rhi, (int)(t % w) - rhi};
+    const int d = max(max(abs(o[0]), abs(o[1])), abs(o[2]));
+    if (d < rlo) return;
+    const int x = wrap_any(mxyz[3 * m] + o[0], g.nx), y = wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
+              z = wrap_any(mxyz[3 * m + 2] + o[2], g.nz);
+    const GradRec rec = fetch_rec(G, (x * g.ny + y) * g.nz + z);
+    int lo[3], hi[3];
+    move_ranges(rec, lo, hi);
+    int D = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));
+    for (int R = d; R < D; R++) bad[m * stride + R] = 1;
+}
+// stamp box id `id` into the key of every voxel of the cube B_R(m)
 __global__ __launch_bounds__(TPB) void k_box_stamp(GridL g, GradRec *G, int mx, int my, int mz, int R, int id) {
     const int w = 2 * R + 1;
     const long long n = (long long)w * w * w;
     const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
     if (t >= n) return;
     const int dz = (int)(t % w), dy = (int)((t / w) % w), dx = (int)(t / ((long long)w * w));
-    const int x = ((mx + dx - R) % g.nx + g.nx) % g.nx, y = ((my + dy - R) % g.ny + g.ny) % g.ny,
-              z = ((mz + dz - R) % g.nz + g.nz) % g.nz;
+    const int x = wrap_any(mx + dx - R, g.nx), y = wrap_any(my + dy - R, g.ny), z = wrap_any(mz + dz - R, g.nz);
     long long *kp = reinterpret_cast<long long *>(&G[(x * g.ny + y) * g.nz + z].key);
     *kp = (*kp & ~(0x3FFLL << 11)) | ((long long)id << 11);
 }
@@ -1272,7 +1281,7 @@ static int read_counter(xb_ctx *c, int idx, int *out);
 static GridL light(const Grid &g);
 
 // layout of the small device int buffer used by the table build (c->boxbuf)
-enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 4352, BB_BOXMAX = 4608, BB_BAD = 8192,
+enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 4352, BB_BOXMAX = 4608, BB_EXT = 5632, BB_BAD = 8192,
        BB_TOTAL = 1 << 20, XB_BOX_SEEDS_MAX = 64 };
 
 // (re)build the gradient-field table from the resident density; with `boxes`, also find and stamp
@@ -1323,28 +1332,48 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     HIPCHK(hipMemcpyAsync(c->boxbuf + BB_MXYZ, mxyz.data(), 3 * ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, rcap.data(), ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->boxbuf + BB_BAD, 0, (size_t)ns * stride * sizeof(int), c->stream));
-    k_box_scan<<<nblocks(c->N), TPB, 0, c->stream>>>(light(g), c->grad, ns, c->boxbuf + BB_MXYZ, c->boxbuf + BB_RCAP,
-                                                    c->boxbuf + BB_BAD, stride);
-    HIPCHK(hipGetLastError());
-    std::vector<int> bad((size_t)ns * stride);
-    HIPCHK(hipMemcpyAsync(bad.data(), c->boxbuf + BB_BAD, bad.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // shells in batches of K radii; a box stops growing after a batch without any closed radius
+    const int K = 32;
+    std::vector<int> best(ns, 0), cap_now(rcap), bad((size_t)ns * stride);
+    int rcap_max = 0;
+    for (int m = 0; m < ns; m++) rcap_max = std::max(rcap_max, rcap[m]);
+    for (int rlo = 0; rlo <= rcap_max; rlo += K + 1) {
+        int rtop = 0;
+        for (int m = 0; m < ns; m++) rtop = std::max(rtop, std::min(rlo + K, cap_now[m]));
+        if (rtop < rlo) break;
+        const long long w = 2LL * rtop + 1;
+        dim3 grid(nblocks(w * w * w), ns);
+        k_box_shells<<<grid, TPB, 0, c->stream>>>(light(g), c->grad, c->boxbuf + BB_MXYZ, c->boxbuf + BB_RCAP, rlo, K,
+                                                  c->boxbuf + BB_BAD, stride);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(bad.data(), c->boxbuf + BB_BAD, bad.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        bool any = false;
+        for (int m = 0; m < ns; m++) {
+            if (cap_now[m] < rlo) continue;
+            bool found = false;
+            // radius R is decided once shells R-1 and R were visited: R <= rlo + K - 0 within this batch
+            for (int R = std::max(rlo, 1); R <= std::min(rlo + K, cap_now[m]); R++)
+                if (!bad[(size_t)m * stride + R]) { best[m] = R; found = true; }
+            if (found) any = true;
+            else cap_now[m] = rlo - 1;  // stop growing this box
+        }
+        if (!any) break;
+        HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, cap_now.data(), ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
     std::vector<int> box_max;
     for (int m = 0; m < ns; m++) {
-        int best = 0;
-        for (int R = 1; R <= rcap[m]; R++)
-            if (!bad[(size_t)m * stride + R]) best = R;
-        if (best < 1 || (int)box_max.size() >= XB_MAX_BOXES) continue;
+        if (best[m] < 1 || (int)box_max.size() >= XB_MAX_BOXES) continue;
         box_max.push_back(seeds[m]);
-        const long long w = 2LL * best + 1, nvox = w * w * w;
+        const long long w = 2LL * best[m] + 1, nvox = w * w * w;
         k_box_stamp<<<nblocks(nvox), TPB, 0, c->stream>>>(light(g), c->grad, mxyz[3 * m], mxyz[3 * m + 1], mxyz[3 * m + 2],
-                                                         best, (int)box_max.size());
+                                                         best[m], (int)box_max.size());
         c->box_voxels += nvox;
     }
     HIPCHK(hipGetLastError());
     if (!box_max.empty())
         HIPCHK(hipMemcpyAsync(c->boxbuf + BB_BOXMAX, box_max.data(), box_max.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // box_max (host vector) must outlive the copy
+    HIPCHK(hipStreamSynchronize(c->stream));  // host vectors must outlive the copies
     c->n_boxes = (int)box_max.size();
     return XB_OK;
 }
