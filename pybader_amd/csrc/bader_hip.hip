@@ -261,6 +261,118 @@ __global__ __launch_bounds__(TPB) void k_box_stamp(GridL g, GradRec *G, int mx, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Growing the trapping regions brick by brick (8x8x8 voxels).  Let U be a union of sets certain
+// for maximum m (closed boxes, earlier bricks).  A brick B without a 26-neighbour maximum whose
+// every possible move (any dr) from every voxel lands in B itself or in bricks that are certain
+// for the SAME m keeps U + B closed, and a trajectory cannot stay in B forever (it only ends on
+// a maximum), so it must enter U: B is certain for m as well.  One round tests the uncertain
+// bricks that touch the certain region of the previous round (deterministic: reads `blab` of the
+// previous round only) and stamps the ones that pass.
+// ---------------------------------------------------------------------------------------------
+#define BRK 8
+// blab: 0 unknown, id > 0 certain for box id, -1 never (holds a maximum)
+__global__ void k_brick_seed(GridL g, int nb0, int nb1, int nb2, int n_boxes, const int *__restrict__ mxyz,
+                             const int *__restrict__ radius, int *blab) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb0 * nb1 * nb2) return;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int lab = 0;
+    for (int m = 0; m < n_boxes; m++) {
+        const int R = radius[m];
+        // the brick [8b, 8b+7] lies inside the cube iff both ends are within R of the maximum on
+        // every axis (minimum image; boxes never wrap onto themselves)
+        bool in = true;
+        const int n3[3] = {g.nx, g.ny, g.nz}, bb[3] = {b0, b1, b2};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            int lo = bb[j] * BRK - mxyz[3 * m + j];
+            lo = ((lo % n3[j]) + n3[j]) % n3[j];
+            if (lo > n3[j] / 2) lo -= n3[j];
+            in &= (lo >= -R) && (lo + BRK - 1 <= R);
+        }
+        if (in) lab = m + 1;
+    }
+    blab[b] = lab;
+}
+// bmask[K]: bit k (k = (d0+1)*9+(d1+1)*3+(d2+1), d = brick offset) is set when some possible move
+// of some voxel of brick K lands in the neighbour brick K+d (moves are <= 2 voxels: only adjacent
+// bricks); bit 27 is set when the brick holds a 26-neighbour maximum.  Depends on the table only.
+__global__ __launch_bounds__(TPB) void k_brick_mask(GridL g, const GradRec *__restrict__ G, int nb1, int nb2,
+                                                    int *__restrict__ bmask) {
+    __shared__ int s_mask;
+    if (threadIdx.x == 0) s_mask = 0;
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int mine = 0;
+    for (int t = threadIdx.x; t < BRK * BRK * BRK; t += TPB) {
+        const int o[3] = {t / (BRK * BRK), (t / BRK) % BRK, t % BRK};
+        const GradRec rec = fetch_rec(G, ((b0 * BRK + o[0]) * g.ny + b1 * BRK + o[1]) * g.nz + b2 * BRK + o[2]);
+        if (key_og(rec.key) == XB_OG_SELF) mine |= 1 << 27;
+        int lo[3], hi[3], k0[3], k1[3];
+        move_ranges(rec, lo, hi);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {  // brick offset reached at the low / high end of the move interval
+            k0[j] = (o[j] + lo[j] < 0) ? -1 : 0;
+            k1[j] = (o[j] + hi[j] >= BRK) ? 1 : 0;
+        }
+        for (int c0 = k0[0]; c0 <= k1[0]; c0++)
+            for (int c1 = k0[1]; c1 <= k1[1]; c1++)
+                for (int c2 = k0[2]; c2 <= k1[2]; c2++) mine |= 1 << ((c0 + 1) * 9 + (c1 + 1) * 3 + (c2 + 1));
+    }
+    atomicOr(&s_mask, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) bmask[b] = s_mask & ~(1 << 13);  // staying inside the brick is always allowed
+}
+__device__ __forceinline__ int brick_nb(int b0, int b1, int b2, int k, int nb0, int nb1, int nb2) {
+    return (wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2);
+}
+// provisional labels: an unlabelled brick adopts the label of a labelled brick it can move into
+// (smallest label on ties); `plab` double-buffered by the caller.  Any guess is sound -- the kill
+// iterations below decide -- a good guess only makes the certain regions larger.
+__global__ void k_brick_propagate(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
+                                  const int *__restrict__ pin, int *__restrict__ pout, int *changed) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb0 * nb1 * nb2) return;
+    int l = pin[b];
+    if (l == 0 && !(bmask[b] >> 27)) {
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        const int m = bmask[b];
+        int best = 0;
+        for (int k = 0; k < 27; k++)
+            if ((m >> k) & 1) {
+                const int q = pin[brick_nb(b0, b1, b2, k, nb0, nb1, nb2)];
+                if (q > 0 && (best == 0 || q < best)) best = q;
+            }
+        if (best) { l = best; *changed = 1; }
+    }
+    pout[b] = l;
+}
+// kill iterations (greatest fixpoint): a non-seed brick stays alive for its label m only while it
+// holds no maximum and every brick it can move into is alive with the same label.  What survives,
+// together with the seed cubes, is closed under every possible move: a trapping region of m.
+__global__ void k_brick_kill(int nb0, int nb1, int nb2, const int *__restrict__ bmask, const int *__restrict__ seed,
+                             const int *__restrict__ ain, int *__restrict__ aout, int *changed) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb0 * nb1 * nb2) return;
+    int l = ain[b];
+    if (l > 0 && seed[b] == 0) {
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        const int m = bmask[b];
+        bool ok = !(m >> 27);
+        for (int k = 0; k < 27 && ok; k++)
+            if ((m >> k) & 1) ok = (ain[brick_nb(b0, b1, b2, k, nb0, nb1, nb2)] == l);
+        if (!ok) { l = 0; *changed = 1; }
+    }
+    aout[b] = l;
+}
+__global__ void k_count_positive(const int *__restrict__ a, int n, int *count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long b = __ballot(i < n && a[i] > 0);
+    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(count, __popcll(b));
+}
+
+// ---------------------------------------------------------------------------------------------
 // neargrid assignment: every owned non-vacuum voxel follows its own dr=0 trajectory
 // (refinement.py:17-322 stepping rules without the early stop) to the maximum it reaches.
 // One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
@@ -272,7 +384,8 @@ __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
 
 template <int K>
 __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
-                                                  const int *__restrict__ box_max, int *labels, int *first,
+                                                  const int *__restrict__ box_max, const int *__restrict__ blab,
+                                                  int nb1, int nb2, int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
                                                   int *ovf_count, int ovf_cap, int maxsteps, int opt) {
     // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
@@ -312,9 +425,13 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     if (valid && labels[v] != -1) {
         px = sx; py = sy; pz = sz;
         lp = v;
-        rec = fetch_rec(G, v);
-        const int b = key_box(rec.key);
-        if (b) result = box_max[b - 1];  // starts inside a trapping box: ends at its maximum
+        // trapping regions: brick labels (grids made of whole 8^3 bricks) or box ids in the keys
+        int b = blab ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
+        if (b <= 0) {
+            rec = fetch_rec(G, v);
+            b = key_box(rec.key);
+        }
+        if (b > 0) result = box_max[b - 1];  // starts inside a trapping region: ends at its maximum
         else { w.init(v, rec.key); moving = true; }
     }
     while (__any(moving)) {
@@ -341,9 +458,10 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
                 }
             }
             if (moving) {
+                const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
                 const GradRec nr = fetch_rec(G, lq);
-                const int b = key_box(nr.key);
-                if (b) {  // arrived inside a trapping box (q cannot be an old path voxel: the
+                const int b = bl > 0 ? bl : key_box(nr.key);
+                if (b) {  // arrived inside a trapping region (q cannot be an old path voxel: the
                     result = box_max[b - 1];  // trajectory would have stopped there already)
                     moving = false;
                 } else if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
@@ -992,6 +1110,9 @@ struct xb_ctx {
     int n_boxes = 0;
     long long box_voxels = 0;
     int opt_boxes = 1;
+    int opt_bricks = 1;
+    int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
+    int nbk[3] = {0, 0, 0};
     int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
     bool grad_valid = false;
     int *labels = nullptr;
@@ -1301,6 +1422,7 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     c->grad_valid = true;
     c->n_boxes = 0;
     c->box_voxels = 0;
+    c->blab = nullptr;
     if (!boxes || !c->opt_boxes) return XB_OK;
     int ns = 0;
     if (int rc = read_counter(c, 9, &ns)) return rc;
@@ -1332,7 +1454,10 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     HIPCHK(hipMemcpyAsync(c->boxbuf + BB_MXYZ, mxyz.data(), 3 * ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, rcap.data(), ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->boxbuf + BB_BAD, 0, (size_t)ns * stride * sizeof(int), c->stream));
-    // shells in batches of K radii; a box stops growing after a batch without any closed radius
+    // shells in batches of K radii; a box stops growing after a batch without any closed radius.
+    // With brick growth available the cubes are only seeds: one batch (R <= K) is enough.
+    const bool bricks = c->opt_bricks && g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 &&
+                        4LL * (c->N / (BRK * BRK * BRK)) <= c->N;
     const int K = 32;
     std::vector<int> best(ns, 0), cap_now(rcap), bad((size_t)ns * stride);
     int rcap_max = 0;
@@ -1352,27 +1477,69 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
         for (int m = 0; m < ns; m++) {
             if (cap_now[m] < rlo) continue;
             bool found = false;
-            // radius R is decided once shells R-1 and R were visited: R <= rlo + K - 0 within this batch
             for (int R = std::max(rlo, 1); R <= std::min(rlo + K, cap_now[m]); R++)
                 if (!bad[(size_t)m * stride + R]) { best[m] = R; found = true; }
             if (found) any = true;
             else cap_now[m] = rlo - 1;  // stop growing this box
         }
-        if (!any) break;
+        if (!any || bricks) break;
         HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, cap_now.data(), ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
-    std::vector<int> box_max;
+    std::vector<int> box_max, bx, br;
     for (int m = 0; m < ns; m++) {
         if (best[m] < 1 || (int)box_max.size() >= XB_MAX_BOXES) continue;
         box_max.push_back(seeds[m]);
-        const long long w = 2LL * best[m] + 1, nvox = w * w * w;
-        k_box_stamp<<<nblocks(nvox), TPB, 0, c->stream>>>(light(g), c->grad, mxyz[3 * m], mxyz[3 * m + 1], mxyz[3 * m + 2],
-                                                         best[m], (int)box_max.size());
-        c->box_voxels += nvox;
+        for (int k = 0; k < 3; k++) bx.push_back(mxyz[3 * m + k]);
+        br.push_back(best[m]);
+        if (!bricks) {  // no brick labels: the cube is stamped into the keys
+            const long long w = 2LL * best[m] + 1, nvox = w * w * w;
+            k_box_stamp<<<nblocks(nvox), TPB, 0, c->stream>>>(light(g), c->grad, mxyz[3 * m], mxyz[3 * m + 1], mxyz[3 * m + 2],
+                                                             best[m], (int)box_max.size());
+            c->box_voxels += nvox;
+        }
     }
     HIPCHK(hipGetLastError());
-    if (!box_max.empty())
-        HIPCHK(hipMemcpyAsync(c->boxbuf + BB_BOXMAX, box_max.data(), box_max.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int nbx = (int)box_max.size();
+    if (nbx)
+        HIPCHK(hipMemcpyAsync(c->boxbuf + BB_BOXMAX, box_max.data(), nbx * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // grow the certain regions brick by brick from the bricks inside the seed cubes
+    if (nbx && bricks) {
+        const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+        // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers
+        int *seed = c->list, *bmask = c->list + nbr, *buf[2] = {c->list + 2 * nbr, c->list + 3 * nbr};
+        HIPCHK(hipMemcpyAsync(c->boxbuf + BB_MXYZ, bx.data(), bx.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, br.data(), br.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        k_brick_seed<<<(nbr + 255) / 256, 256, 0, c->stream>>>(light(g), nb0, nb1, nb2, nbx, c->boxbuf + BB_MXYZ,
+                                                             c->boxbuf + BB_RCAP, seed);
+        k_brick_mask<<<nbr, TPB, 0, c->stream>>>(light(g), c->grad, nb1, nb2, bmask);
+        HIPCHK(hipMemcpyAsync(buf[0], seed, nbr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        int cur = 0;
+        const int max_rounds = 2 * (nb0 + nb1 + nb2) + 8;
+        for (int phase = 0; phase < 2; phase++) {  // 0: propagate provisional labels, 1: kill violators
+            for (int round = 1; round <= max_rounds; round++) {
+                if ((round & 3) == 1) HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
+                if (phase == 0)
+                    k_brick_propagate<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, bmask, buf[cur], buf[1 - cur], c->counters + 11);
+                else
+                    k_brick_kill<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf[cur], buf[1 - cur], c->counters + 11);
+                cur = 1 - cur;
+                if ((round & 3) == 0) {  // poll the change flag of the last four rounds
+                    HIPCHK(hipGetLastError());
+                    int ch = 0;
+                    if (int rc = read_counter(c, 11, &ch)) return rc;
+                    if (!ch) break;
+                }
+            }
+        }
+        int *blab = buf[cur];
+        HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
+        k_count_positive<<<(nbr + 255) / 256, 256, 0, c->stream>>>(blab, nbr, c->counters + 11);
+        int ncertain = 0;
+        if (int rc = read_counter(c, 11, &ncertain)) return rc;
+        c->box_voxels = (long long)ncertain * BRK * BRK * BRK;
+        c->blab = blab;
+        c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
+    }
     HIPCHK(hipStreamSynchronize(c->stream));  // host vectors must outlive the copies
     c->n_boxes = (int)box_max.size();
     return XB_OK;
@@ -1431,7 +1598,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
             const int tpb = c->opt_trace_tpb;
             k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
-                light(g), c->grad, c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
+                light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
                 c->counters + 1, c->ovf_cap, maxsteps, opt);
         }
         HIPCHK(hipGetLastError());
@@ -1784,7 +1951,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
 int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (key == 0) c->opt_trace = value;
-    else if (key == 1) c->opt_boxes = value;
+    else if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;

@@ -92,17 +92,22 @@ def test_slabs_equal_one_gpu_256():
 
 
 @pytest.mark.parametrize('size,lattice', [(256, synth.CUBIC6), (192, synth.TRICLINIC), (512, synth.CUBIC6)])
-def test_trapping_boxes_do_not_change_the_map(size, lattice):
-    """The trapping-box early exit (k_box_scan) is exact by construction; check it anyway against the
-    plain full-trajectory trace at sizes the CPU oracle cannot reach."""
+def test_trapping_regions_do_not_change_the_map(size, lattice):
+    """The trapping-region early exit (closed cubes + brick growth) is exact by construction; check it
+    anyway against the plain full-trajectory trace at sizes the CPU oracle cannot reach."""
     ctx = _lib.Context(0)
     shape = (size,) * 3
-    ctx.set_option(1, 0)
+    ctx.set_option(1, 0)                      # plain tracing
     n0, max0, lab0 = run(ctx, shape, lattice)
     assert ctx.box_stats() == (0, 0)
-    ctx.set_option(1, 1)
+    ctx.set_option(1, 1)                      # closed cubes only
     n1, max1, lab1 = run(ctx, shape, lattice)
-    nb, nv = ctx.box_stats()
-    assert nb == n1 and nv > 0.05 * size ** 3
+    nb, nv1 = ctx.box_stats()
+    assert nb == n1 and nv1 > 0.05 * size ** 3
     assert n0 == n1 and np.array_equal(max0, max1) and np.array_equal(lab0, lab1)
+    ctx.set_option(1, 3)                      # cubes + brick growth (the default)
+    n2, max2, lab2 = run(ctx, shape, lattice)
+    nb, nv2 = ctx.box_stats()
+    assert nv2 > nv1
+    assert n0 == n2 and np.array_equal(max0, max2) and np.array_equal(lab0, lab2)
     ctx.close()
