@@ -123,14 +123,28 @@ __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *f
 // depends on the carried remainder `dr`, so every trajectory step afterwards is ONE 32-byte gather.
 // 26-neighbour maxima (ongrid successor == self) are appended to `seeds`.
 // ---------------------------------------------------------------------------------------------
-#define GT_X 4
+#define GT_X 8
 #define GT_Y 8
 #define GT_Z 64
+// The tile is 8 whole 8^3 bricks in a row along z; when the grid is made of whole bricks
+// (`bmask` != null) the block also reduces, per brick, which neighbour bricks any possible move of
+// its voxels can reach (the k_brick_* kernels below work on these masks alone).
+__device__ __forceinline__ void move_ranges_raw(int code, int og, double r0, double r1, double r2, int lo[3], int hi[3]) {
+    lo[0] = hi[0] = og / 9 - 1; lo[1] = hi[1] = (og / 3) % 3 - 1; lo[2] = hi[2] = og % 3 - 1;
+    if (code != XB_STAY_CODE) {
+        const int i0 = (code & 3) - 1, i1 = ((code >> 2) & 3) - 1, i2 = (code >> 4) - 1;
+        lo[0] = min(lo[0], i0 - (r0 < 1e-12)); hi[0] = max(hi[0], i0 + (r0 > -1e-12));
+        lo[1] = min(lo[1], i1 - (r1 < 1e-12)); hi[1] = max(hi[1], i1 + (r1 > -1e-12));
+        lo[2] = min(lo[2], i2 - (r2 < 1e-12)); hi[2] = max(hi[2], i2 + (r2 > -1e-12));
+    }
+}
 __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__restrict__ rho,
                                                     GradRec *__restrict__ G, int *seeds, int *seed_count,
-                                                    int seed_cap, int small) {
+                                                    int seed_cap, int small, int *__restrict__ bmask) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
+    __shared__ int s_mask[GT_Z / 8];
     const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
+    if (threadIdx.x < GT_Z / 8) s_mask[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2); i += TPB) {
         const int ez = i % (GT_Z + 2);
         const int r = i / (GT_Z + 2);
@@ -145,8 +159,9 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
     }
     __syncthreads();
     const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+    int mine = 0;  // move mask of this thread's voxels (all in brick tz >> 3 of the tile)
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
         const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
         const int x = x0 + tx, y = y0 + ty, z = z0 + tz;
         if (x >= g.nx || y >= g.ny || z >= g.nz) continue;
@@ -189,6 +204,29 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
         if (og == XB_OG_SELF) {
             const int q = atomicAdd(seed_count, 1);
             if (q < seed_cap) seeds[q] = v;
+            mine |= 1 << 27;
+        }
+        if (bmask) {  // which neighbour bricks can a move from this voxel reach (moves <= 2 voxels)
+            int lo[3], hi[3];
+            move_ranges_raw(code, og, o.r0, o.r1, o.r2, lo, hi);
+            const int ob[3] = {tx, ty, tz & 7};
+            int k0[3], k1[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                k0[j] = (ob[j] + lo[j] < 0) ? -1 : 0;
+                k1[j] = (ob[j] + hi[j] >= 8) ? 1 : 0;
+            }
+            for (int c0 = k0[0]; c0 <= k1[0]; c0++)
+                for (int c1 = k0[1]; c1 <= k1[1]; c1++)
+                    for (int c2 = k0[2]; c2 <= k1[2]; c2++) mine |= 1 << ((c0 + 1) * 9 + (c1 + 1) * 3 + (c2 + 1));
+        }
+    }
+    if (bmask) {
+        atomicOr(&s_mask[tz >> 3], mine);
+        __syncthreads();
+        if (threadIdx.x < GT_Z / 8 && z0 + threadIdx.x * 8 < g.nz) {
+            const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+            bmask[((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x] = s_mask[threadIdx.x] & ~(1 << 13);
         }
     }
 }
@@ -294,36 +332,9 @@ __global__ void k_brick_seed(GridL g, int nb0, int nb1, int nb2, int n_boxes, co
     }
     blab[b] = lab;
 }
-// bmask[K]: bit k (k = (d0+1)*9+(d1+1)*3+(d2+1), d = brick offset) is set when some possible move
-// of some voxel of brick K lands in the neighbour brick K+d (moves are <= 2 voxels: only adjacent
-// bricks); bit 27 is set when the brick holds a 26-neighbour maximum.  Depends on the table only.
-__global__ __launch_bounds__(TPB) void k_brick_mask(GridL g, const GradRec *__restrict__ G, int nb1, int nb2,
-                                                    int *__restrict__ bmask) {
-    __shared__ int s_mask;
-    if (threadIdx.x == 0) s_mask = 0;
-    __syncthreads();
-    const int b = blockIdx.x;
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int mine = 0;
-    for (int t = threadIdx.x; t < BRK * BRK * BRK; t += TPB) {
-        const int o[3] = {t / (BRK * BRK), (t / BRK) % BRK, t % BRK};
-        const GradRec rec = fetch_rec(G, ((b0 * BRK + o[0]) * g.ny + b1 * BRK + o[1]) * g.nz + b2 * BRK + o[2]);
-        if (key_og(rec.key) == XB_OG_SELF) mine |= 1 << 27;
-        int lo[3], hi[3], k0[3], k1[3];
-        move_ranges(rec, lo, hi);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {  // brick offset reached at the low / high end of the move interval
-            k0[j] = (o[j] + lo[j] < 0) ? -1 : 0;
-            k1[j] = (o[j] + hi[j] >= BRK) ? 1 : 0;
-        }
-        for (int c0 = k0[0]; c0 <= k1[0]; c0++)
-            for (int c1 = k0[1]; c1 <= k1[1]; c1++)
-                for (int c2 = k0[2]; c2 <= k1[2]; c2++) mine |= 1 << ((c0 + 1) * 9 + (c1 + 1) * 3 + (c2 + 1));
-    }
-    atomicOr(&s_mask, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) bmask[b] = s_mask & ~(1 << 13);  // staying inside the brick is always allowed
-}
+// bmask[K] (built by k_grad_field): bit k (k = (d0+1)*9+(d1+1)*3+(d2+1), d = brick offset) is set
+// when some possible move of some voxel of brick K lands in the neighbour brick K+d; bit 27 is set
+// when the brick holds a 26-neighbour maximum.
 __device__ __forceinline__ int brick_nb(int b0, int b1, int b2, int k, int nb0, int nb1, int nb2) {
     return (wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2);
 }
@@ -663,6 +674,50 @@ __device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
     return base + incl - cnt;
 }
 
+// buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
+// Lets the edge sweep skip tiles whose whole 3x3x3 surroundings carry one label (no edge possible).
+#define XB_MIXED (-2147483647 - 1)
+__global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__restrict__ labels, int nb1, int nb2,
+                                                       int *__restrict__ buni) {
+    __shared__ int s_min, s_max;
+    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int lo = 2147483647, hi = XB_MIXED;
+    for (int t = threadIdx.x; t < 512; t += TPB) {
+        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
+        lo = min(lo, l); hi = max(hi, l);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    __syncthreads();
+    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
+}
+// refinement.py:385-404 as written there: every listed edge voxel turns the known >= 0 voxels of
+// its 27-box into -1 (all -2 flags are final before this kernel starts).
+__global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known, const int *__restrict__ list, int n) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int l = (tx * g.ny + ty) * g.nz + wrapi(z + iz, g.nz);
+                if (known[l] >= 0) known[l] = -1;
+            }
+        }
+    }
+}
+
 // LDS-tiled edge_find pass 1: a block stages the labels of a 4x8x64 tile plus a one-voxel periodic
 // halo (6x10x66 ints) in LDS, every thread classifies 8 voxels from the staged 3x3x3
 // neighbourhoods, and the block appends its owned edge voxels to the edge list with ONE atomic
@@ -674,9 +729,46 @@ __device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
 __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *__restrict__ rho,
                                                          const int *__restrict__ labels,
                                                          int8_t *__restrict__ known, int xa, int nplanes,
-                                                         int *__restrict__ list, int *list_count, int small) {
+                                                         int *__restrict__ list, int *list_count, int small,
+                                                         const int *__restrict__ buni) {
     __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
     const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
+    if (buni) {
+        // every brick that meets the tile or its one-voxel halo carries the same single label: no
+        // voxel of the tile has a foreign neighbour (2 x 3 x 10 bricks, one lookup per thread)
+        __shared__ int s_lab, s_mixed;
+        if (threadIdx.x == 0) { s_lab = XB_MIXED; s_mixed = 0; }
+        __syncthreads();
+        const int nb0 = g.nx >> 3, nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        const int bx_lo = (xa + tx0 - 1) >> 3, bx_n = ((xa + tx0 + ET_X) >> 3) - bx_lo + 1;  // arithmetic shift: -1 >> 3 == -1
+        const int by_lo = (y0 - 1) >> 3, by_n = ((y0 + ET_Y) >> 3) - by_lo + 1;
+        const int bz_lo = (z0 - 1) >> 3, bz_n = ((z0 + ET_Z) >> 3) - bz_lo + 1;
+        for (int t = threadIdx.x; t < bx_n * by_n * bz_n; t += TPB) {
+            const int q0 = wrap_any(bx_lo + t / (by_n * bz_n), nb0), q1 = wrap_any(by_lo + (t / bz_n) % by_n, nb1),
+                      q2 = wrap_any(bz_lo + t % bz_n, nb2);
+            const int l = buni[(q0 * nb1 + q1) * nb2 + q2];
+            if (l == XB_MIXED) s_mixed = 1;
+            else {
+                const int old = atomicCAS(&s_lab, XB_MIXED, l);
+                if (old != XB_MIXED && old != l) s_mixed = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_mixed) {
+            const int8_t o = (s_lab == -1) ? 0 : 2;  // vacuum stays 0 (refinement.py:342-343), else "known"
+            const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int xr = tx0 + (k >> 1), y = y0 + tyb + ((k & 1) << 2), z = z0 + tz;
+                if (xr < nplanes && y < g.ny && z < g.nz) {
+                    int x = xa + xr;
+                    if (x >= g.nx) x -= g.nx;
+                    known[(x * g.ny + y) * g.nz + z] = o;
+                }
+            }
+            return;
+        }
+    }
     for (int i = threadIdx.x; i < (ET_X + 2) * (ET_Y + 2) * (ET_Z + 2); i += TPB) {
         const int ez = i % (ET_Z + 2);
         const int r = i / (ET_Z + 2);
@@ -1412,11 +1504,15 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     const Grid &g = c->g;
     ScopedTimer t(c, 4);
     HIPCHK(hipMemsetAsync(c->counters + 9, 0, sizeof(int), c->stream));
+    // brick growth needs a grid made of whole 8^3 bricks; its scratch is carved from `list`
+    const bool bricks = boxes && c->opt_boxes && c->opt_bricks && g.nx % BRK == 0 && g.ny % BRK == 0 &&
+                        g.nz % BRK == 0 && 4LL * (c->N / (BRK * BRK * BRK)) <= c->N;
+    const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
     {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
         k_grad_field<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
-                                                 BB_SEED_CAP, small);
+                                                 BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
     }
     HIPCHK(hipGetLastError());
     c->grad_valid = true;
@@ -1456,8 +1552,6 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     HIPCHK(hipMemsetAsync(c->boxbuf + BB_BAD, 0, (size_t)ns * stride * sizeof(int), c->stream));
     // shells in batches of K radii; a box stops growing after a batch without any closed radius.
     // With brick growth available the cubes are only seeds: one batch (R <= K) is enough.
-    const bool bricks = c->opt_bricks && g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 &&
-                        4LL * (c->N / (BRK * BRK * BRK)) <= c->N;
     const int K = 32;
     std::vector<int> best(ns, 0), cap_now(rcap), bad((size_t)ns * stride);
     int rcap_max = 0;
@@ -1511,7 +1605,6 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
         HIPCHK(hipMemcpyAsync(c->boxbuf + BB_RCAP, br.data(), br.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         k_brick_seed<<<(nbr + 255) / 256, 256, 0, c->stream>>>(light(g), nb0, nb1, nb2, nbx, c->boxbuf + BB_MXYZ,
                                                              c->boxbuf + BB_RCAP, seed);
-        k_brick_mask<<<nbr, TPB, 0, c->stream>>>(light(g), c->grad, nb1, nb2, bmask);
         HIPCHK(hipMemcpyAsync(buf[0], seed, nbr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
         int cur = 0;
         const int max_rounds = 2 * (nb0 + nb1 + nb2) + 8;
@@ -1722,14 +1815,25 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
         ScopedTimer t(c, 2);
         const GridL gl = light(g);
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        int *buni = nullptr;
+        if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {  // whole bricks: per-brick label uniformity first
+            buni = reinterpret_cast<int *>(c->st);             // N bytes >= N/512 ints; edge_check reuses st later
+            k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
+        }
         dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
         k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
-                                                       c->counters + 5, small);
-        k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
+                                                       c->counters + 5, small, buni);
+        if (!whole)
+            k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
     }
     HIPCHK(hipGetLastError());
     int n = 0;
     if (int rc = read_counter(c, 5, &n)) return rc;
+    if (whole && n) {  // one slab: the list holds every edge, dilate from it
+        ScopedTimer t(c, 2);
+        k_edge_dilate_list<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->known, c->list, n);
+        HIPCHK(hipGetLastError());
+    }
     c->list_n = n;           // the edge list stays valid until `known` changes
     c->list_valid = true;
     if (edges) *edges = (int64_t)n;
