@@ -109,6 +109,8 @@ def main():
     ctx.enable_timing(True)
     if 'XB_OPT_TRACE' in os.environ:
         ctx.set_option(0, int(os.environ['XB_OPT_TRACE']))
+    if 'XB_OPT_DBG' in os.environ:
+        ctx.set_option(3, int(os.environ['XB_OPT_DBG']))
     if 'XB_OPT_TPB' in os.environ:
         ctx.set_option(2, int(os.environ['XB_OPT_TPB']))
 

@@ -730,7 +730,8 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
                                                          const int *__restrict__ labels,
                                                          int8_t *__restrict__ known, int xa, int nplanes,
                                                          int *__restrict__ list, int *list_count, int small,
-                                                         const int *__restrict__ buni) {
+                                                         const int *__restrict__ buni,
+                                                         const GradRec *__restrict__ G) {
     __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
     const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
     if (buni) {
@@ -811,17 +812,30 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
                         }
                 o = 2;
                 if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
-                    const double c = rho[v];
-                    bool is_max = true;
-                    for (int dx = -1; dx < 2; dx++) {
-                        const int X = wrapi(x + dx, g.nx);
-                        for (int dy = -1; dy < 2; dy++) {
-                            const int Y = wrapi(y + dy, g.ny);
-                            for (int dz = -1; dz < 2; dz++) {
-                                const int Z = wrapi(z + dz, g.nz);
-                                if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 &&
-                                    rho[(X * g.ny + Y) * g.nz + Z] > c)
-                                    is_max = false;
+                    bool is_max = true, decided = false;
+                    if (G) {
+                        // the table knows the best distance-weighted neighbour of v; if there is one
+                        // (and it is not vacuum) that neighbour is denser than v: not a maximum.
+                        // (weighted > rho(v) implies rho(n) > rho(v); the converse can fail by
+                        // rounding, so "no such neighbour" still takes the full test)
+                        const int og = key_og(G[v].key);
+                        if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
+                            is_max = false;
+                            decided = true;
+                        }
+                    }
+                    if (!decided) {
+                        const double c = rho[v];
+                        for (int dx = -1; dx < 2; dx++) {
+                            const int X = wrapi(x + dx, g.nx);
+                            for (int dy = -1; dy < 2; dy++) {
+                                const int Y = wrapi(y + dy, g.ny);
+                                for (int dz = -1; dz < 2; dz++) {
+                                    const int Z = wrapi(z + dz, g.nz);
+                                    if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 &&
+                                        rho[(X * g.ny + Y) * g.nz + Z] > c)
+                                        is_max = false;
+                                }
                             }
                         }
                     }
@@ -1203,6 +1217,7 @@ struct xb_ctx {
     long long box_voxels = 0;
     int opt_boxes = 1;
     int opt_bricks = 1;
+    int opt_dbg = 0;
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
     int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
@@ -1822,7 +1837,7 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
         }
         dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
         k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
-                                                       c->counters + 5, small, buni);
+                                                       c->counters + 5, small, buni, c->grad_valid ? c->grad : nullptr);
         if (!whole)
             k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
     }
@@ -2056,6 +2071,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (key == 0) c->opt_trace = value;
     else if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
+    else if (key == 3) c->opt_dbg = value;
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
