@@ -1491,6 +1491,14 @@ int xb_download_known(xb_ctx *c, int8_t *known_host) {
 
 int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume) {
     NEED_GRID("xb_vacuum_assign");
+    if (vac_tol != vac_tol) {
+        // vacuum_tol=None reaches the reference's sweep as NaN (interface.py:459): `rho <= NaN` is never
+        // true, so the result is all-zero labels and zero vacuum charge/volume -- no need to read rho
+        HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+        if (vac_charge) *vac_charge = 0.;
+        if (vac_volume) *vac_volume = 0.;
+        return XB_OK;
+    }
     HIPCHK(hipMemsetAsync(c->dsum, 0, sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
     k_vacuum_assign<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, vac_tol, c->dsum, c->counters64);
@@ -1625,13 +1633,13 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
         const int max_rounds = 2 * (nb0 + nb1 + nb2) + 8;
         for (int phase = 0; phase < 2; phase++) {  // 0: propagate provisional labels, 1: kill violators
             for (int round = 1; round <= max_rounds; round++) {
-                if ((round & 3) == 1) HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
+                if ((round & 7) == 1) HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
                 if (phase == 0)
                     k_brick_propagate<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, bmask, buf[cur], buf[1 - cur], c->counters + 11);
                 else
                     k_brick_kill<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf[cur], buf[1 - cur], c->counters + 11);
                 cur = 1 - cur;
-                if ((round & 3) == 0) {  // poll the change flag of the last four rounds
+                if ((round & 7) == 0) {  // poll the change flag of the last eight rounds
                     HIPCHK(hipGetLastError());
                     int ch = 0;
                     if (int rc = read_counter(c, 11, &ch)) return rc;
