@@ -99,7 +99,8 @@ class TorchComm:
         self.transport = 'rccl-p2p' if self.device_p2p else ('gloo' if device is None else 'host-staged-gloo')
 
     def _selftest(self):
-        """ring exchange of a small device tensor; every rank must see the right payload"""
+        """ring exchange of a small device tensor + a device all-reduce; every rank must see the right
+        payload.  The verdict is agreed on over the gloo group, so all ranks pick the same transport."""
         import torch
         ok = True
         try:
@@ -110,8 +111,10 @@ class TorchComm:
                 ops = [self.dist.P2POp(self.dist.irecv, dst, prv), self.dist.P2POp(self.dist.isend, src, nxt)]
                 for w in self.dist.batch_isend_irecv(ops):
                     w.wait()
+                t = torch.tensor([self.rank + 1, 1], dtype=torch.int64, device=self.device)
+                self.dist.all_reduce(t)
                 torch.cuda.synchronize(self.device)
-                ok = bool((dst == float(prv)).all().item())
+                ok = bool((dst == float(prv)).all().item()) and t.tolist() == [self.size * (self.size + 1) // 2, self.size]
         except Exception:  # noqa: BLE001
             ok = False
         flags = [None] * self.size
@@ -124,6 +127,11 @@ class TorchComm:
         return out
 
     def sum(self, *vals):
+        if self.device_p2p:          # RCCL all-reduce of a tiny device tensor (tens of microseconds)
+            import torch
+            t = torch.tensor([int(v) for v in vals], dtype=torch.int64, device=self.device)
+            self.dist.all_reduce(t)
+            return t.tolist()
         got = self.allgather([int(v) for v in vals])
         return [sum(g[i] for g in got) for i in range(len(vals))]
 
