@@ -109,6 +109,17 @@ int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap);
 int xb_atom_assign(const double *bader_max_cart, int64_t n_max, const double *atoms_cart, int64_t n_atoms,
                    const double lattice[9], int64_t *atom_out, double *dist_out);
 
+/* thread_handlers.surface_distance (thread_handlers.py:239-297) + utils.surface_dist (utils.py:320-379)
+ * on the resident atom map (labels = atoms_volumes): runs edge_find, then returns per atom the minimum
+ * SQUARED distance of its edge voxels to the atom over the 27 periodic images (+inf: no edge voxel). */
+int xb_surface_distance(xb_ctx *c, const double lattice[9], const double *atoms_cart, int64_t n_atoms,
+                        double *min_d2, int64_t *edges);
+/* utils.volume_mask (utils.py:461-476): density where labels == vol_num, else 0 (host float64 N) */
+int xb_volume_mask(xb_ctx *c, int64_t vol_num, double *out_host);
+/* sum of the resident density / count over owned voxels with labels == value (vacuum sums when the
+ * reference density differs from the charge density, utils.py:396-400) */
+int xb_label_sum(xb_ctx *c, int64_t value, double *sum, int64_t *count);
+
 /* ---- slab halo planes (multi-GPU) -------------------------------------------------------- */
 /* Device pointers of the label / known arrays and the plane size in elements, so that the slab
  * scheduler can hand plane ranges to RCCL (ncclSend/ncclRecv) or any other transport. */

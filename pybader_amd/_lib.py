@@ -44,6 +44,9 @@ SYMBOLS = {
     'xb_charge_sum': (_int, [_vp, _dbl, _i64, _vp, _vp]),
     'xb_volume_assign': (_int, [_vp, _vp, _i64]),
     'xb_atom_assign': (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    'xb_surface_distance': (_int, [_vp, _vp, _vp, _i64, _vp, _pi64]),
+    'xb_volume_mask': (_int, [_vp, _i64, _vp]),
+    'xb_label_sum': (_int, [_vp, _i64, _pdbl, _pi64]),
     'xb_labels_ptr': (_vp, [_vp]),
     'xb_known_ptr': (_vp, [_vp]),
     'xb_density_ptr': (_vp, [_vp]),
@@ -234,6 +237,23 @@ class Context:
     def volume_assign(self, swap):
         sw = np.ascontiguousarray(swap, dtype=np.int64)
         check(self.lib.xb_volume_assign(self.h, _ptr(sw), sw.shape[0]))
+
+    def surface_distance(self, lattice, atoms_cart):
+        lat, at = _f64(lattice).reshape(9), _f64(atoms_cart).reshape(-1, 3)
+        out = np.zeros(at.shape[0], np.float64)
+        e = C.c_int64()
+        check(self.lib.xb_surface_distance(self.h, _ptr(lat), _ptr(at), at.shape[0], _ptr(out), C.byref(e)))
+        return out, e.value
+
+    def volume_mask(self, vol_num):
+        out = np.empty(self.shape, np.float64)
+        check(self.lib.xb_volume_mask(self.h, int(vol_num), _ptr(out)))
+        return out
+
+    def label_sum(self, value):
+        s, n = C.c_double(), C.c_int64()
+        check(self.lib.xb_label_sum(self.h, int(value), C.byref(s), C.byref(n)))
+        return s.value, n.value
 
     def copy_planes(self, which, to_device, host, xa, xb):
         check(self.lib.xb_copy_planes(self.h, int(which), int(to_device), _ptr(host), int(xa), int(xb)))

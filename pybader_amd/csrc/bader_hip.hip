@@ -1156,6 +1156,62 @@ __global__ __launch_bounds__(TPB) void k_charge_sum_glb(Grid g, const double *__
     if (a >= 0 && a < n_labels) { atomicAdd(&charge[a], rho[v]); atomicAdd(&count[a], 1ull); }
 }
 
+// utils.surface_dist (utils.py:320-379) over the edge list: squared minimum-image distance of every
+// edge voxel to the atom that owns it, reduced per atom with an integer atomicMin on the bit
+// pattern (non-negative doubles order like their bits), so the minimum is exact and order-free.
+__global__ __launch_bounds__(TPB) void k_surface_dist(GridL g, const int *__restrict__ labels,
+                                                      const int *__restrict__ list, int n,
+                                                      const double *__restrict__ lat, const double *__restrict__ atoms,
+                                                      int n_atoms, unsigned long long *min_d2) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    const int a = labels[v];
+    if (a < 0 || a >= n_atoms) return;
+    const int p0 = v / g.nyz;
+    const int r = v - p0 * g.nyz;
+    const int p1 = r / g.nz, p2 = r - p1 * g.nz;
+    double pc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // utils.py:357-359
+        pc[j] = lat[j] * (double)p0 / (double)g.nx;
+        pc[j] += lat[3 + j] * (double)p1 / (double)g.ny;
+        pc[j] += lat[6 + j] * (double)p2 / (double)g.nz;
+    }
+    double best = 1.7976931348623157e308;
+    for (int x = -1; x < 2; x++)
+        for (int y = -1; y < 2; y++)
+            for (int z = -1; z < 2; z++) {
+                double d2 = 0.;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {  // utils.py:369-374
+                    const double pbc = (lat[j] * (double)x + lat[3 + j] * (double)y) + lat[6 + j] * (double)z;
+                    const double e = pc[j] - (atoms[3 * a + j] + pbc);
+                    d2 = (j == 0) ? e * e : d2 + e * e;
+                }
+                if (d2 < best) best = d2;
+            }
+    atomicMin(&min_d2[a], (unsigned long long)__double_as_longlong(best));
+}
+// utils.volume_mask (utils.py:461-476)
+__global__ __launch_bounds__(TPB) void k_volume_mask(const double *__restrict__ rho, const int *__restrict__ labels,
+                                                     int vol_num, double *__restrict__ out, long long N) {
+    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v < N) out[v] = (labels[v] == vol_num) ? rho[v] : 0.;
+}
+// sum of rho and count over the owned voxels whose label equals `value` (vacuum sums with a
+// separate reference density, utils.py:396-400)
+__global__ __launch_bounds__(TPB) void k_label_sum(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
+                                                   int value, double *sum, unsigned long long *count) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    double s = 0.;
+    unsigned int n = 0;
+    if (v < vend && labels[v] == value) { s = rho[v]; n = 1; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); n += __shfl_down(n, o); }
+    if (threadIdx.x % XB_WAVE == 0 && n) { atomicAdd(sum, s); atomicAdd(count, (unsigned long long)n); }
+}
+
 // utils.volume_assign (utils.py:404-421)
 __global__ __launch_bounds__(TPB) void k_volume_assign(Grid g, int *labels, const int *__restrict__ swap, int n_swap) {
     const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
@@ -2054,6 +2110,57 @@ int xb_atom_assign(const double *b_max, int64_t n_max, const double *atoms, int6
         atom_out[i] = who;
         dist_out[i] = std::sqrt(best);
     }
+    return XB_OK;
+}
+
+// thread_handlers.surface_distance (thread_handlers.py:239-297) on the resident atom map: edge_find
+// on a fresh `known`, then the per-atom minimum squared distance of the edge voxels (+inf: no edge).
+int xb_surface_distance(xb_ctx *c, const double lattice[9], const double *atoms_cart, int64_t n_atoms,
+                        double *min_d2, int64_t *edges_out) {
+    NEED_GRID("xb_surface_distance");
+    if (n_atoms <= 0 || n_atoms > 100000) return fail(XB_E_ARG, "xb_surface_distance: bad atom count");
+    int64_t edges = 0;
+    if (int rc = xb_edge_find(c, &edges)) return rc;
+    if (edges_out) *edges_out = edges;
+    std::vector<unsigned long long> init(n_atoms, 0x7FF0000000000000ULL);  // +inf
+    double *dbuf = (double *)c->stage;  // lattice (9), atoms (3n), minima (n as u64)
+    unsigned long long *dmin = (unsigned long long *)(dbuf + 16 + 3 * n_atoms);
+    HIPCHK(hipMemcpyAsync(dbuf, lattice, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dbuf + 16, atoms_cart, 3 * n_atoms * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dmin, init.data(), n_atoms * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    if (edges)
+        k_surface_dist<<<nblocks(edges), TPB, 0, c->stream>>>(light(c->g), c->labels, c->list, (int)edges, dbuf, dbuf + 16,
+                                                             (int)n_atoms, dmin);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(min_d2, dmin, n_atoms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+int xb_volume_mask(xb_ctx *c, int64_t vol_num, double *out_host) {
+    NEED_GRID("xb_volume_mask");
+    double *tmp = (double *)c->stage;  // N*8 bytes
+    k_volume_mask<<<nblocks(c->N), TPB, 0, c->stream>>>(c->rho, c->labels, (int)vol_num, tmp, c->N);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_host, tmp, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+int xb_label_sum(xb_ctx *c, int64_t value, double *sum, int64_t *count) {
+    NEED_GRID("xb_label_sum");
+    const Grid &g = c->g;
+    HIPCHK(hipMemsetAsync(c->dsum, 0, sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
+    k_label_sum<<<nblocks((long long)(g.x1 - g.x0) * g.nyz), TPB, 0, c->stream>>>(g, c->rho, c->labels, (int)value, c->dsum, c->counters64);
+    HIPCHK(hipGetLastError());
+    double s;
+    unsigned long long n;
+    HIPCHK(hipMemcpyAsync(&s, c->dsum, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&n, c->counters64, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (sum) *sum = s;
+    if (count) *count = (int64_t)n;
     return XB_OK;
 }
 

@@ -8,7 +8,7 @@ numpy operations, in the same order, as the reference (they are inputs of every 
 bit-identical)."""
 import numpy as np
 
-from .thread_handlers import assign_to_atoms, bader_calc, dtype_calc, refine
+from .thread_handlers import assign_to_atoms, bader_calc, dtype_calc, refine, surface_distance
 from .utils import charge_sum, vacuum_assign
 
 
@@ -141,6 +141,16 @@ class Bader:
         self.bader_atoms, self.bader_distance, self.atoms_volumes = assign_to_atoms(
             self.bader_maxima, self.atoms, self.lattice, self.bader_volumes, self.threads)
 
+    @property
+    def voxel_offset(self):
+        return np.dot(self.voxel_offset_fractional, self.voxel_lattice)                # interface.py:273-277
+
+    def min_surface_distance(self):
+        """interface.py:527-534."""
+        atoms = self.atoms - self.voxel_offset
+        self.atoms_surface_distance = surface_distance(self.reference, self.atoms_volumes, self.lattice, atoms,
+                                                       self.threads)
+
     def sum_volumes(self, bader=False):
         """interface.py:492-525 (charge only; the spin branch re-runs charge_sum on the spin array)."""
         if bader:
@@ -153,8 +163,8 @@ class Bader:
             charge_sum(self.atoms_charge, self.atoms_volume, self.voxel_volume, self.density, self.atoms_volumes)
 
     def __call__(self, **kwargs):
-        """The compute part of Bader.__call__ (interface.py:399-416); surface distance, export and
-        the pickle/dat output stay with the reference class (out of the hot path)."""
+        """The compute part of Bader.__call__ (interface.py:399-416); export and the pickle/dat output stay
+        with the reference class (out of the hot path)."""
         for k, v in kwargs.items():
             setattr(self, k, v)
         self.volumes_init()
@@ -166,4 +176,5 @@ class Bader:
         if self.speed_flag:
             self.refine_volumes(self.atoms_volumes)
             del self.bader_volumes
+        self.min_surface_distance()
         self.sum_volumes()

@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib, methods, refinement
 from .utils import atom_assign, dtype_calc, ensure_density
 
-__all__ = ['bader_calc', 'refine', 'assign_to_atoms', 'dtype_calc']
+__all__ = ['bader_calc', 'refine', 'assign_to_atoms', 'surface_distance', 'dtype_calc']
 
 VERBOSE = True
 
@@ -72,3 +72,22 @@ def assign_to_atoms(bader_max, atoms, lattice, volumes, threads):
     ctx.volume_assign(bader_atoms)
     atom_volumes = ctx.download_labels(np.dtype(dtype_calc(-atoms.shape[0])))
     return bader_atoms, bader_distance, atom_volumes
+
+
+def surface_distance(density, volumes, lattice, atoms, threads):
+    """thread_handlers.surface_distance (thread_handlers.py:239-297): minimum distance from every atom
+    to the surface (edge voxels) of its volume; 0 for atoms whose volume has no edge voxel."""
+    _say("\n  Calculating min. surface disance:")
+    ctx = _lib.default_context()
+    if ctx.shape != tuple(volumes.shape):
+        ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
+    ensure_density(ctx, density)
+    ctx.upload_labels(volumes)
+    d2, edges = ctx.surface_distance(lattice, atoms)
+    if edges == 0:
+        _say("  No edges found.")          # thread_handlers.py:256-258 (returns None)
+        return
+    out = np.zeros(atoms.shape[0], dtype=np.float64)
+    hit = np.isfinite(d2)
+    out[hit] = d2[hit]**.5                   # utils.py:377
+    return out

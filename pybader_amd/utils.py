@@ -47,11 +47,13 @@ def vacuum_assign(reference, volumes, vac_tol, density, voxel_volume):
     if ctx.shape != tuple(volumes.shape):
         ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
     same = reference is density or (reference.shape == density.shape and np.shares_memory(reference, density))
-    if not same:
-        raise NotImplementedError("vacuum_assign with a separate reference density (bader -ref) is not "
-                                  "on the GPU path yet")
     ensure_density(ctx, reference)
     charge, volume = ctx.vacuum_assign(vac_tol, voxel_volume)
+    if not same and volume:
+        # vacuum is decided on `reference`, its charge is summed over `density` (utils.py:396-400)
+        ensure_density(ctx, density)
+        s, n = ctx.label_sum(-1)
+        charge, volume = s * voxel_volume, n * voxel_volume
     # the device sets non-vacuum voxels to 0; the reference leaves them untouched
     if np.any(volumes):
         keep = volumes.copy()
@@ -89,3 +91,13 @@ def volume_assign(volumes, swap, i_c=None):
     ctx.upload_labels(volumes)
     ctx.volume_assign(swap)
     ctx.download_labels(out=volumes)
+
+
+def volume_mask(volumes, density, vol_num):
+    """utils.volume_mask (utils.py:461-476): `density` where volumes == vol_num, zero elsewhere."""
+    ctx = _lib.default_context()
+    if ctx.shape != tuple(volumes.shape):
+        ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
+    ensure_density(ctx, density)
+    ctx.upload_labels(volumes)
+    return ctx.volume_mask(vol_num)

@@ -296,3 +296,50 @@ def test_python_mirror_api(ctx):
     assert thread_handlers.refine('ongrid', ('changed', 2), rho, v, g['dist_mat'], g['T_grad'], 1) is None
     assert thread_handlers.refine('neargrid', ('changed', 0), rho, v, g['dist_mat'], g['T_grad'], 1) is None
     assert np.array_equal(v, g['ng_main'])
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_surface_distance(ctx, name):
+    """thread_handlers.surface_distance on the reference's atom map."""
+    g, rho = setup_case(ctx, name)
+    atoms_cart = synth.atoms_cartesian(g['atoms'], g['lattice'])
+    ctx.upload_labels(g['ng_atoms_volumes'])
+    d2, edges = ctx.surface_distance(g['lattice'], atoms_cart)
+    want = g['ng_atoms_surface_distance']
+    got = np.where(np.isfinite(d2), np.sqrt(d2), 0.0)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_speed_profile_and_extras_through_python_mirror(ctx):
+    """speed profile (entry_points.py:340-345) end to end, volume_mask, vacuum sums with a separate reference."""
+    from pybader_amd import thread_handlers, utils
+    from pybader_amd.interface import Bader
+    thread_handlers.VERBOSE = False
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    atoms_cart = synth.atoms_cartesian(g['atoms'], g['lattice'])
+    b = Bader({'charge': rho}, g['lattice'], atoms_cart, method='ongrid', refine_method='neargrid',
+              refine_mode=('changed', 3), speed_flag=True)
+    b()
+    assert not hasattr(b, 'bader_volumes')
+    assert np.array_equal(b.bader_atoms, g['og_bader_atoms'])
+    assert b.atoms_volumes.dtype == g['og_atoms_volumes_speed'].dtype
+    assert np.array_equal(b.atoms_volumes, g['og_atoms_volumes_speed'])
+    np.testing.assert_allclose(b.atoms_charge, g['og_atoms_charge_speed'], rtol=1e-9)
+    np.testing.assert_allclose(b.atoms_volume, g['og_atoms_volume_speed'], rtol=1e-9)
+    # default profile also fills the surface distances
+    b2 = Bader({'charge': rho}, g['lattice'], atoms_cart)
+    b2()
+    np.testing.assert_allclose(b2.atoms_surface_distance, g['ng_atoms_surface_distance'], rtol=1e-12)
+    # volume_mask
+    m = utils.volume_mask(b2.bader_volumes, rho, 3)
+    assert np.array_equal(m, np.where(b2.bader_volumes == 3, rho, 0.0))
+    # vacuum decided on a reference density, charge summed on another (bader -ref)
+    ref = rho * 0.5 + 0.01
+    vol = np.zeros(rho.shape, np.int32)
+    vol, vc, vv = utils.vacuum_assign(ref, vol, 0.03, rho, 0.25)
+    mask = ref <= 0.03
+    assert np.array_equal(vol == -1, mask) and mask.any()
+    np.testing.assert_allclose(vc, rho[mask].sum() * 0.25, rtol=1e-9)
+    np.testing.assert_allclose(vv, mask.sum() * 0.25, rtol=1e-12)
+    utils.forget_density(_lib.default_context())
