@@ -3,7 +3,7 @@
 on a synthetic 512^3 grid (BASELINE config 3), data resident in HBM, on N GPUs of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--method neargrid]
-                    [--refine changed:2] [--cpu-size 160] [--no-cpu]
+                    [--refine changed:2] [--cpu-size 320] [--no-cpu]
 
 A "step" is one full pass of the hot path over the grid: volumes_init (label reset) -> bader_calc
 -> refine, exactly the call sequence of Bader.__call__ (interface.py:406-409).  N > 1 is launched
@@ -57,7 +57,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--method', default='neargrid', choices=['neargrid', 'ongrid'])
     ap.add_argument('--refine', default='changed:2')
-    ap.add_argument('--cpu-size', type=int, default=160)
+    ap.add_argument('--cpu-size', type=int, default=320)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--halo', type=int, default=8)
     args = ap.parse_args()

@@ -144,6 +144,8 @@ int xb_enable_timing(xb_ctx *c, int on);
 int xb_set_option(xb_ctx *c, int key, int value);
 /* statistics of the last assignment: trapping boxes found and voxels they cover */
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);
+/* trajectories / retraces handed to the exact slow kernel since the context was created */
+int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ SYMBOLS = {
     'xb_enable_timing': (_int, [_vp, _int]),
     'xb_set_option': (_int, [_vp, _int, _int]),
     'xb_box_stats': (_int, [_vp, _pi64, _pi64]),
+    'xb_slow_path_stats': (_int, [_vp, _pi64, _pi64]),
 }
 
 _lib = None
@@ -276,6 +277,11 @@ class Context:
     def box_stats(self):
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_box_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def slow_path_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_slow_path_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def sync(self):

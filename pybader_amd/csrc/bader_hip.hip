@@ -1274,6 +1274,7 @@ struct xb_ctx {
     int opt_boxes = 1;
     int opt_bricks = 1;
     int opt_dbg = 0;
+    long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
     int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
@@ -1686,7 +1687,8 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
                                                              c->boxbuf + BB_RCAP, seed);
         HIPCHK(hipMemcpyAsync(buf[0], seed, nbr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
         int cur = 0;
-        const int max_rounds = 2 * (nb0 + nb1 + nb2) + 8;
+        const int max_rounds = 8 * ((2 * (nb0 + nb1 + nb2) + 15) / 8);  // a multiple of the polling period
+        bool kill_converged = false;
         for (int phase = 0; phase < 2; phase++) {  // 0: propagate provisional labels, 1: kill violators
             for (int round = 1; round <= max_rounds; round++) {
                 if ((round & 7) == 1) HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
@@ -1699,11 +1701,16 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
                     HIPCHK(hipGetLastError());
                     int ch = 0;
                     if (int rc = read_counter(c, 11, &ch)) return rc;
-                    if (!ch) break;
+                    if (!ch) {
+                        if (phase == 1) kill_converged = true;
+                        break;
+                    }
                 }
             }
         }
-        int *blab = buf[cur];
+        // only a FIXPOINT of the kill iteration is closed under every move; without it fall back to
+        // the seed cubes, which are trapping regions on their own
+        int *blab = kill_converged ? buf[cur] : seed;
         HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
         k_count_positive<<<(nbr + 255) / 256, 256, 0, c->stream>>>(blab, nbr, c->counters + 11);
         int ncertain = 0;
@@ -1777,6 +1784,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         int novf = 0;
         if (int rc = read_counter(c, 1, &novf)) return rc;
         if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
+        c->stat_ovf_assign += novf;
         if (novf > 0)
             if (int rc = run_slow(c, novf, 0)) return rc;
     } else if (method == XB_METHOD_ONGRID) {
@@ -1952,6 +1960,7 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
         int novf = 0;
         if (int rc = read_counter(c, 1, &novf)) return rc;
         if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
+        c->stat_ovf_refine += novf;
         if (novf > 0)
             if (int rc = run_slow(c, novf, 1)) return rc;
     }
@@ -2189,6 +2198,12 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 3) c->opt_dbg = value;
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
+    return XB_OK;
+}
+int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    if (assign_total) *assign_total = c->stat_ovf_assign;
+    if (refine_total) *refine_total = c->stat_ovf_refine;
     return XB_OK;
 }
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels) {

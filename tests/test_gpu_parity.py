@@ -343,3 +343,60 @@ def test_speed_profile_and_extras_through_python_mirror(ctx):
     np.testing.assert_allclose(vc, rho[mask].sum() * 0.25, rtol=1e-9)
     np.testing.assert_allclose(vv, mask.sum() * 0.25, rtol=1e-12)
     utils.forget_density(_lib.default_context())
+
+
+@pytest.mark.parametrize('kind,shape', [('noise', (24, 28, 20)), ('quantised', (32, 24, 24)), ('noise64', (40, 40, 40)),
+                                        ('flat_vacuum', (24, 24, 24))])
+def test_rough_densities_against_oracle(ctx, kind, shape):
+    """Non-smooth inputs: hundreds of maxima (no trapping boxes), exact ties and plateaus (stay voxels,
+    ongrid steps, non-monotone paths -> the window/slow-path logic), flat vacuum."""
+    import oracle
+    rho, lat, atoms, dm, tg = random_case(7, shape)
+    rng = np.random.default_rng(99)
+    tol = None
+    if kind.startswith('noise'):
+        rho = rho + 0.4 * rng.random(shape)
+    elif kind == 'quantised':
+        rho = np.round(rho * 8) / 8          # plateaus of exactly equal density
+    else:
+        rho = np.where(rho < 0.2, 0.0, rho)  # a flat zero region, declared vacuum
+        tol = 0.0
+    rho = np.ascontiguousarray(rho)
+    ctx.set_grid(shape, dm, tg)
+    ctx.upload_density(rho)
+    vol0 = np.zeros(shape, np.int32)
+    vol0, _, _ = oracle.vacuum_assign(rho, vol0, float('nan') if tol is None else tol, rho, 1.0)
+    ctx.vacuum_assign(tol, 1.0)
+    assert np.array_equal(ctx.download_labels(np.int32), vol0)
+    F = oracle.own_trajectory_map(rho, vol0, dm, tg)
+    # a trajectory that ends on a vacuum maximum hands -1 to its start voxel (refinement.py:286)
+    flat = F.reshape(-1).copy()
+    ends_in_vac = (flat >= 0) & (vol0.reshape(-1)[np.maximum(flat, 0)] == -1)
+    flat[ends_in_vac] = -1
+    want, maxima = rank_labels(flat.reshape(shape))
+    n = ctx.assign('neargrid')
+    assert n == maxima.shape[0]
+    assert np.array_equal(np.ravel_multi_index(tuple(ctx.maxima().T), shape), maxima)
+    assert np.array_equal(ctx.download_labels(np.int64), want)
+    # refinement from the sequential reference main map, and ongrid
+    bmax, main = oracle.bader_calc('neargrid', rho, vol0, dm, tg, 1)
+    for mode in (('changed', 3), ('all', 2)):
+        v = main.copy()
+        olog = []
+        oracle.refine('neargrid', mode, rho, v, dm, tg, 1, log=olog)
+        ctx.upload_labels(main)
+        assert ctx.refine(*mode) == [tuple(x) for x in olog], mode
+        assert np.array_equal(ctx.download_labels(main.dtype), v), mode
+    bmax, omain = oracle.bader_calc('ongrid', rho, vol0, dm, tg, 1)
+    ctx.upload_labels(vol0)
+    ctx.assign('ongrid')
+    assert np.array_equal(ctx.maxima(), bmax)
+    assert np.array_equal(ctx.download_labels(omain.dtype), omain)
+    print('slow-path totals (assign, refine):', ctx.slow_path_stats())
+
+
+def test_slow_path_was_exercised(ctx):
+    """runs after the rough-density cases (same module-scoped context): the exact slow kernel must have
+    seen work, otherwise that code would be untested"""
+    a, r = ctx.slow_path_stats()
+    assert a > 0, (a, r)
