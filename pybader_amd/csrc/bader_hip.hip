@@ -125,8 +125,8 @@ __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *f
 // ---------------------------------------------------------------------------------------------
 #define GT_X 8
 #define GT_Y 8
-#define GT_Z 64
-// The tile is 8 whole 8^3 bricks in a row along z; when the grid is made of whole bricks
+#define GT_Z 32
+// The tile is GT_Z/8 whole 8^3 bricks in a row along z; when the grid is made of whole bricks
 // (`bmask` != null) the block also reduces, per brick, which neighbour bricks any possible move of
 // its voxels can reach (the k_brick_* kernels below work on these masks alone).
 __device__ __forceinline__ void move_ranges_raw(int code, int og, double r0, double r1, double r2, int lo[3], int hi[3]) {
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
         tile[ex][ey][ez] = rho[(X * g.ny + Y) * g.nz + Z];
     }
     __syncthreads();
-    const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+    const int tz = threadIdx.x & (GT_Z - 1), ty = threadIdx.x / GT_Z;   // 32 x 8 threads, 8 voxels (x) each
     int mine = 0;  // move mask of this thread's voxels (all in brick tz >> 3 of the tile)
 #pragma unroll 1
-    for (int k = 0; k < 16; k++) {
-        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+    for (int k = 0; k < GT_X; k++) {
+        const int tx = k;
         const int x = x0 + tx, y = y0 + ty, z = z0 + tz;
         if (x >= g.nx || y >= g.ny || z >= g.nz) continue;
         const int v = (x * g.ny + y) * g.nz + z;
@@ -389,6 +389,44 @@ __global__ void k_count_positive(const int *__restrict__ a, int n, int *count) {
 // One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
 // of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
 // ---------------------------------------------------------------------------------------------
+// Voxels inside a trapping region end at its maximum: fill their labels in one streaming sweep
+// (vacuum voxels keep -1; a region whose maximum is vacuum hands out -1, refinement.py:286) and note
+// the maxima for the numbering.  The uncertain bricks go to the work list of k_ng_trace.
+__global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__restrict__ blab, int nb1, int nb2,
+                                                      const int *__restrict__ box_max, int *labels, int *first,
+                                                      int *max_list, int *max_count, int max_cap) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool in = vv < vend;
+    const int v = in ? (int)vv : 0;
+    int result = -1;
+    bool has = false;
+    if (in) {
+        const int x = v / g.nyz;
+        const int r = v - x * g.nyz;
+        const int y = r / g.nz, z = r - y * g.nz;
+        const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
+        if (b > 0 && labels[v] != -1) {
+            result = box_max[b - 1];
+            if (result != v && labels[result] == -1) result = -1;
+            labels[v] = result;
+            has = result >= 0;
+        }
+    }
+    note_maximum_wave(has, result, v, first, max_list, max_count, max_cap);
+}
+__global__ void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab, int *walk, int *n_walk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;   // bricks [b_lo, b_hi) are the owned slab
+    const bool hit = b < nbr && b >= b_lo && b < b_hi && blab[b] <= 0;
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int lane = threadIdx.x % XB_WAVE;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(n_walk, __popcll(m));
+    base = __shfl(base, 0);
+    if (hit) walk[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+
 __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
     ox = og / 9 - 1; oy = (og / 3) % 3 - 1; oz = og % 3 - 1;
 }
@@ -396,7 +434,8 @@ __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
 template <int K>
 __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
                                                   const int *__restrict__ box_max, const int *__restrict__ blab,
-                                                  int nb1, int nb2, int *labels, int *first,
+                                                  int nb1, int nb2, const int *__restrict__ walk, int n_walk,
+                                                  int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
                                                   int *ovf_count, int ovf_cap, int maxsteps, int opt) {
     // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
@@ -411,7 +450,15 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     const int wave = blk * wpb + threadIdx.x / XB_WAVE;
     const int lane = threadIdx.x % XB_WAVE;
     int sx, sy, sz;
-    if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
+    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (4x4x4 each) per brick
+        if ((wave >> 3) >= n_walk) return;
+        const int b = walk[wave >> 3], sub = wave & 7;
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        sx = b0 * 8 + ((sub >> 2) << 2) + (lane >> 4);
+        sy = b1 * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
+        sz = b2 * 8 + ((sub & 1) << 2) + (lane & 3);
+        if (sx < g.x0 || sx >= g.x1) return;  // whole wave: 4 planes of one brick half, slab edges are brick aligned or not owned
+    } else if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
         const int bz_n = (g.nz + 3) >> 2, by_n = (g.ny + 3) >> 2;
         const int bx = wave / (by_n * bz_n);
         const int brem = wave - bx * (by_n * bz_n);
@@ -1772,13 +1819,36 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         {
             ScopedTimer t(c, 0);
             const int opt = c->opt_trace;
-            const long long waves = (opt & 1)
-                ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
-                : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
             const int tpb = c->opt_trace_tpb;
-            k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
-                light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], c->labels, c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list,
-                c->counters + 1, c->ovf_cap, maxsteps, opt);
+            const bool slab_bricks = (g.x0 % 8 == 0) && (g.x1 % 8 == 0);
+            if (c->blab && slab_bricks) {
+                // trapping regions known per brick: fill them in one sweep, trace only the rest
+                const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+                int *walk = c->blab + nbr;  // next scratch slice of `list` (see ensure_grad)
+                HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
+                k_brick_walk_list<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
+                                                                         (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, c->counters + 13);
+                k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],
+                                                                    c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list,
+                                                                    c->counters + 0, c->max_cap);
+                int nwalk = 0;
+                if (int rc = read_counter(c, 13, &nwalk)) return rc;
+                if (nwalk) {
+                    const long long waves = 8LL * nwalk;
+                    k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
+                        light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
+                        c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                        maxsteps, opt);
+                }
+            } else {
+                const long long waves = (opt & 1)
+                    ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
+                    : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
+                k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
+                    light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], nullptr, 0, c->labels,
+                    c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                    maxsteps, opt);
+            }
         }
         HIPCHK(hipGetLastError());
         int novf = 0;
