@@ -395,10 +395,9 @@ __global__ void k_count_positive(const int *__restrict__ a, int n, int *count) {
 __global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__restrict__ blab, int nb1, int nb2,
                                                       const int *__restrict__ box_max, int *labels, int *first,
                                                       int *max_list, int *max_count, int max_cap) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    const bool in = vv < vend;
-    const int v = in ? (int)vv : 0;
+    const int vbeg = g.x0 * g.nyz, vend = g.x1 * g.nyz;
+    const int v = vbeg + blockIdx.x * TPB + threadIdx.x;
+    const bool in = v < vend;
     int result = -1;
     bool has = false;
     if (in) {
@@ -413,7 +412,38 @@ __global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__rest
             has = result >= 0;
         }
     }
-    note_maximum_wave(has, result, v, first, max_list, max_count, max_cap);
+    note_maximum_wave(has, result, in ? v : 0, first, max_list, max_count, max_cap);
+}
+// Without vacuum every voxel of a certain brick belongs to its maximum and the smallest voxel
+// index of a brick is its corner: the numbering needs one note per owned certain brick, and the
+// labels themselves are written by k_relabel_regions after the trace.
+__global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_lo, int b_hi,
+                                      const int *__restrict__ blab, const int *__restrict__ box_max, int *first,
+                                      int *max_list, int *max_count, int max_cap) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = (b < nb0 * nb1 * nb2 && b >= b_lo && b < b_hi) ? blab[b] : 0;
+    const bool has = l > 0;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    // one atomic per distinct maximum per wave (a handful of maxima own all the bricks)
+    note_maximum_wave(has, has ? box_max[l - 1] : 0, ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list,
+                      max_count, max_cap);
+}
+// labels := rank of the maximum; voxels of certain bricks take it from the brick label, the others
+// from the maximum index the trace left in `labels`
+__global__ __launch_bounds__(TPB) void k_relabel_regions(GridL g, int *labels, const int *__restrict__ rank,
+                                                         const int *__restrict__ blab, int nb1, int nb2,
+                                                         const int *__restrict__ box_max) {
+    const int v = g.x0 * g.nyz + blockIdx.x * TPB + threadIdx.x;
+    if (v >= g.x1 * g.nyz) return;
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
+    if (b > 0) labels[v] = rank[box_max[b - 1]];
+    else {
+        const int m = labels[v];
+        if (m >= 0) labels[v] = rank[m];
+    }
 }
 __global__ void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab, int *walk, int *n_walk) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;   // bricks [b_lo, b_hi) are the owned slab
@@ -1321,6 +1351,8 @@ struct xb_ctx {
     int opt_boxes = 1;
     int opt_bricks = 1;
     int opt_dbg = 0;
+    bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
+    bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
@@ -1549,6 +1581,7 @@ static size_t dtype_size(int dtype) { return (dtype == XB_I8 || dtype == XB_I16 
 int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     NEED_GRID("xb_upload_labels");
     c->list_valid = false;
+    c->has_vacuum = true;
     const size_t sz = dtype_size(dtype);
     if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
     if (dtype == XB_I32) {
@@ -1599,6 +1632,7 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
         // vacuum_tol=None reaches the reference's sweep as NaN (interface.py:459): `rho <= NaN` is never
         // true, so the result is all-zero labels and zero vacuum charge/volume -- no need to read rho
         HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+        c->has_vacuum = false;
         if (vac_charge) *vac_charge = 0.;
         if (vac_volume) *vac_volume = 0.;
         return XB_OK;
@@ -1612,6 +1646,7 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
     HIPCHK(hipMemcpyAsync(&s, c->dsum, sizeof s, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&n, c->counters64, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->has_vacuum = true;   // (the count covers the owned slab only: stay conservative)
     if (vac_charge) *vac_charge = s * voxel_volume;  // utils.py:400
     if (vac_volume) *vac_volume = (double)n * voxel_volume;
     return XB_OK;
@@ -1811,6 +1846,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         HIPCHK(hipGetLastError());
     }
     c->first_clean = false;
+    c->regions_pending = false;
     if (method == XB_METHOD_NEARGRID) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
         // the table is a pure function of the resident density, but it is part of the assignment
@@ -1828,9 +1864,17 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
                 k_brick_walk_list<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
                                                                          (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, c->counters + 13);
-                k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],
-                                                                    c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list,
-                                                                    c->counters + 0, c->max_cap);
+                if (c->has_vacuum) {
+                    k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],
+                                                                        c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list,
+                                                                        c->counters + 0, c->max_cap);
+                } else {
+                    k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(
+                        light(g), c->nbk[0], c->nbk[1], c->nbk[2], (g.x0 / 8) * c->nbk[1] * c->nbk[2],
+                        (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, c->boxbuf + BB_BOXMAX, c->first, c->max_list,
+                        c->counters + 0, c->max_cap);
+                    c->regions_pending = true;
+                }
                 int nwalk = 0;
                 if (int rc = read_counter(c, 13, &nwalk)) return rc;
                 if (nwalk) {
@@ -1911,7 +1955,12 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
         k_set_rank<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
         HIPCHK(hipGetLastError());
     }
-    k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first);
+    if (c->regions_pending && c->blab)
+        k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
+                                                               c->boxbuf + BB_BOXMAX);
+    else
+        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first);
+    c->regions_pending = false;
     HIPCHK(hipGetLastError());
     if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
         k_reset_first<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
@@ -2254,7 +2303,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     const size_t es = which == 0 ? 4 : 1;
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
-    if (to_device) c->list_valid = false;
+    if (to_device) { c->list_valid = false; c->has_vacuum = true; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -1,4 +1,9 @@
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu --size 1024 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('1024:', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['other_kernels_ms_avg'], d['config']['trapping_boxes'], d['config']['refine_log'])"
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --size 256 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('256:', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['other_kernels_ms_avg'], d['config']['trapping_boxes'])"
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --method ongrid 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ongrid 512:', d['value'], d['ms_per_step'], d['config']['refine_log'])"
-(timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --size 256 --steps 2 --warmup 1 2>&1 | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('2 ranks 256:', d['value'], d['ms_per_step'], d['config']['parallelism'], d['config']['refine_log'])")
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt18 -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+python3 - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/kt18/*/*kernel_stats.csv')[0]
+tot=0
+for r in list(csv.DictReader(open(f)))[:16]:
+    print(f"{r['Name'][:48]:50s} calls={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:10.1f} per_step_ms={float(r['TotalDurationNs'])/1e6/4:7.3f}")
+PY
