@@ -771,6 +771,35 @@ __global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__res
     __syncthreads();
     if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
 }
+// After an assignment without vacuum every certain brick is uniform by construction (all its voxels
+// carry the rank of the region's maximum): only the bricks of the walk list need the label scan.
+__global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
+                                    const int *__restrict__ rank, int *__restrict__ buni) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbr) return;
+    const int l = blab[b];
+    if (l > 0) buni[b] = rank[box_max[l - 1]];
+}
+__global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *__restrict__ labels, int nb1, int nb2,
+                                                            const int *__restrict__ walk, int n_walk,
+                                                            int *__restrict__ buni) {
+    __shared__ int s_min, s_max;
+    if ((int)blockIdx.x >= n_walk) return;
+    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
+    __syncthreads();
+    const int b = walk[blockIdx.x];
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int lo = 2147483647, hi = XB_MIXED;
+    for (int t = threadIdx.x; t < 512; t += TPB) {
+        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
+        lo = min(lo, l); hi = max(hi, l);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    __syncthreads();
+    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
+}
+
 // refinement.py:385-404 as written there: every listed edge voxel turns the known >= 0 voxels of
 // its 27-box into -1 (all -2 flags are final before this kernel starts).
 __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known, const int *__restrict__ list, int n) {
@@ -1353,6 +1382,8 @@ struct xb_ctx {
     int opt_dbg = 0;
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
+    bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
+    int n_walk = 0;                // bricks on the walk list of the last assignment
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
@@ -1582,6 +1613,7 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     NEED_GRID("xb_upload_labels");
     c->list_valid = false;
     c->has_vacuum = true;
+    c->buni_valid = false;
     const size_t sz = dtype_size(dtype);
     if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
     if (dtype == XB_I32) {
@@ -1628,6 +1660,7 @@ int xb_download_known(xb_ctx *c, int8_t *known_host) {
 
 int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume) {
     NEED_GRID("xb_vacuum_assign");
+    c->buni_valid = false;
     if (vac_tol != vac_tol) {
         // vacuum_tol=None reaches the reference's sweep as NaN (interface.py:459): `rho <= NaN` is never
         // true, so the result is all-zero labels and zero vacuum charge/volume -- no need to read rho
@@ -1877,6 +1910,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 }
                 int nwalk = 0;
                 if (int rc = read_counter(c, 13, &nwalk)) return rc;
+                c->n_walk = nwalk;
                 if (nwalk) {
                     const long long waves = 8LL * nwalk;
                     k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
@@ -1955,10 +1989,20 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
         k_set_rank<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
         HIPCHK(hipGetLastError());
     }
-    if (c->regions_pending && c->blab)
+    c->buni_valid = false;
+    if (c->regions_pending && c->blab) {
         k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
                                                                c->boxbuf + BB_BOXMAX);
-    else
+        if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
+            const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+            int *buni = reinterpret_cast<int *>(c->st);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, c->boxbuf + BB_BOXMAX, c->first, buni);
+            if (c->n_walk)
+                k_label_uniform_list<<<c->n_walk, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
+                                                                      c->blab + nbr, c->n_walk, buni);
+            c->buni_valid = true;
+        }
+    } else
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first);
     c->regions_pending = false;
     HIPCHK(hipGetLastError());
@@ -2024,7 +2068,8 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
         int *buni = nullptr;
         if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {  // whole bricks: per-brick label uniformity first
             buni = reinterpret_cast<int *>(c->st);             // N bytes >= N/512 ints; edge_check reuses st later
-            k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
+            if (!c->buni_valid)
+                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
         }
         dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
         k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
@@ -2065,6 +2110,7 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     if (c->list_valid && flag == -2) n = c->list_n;
     else if (int rc = compact(c, flag, &n)) return rc;
     c->list_valid = false;  // the retrace rewrites known
+    c->buni_valid = false;  // ... and may relabel edge voxels; st is also edge_check's scratch
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
@@ -2094,6 +2140,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     NEED_GRID("xb_edge_check");
     const Grid &g = c->g;
     c->list_valid = false;
+    c->buni_valid = false;
     if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: 'changed' mode is single-slab only; slabs use mode 'all'");
     int n = 0;
     if (int rc = compact(c, -2, &n)) return rc;
@@ -2201,6 +2248,7 @@ int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *char
 
 int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap) {
     NEED_GRID("xb_volume_assign");
+    c->buni_valid = false;
     if (n_swap <= 0) return XB_OK;
     if (n_swap > c->max_cap) return fail(XB_E_LIMIT, "xb_volume_assign: swap table too long");
     std::vector<int> s(n_swap);
@@ -2303,7 +2351,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     const size_t es = which == 0 ? 4 : 1;
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
-    if (to_device) { c->list_valid = false; c->has_vacuum = true; }
+    if (to_device) { c->list_valid = false; c->has_vacuum = true; c->buni_valid = false; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
