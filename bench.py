@@ -139,14 +139,26 @@ def main():
 
     nvox = float(np.prod(shape))
     ms_per_step = dt / args.steps * 1e3
-    which = 0 if args.method == 'neargrid' else 1
-    k_ms, k_n = ctx.kernel_time(which)
-    gf_ms, gf_n = ctx.kernel_time(4)
-    ef_ms, ef_n = ctx.kernel_time(2)
-    rt_ms, rt_n = ctx.kernel_time(3)
-    own_vox = nvox * (runner.x_range[1] - runner.x_range[0]) / shape[0]
-    k_avg = k_ms / max(k_n, 1)
-    achieved = BYTES_ASSIGN * own_vox / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
+    # HIP-event timings on the library's own stream (xb_kernel_time)
+    tm = {name: ctx.kernel_time(i) for i, name in enumerate(
+        ['assign_after_table(fill+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
+         'table_build(k_grad_field+trapping_regions)', 'k_grad_field'])}
+    avg = {k: (ms / n if n else 0.0) for k, (ms, n) in tm.items()}
+    # the dominant single kernel of the path
+    if args.method == 'neargrid':
+        dom = 'k_grad_field' if avg['k_grad_field'] >= avg['assign_after_table(fill+k_ng_trace)'] else 'k_ng_trace'
+        k_avg = max(avg['k_grad_field'], avg['assign_after_table(fill+k_ng_trace)'])
+        k_n = tm['k_grad_field'][1]
+        # k_grad_field works on the whole grid on every rank; the trace on the owned slab
+        units = nvox if dom == 'k_grad_field' else nvox * (runner.x_range[1] - runner.x_range[0]) / shape[0]
+    else:
+        dom, k_avg, k_n, units = 'k_og_pointer', avg['k_og_pointer'], tm['k_og_pointer'][1], nvox
+    achieved = BYTES_ASSIGN * units / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (same command, 512^3):
+    # profiles/r1_final_pmc_fetch_write_512_neargrid.txt -- FETCH_SIZE + WRITE_SIZE as reported
+    traffic = None
+    if args.size == 512 and args.method == 'neargrid' and world == 1:
+        traffic = {'k_grad_field': (1306675 + 4196352) * 1024.0, 'k_ng_trace': (4043183 + 215972) * 1024.0}[dom]
 
     out = {
         'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',
@@ -168,15 +180,15 @@ def main():
                    'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}, transport {comm.transport}',
                    'basins': int(n_basins), 'refine_log': log,
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_ng_trace' if which == 0 else 'k_og_pointer',
-                     'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'traffic_note': 'bytes/launch, FETCH_SIZE+WRITE_SIZE as reported by rocprofv3 --pmc (committed under '
+                                     'profiles/, not corrected for the gfx950 2x FETCH under-count of coalesced streams)',
                      'algorithmic_bytes_per_voxel': BYTES_ASSIGN, 'kernel_ms_avg': k_avg, 'launches': int(k_n),
                      'whole_path': {'bytes_per_voxel': BYTES_PATH,
                                     'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
                                     'frac': BYTES_PATH * nvox / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
-                     'other_kernels_ms_avg': {'table_build(grad_field+box_scan+stamp)': gf_ms / max(gf_n, 1), 'edge_find': ef_ms / max(ef_n, 1),
-                                              'refine_trace': rt_ms / max(rt_n, 1)}},
+                     'stage_ms_avg': avg},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -134,8 +134,9 @@ int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that ho
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel, measured on the context's stream: accumulated
- * milliseconds and launch count since the last reset.  which: 0 neargrid trace, 1 ongrid pointer,
- * 2 edge_find, 3 refine trace, 4 gradient-field table. */
+ * milliseconds and launch count since the last reset.  which: 0 neargrid assignment after the table
+ * (region fill + walker trace), 1 ongrid pointer, 2 edge_find, 3 refine trace, 4 whole table build
+ * (gradient field + trapping regions), 5 k_grad_field alone. */
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);

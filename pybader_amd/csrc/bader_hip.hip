@@ -1412,7 +1412,7 @@ struct xb_ctx {
     bool list_valid = false;   // ... when this is set (by xb_edge_find)
     bool timing = false;
     int opt_trace = 1;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
-    TimedKernel tk[5];
+    TimedKernel tk[6];
     long long n_alloc = 0;
 };
 
@@ -1706,6 +1706,7 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+        ScopedTimer tk(c, 5);
         k_grad_field<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
                                                  BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
     }
@@ -2397,7 +2398,7 @@ int xb_kernel_time_reset(xb_ctx *c) {
     return XB_OK;
 }
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches) {
-    if (!c || which < 0 || which > 4) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
+    if (!c || which < 0 || which > 5) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     TimedKernel &t = c->tk[which];
