@@ -60,6 +60,8 @@ def main():
     ap.add_argument('--cpu-size', type=int, default=320)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--halo', type=int, default=8)
+    ap.add_argument('--table-margin', type=int, default=32,
+                    help='planes of gradient-field table each side of a slab (N > 1)')
     args = ap.parse_args()
     mode, iters = args.refine.split(':')
     iters = int(iters)
@@ -105,6 +107,7 @@ def main():
     dev_index = dev_index if world > 1 else 0
     ctx = _lib.Context(dev_index)
     runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=args.halo)
+    windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
     ctx.enable_timing(True)
     if 'XB_OPT_TRACE' in os.environ:
@@ -149,8 +152,8 @@ def main():
         dom = 'k_grad_field' if avg['k_grad_field'] >= avg['assign_after_table(fill+k_ng_trace)'] else 'k_ng_trace'
         k_avg = max(avg['k_grad_field'], avg['assign_after_table(fill+k_ng_trace)'])
         k_n = tm['k_grad_field'][1]
-        # k_grad_field works on the whole grid on every rank; the trace on the owned slab
-        units = nvox if dom == 'k_grad_field' else nvox * (runner.x_range[1] - runner.x_range[0]) / shape[0]
+        own_frac = (runner.x_range[1] - runner.x_range[0]) / shape[0]
+        units = nvox * own_frac   # voxels this rank labels (its k_grad_field also covers the window margin)
     else:
         dom, k_avg, k_n, units = 'k_og_pointer', avg['k_og_pointer'], tm['k_og_pointer'][1], nvox
     achieved = BYTES_ASSIGN * units / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
@@ -177,7 +180,8 @@ def main():
                                f'{args.method} assign + neargrid edge refinement {mode}:{iters}, '
                                'density resident in HBM',
                    'grid': list(shape), 'method': args.method, 'refine_mode': [mode, iters],
-                   'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}, transport {comm.transport}',
+                   'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}, transport {comm.transport}, '
+                                  f'table window {"slab+-%d planes" % args.table_margin if windowed else "whole grid"}',
                    'basins': int(n_basins), 'refine_log': log,
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -120,6 +120,17 @@ int xb_volume_mask(xb_ctx *c, int64_t vol_num, double *out_host);
  * reference density differs from the charge density, utils.py:396-400) */
 int xb_label_sum(xb_ctx *c, int64_t value, double *sum, int64_t *count);
 
+/* ---- windowed table build (multi-GPU): each rank builds the 32-B/voxel gradient-field table only for
+ * its slab +- `margin` planes.  The trapping regions need two global inputs, exchanged by the slab
+ * scheduler between the two calls: the 26-neighbour maxima of every rank (tiny) and the per-brick move
+ * masks (one int per 8^3 brick; every rank contributes the bricks of its own slab).
+ *   xb_set_table_window -> xb_table_build -> [all-gather seeds + masks] -> xb_table_finish -> xb_assign_trace */
+int xb_set_table_window(xb_ctx *c, int64_t margin);           /* margin < 0: whole grid (default) */
+int xb_table_build(xb_ctx *c, int64_t *n_local_seeds);
+int xb_table_local_seeds(xb_ctx *c, int64_t *out, int64_t capacity);  /* linear voxel indices */
+int xb_brick_masks(xb_ctx *c, void **dev_ptr, int64_t *n_bricks, int64_t *own_first, int64_t *own_count);
+int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds);
+
 /* ---- slab halo planes (multi-GPU) -------------------------------------------------------- */
 /* Device pointers of the label / known arrays and the plane size in elements, so that the slab
  * scheduler can hand plane ranges to RCCL (ncclSend/ncclRecv) or any other transport. */

@@ -47,6 +47,11 @@ SYMBOLS = {
     'xb_surface_distance': (_int, [_vp, _vp, _vp, _i64, _vp, _pi64]),
     'xb_volume_mask': (_int, [_vp, _i64, _vp]),
     'xb_label_sum': (_int, [_vp, _i64, _pdbl, _pi64]),
+    'xb_set_table_window': (_int, [_vp, _i64]),
+    'xb_table_build': (_int, [_vp, _pi64]),
+    'xb_table_local_seeds': (_int, [_vp, _vp, _i64]),
+    'xb_brick_masks': (_int, [_vp, C.POINTER(_vp), _pi64, _pi64, _pi64]),
+    'xb_table_finish': (_int, [_vp, _vp, _i64]),
     'xb_labels_ptr': (_vp, [_vp]),
     'xb_known_ptr': (_vp, [_vp]),
     'xb_density_ptr': (_vp, [_vp]),
@@ -255,6 +260,25 @@ class Context:
         s, n = C.c_double(), C.c_int64()
         check(self.lib.xb_label_sum(self.h, int(value), C.byref(s), C.byref(n)))
         return s.value, n.value
+
+    def set_table_window(self, margin):
+        check(self.lib.xb_set_table_window(self.h, int(margin)))
+
+    def table_build(self):
+        n = C.c_int64()
+        check(self.lib.xb_table_build(self.h, C.byref(n)))
+        out = np.zeros(n.value, np.int64)
+        check(self.lib.xb_table_local_seeds(self.h, _ptr(out), n.value))
+        return out
+
+    def brick_masks(self):
+        p, n, f, k = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.xb_brick_masks(self.h, C.byref(p), C.byref(n), C.byref(f), C.byref(k)))
+        return p.value, n.value, f.value, k.value
+
+    def table_finish(self, seeds):
+        sd = np.ascontiguousarray(seeds, dtype=np.int64)
+        check(self.lib.xb_table_finish(self.h, _ptr(sd), sd.shape[0]))
 
     def copy_planes(self, which, to_device, host, xa, xb):
         check(self.lib.xb_copy_planes(self.h, int(which), int(to_device), _ptr(host), int(xa), int(xb)))

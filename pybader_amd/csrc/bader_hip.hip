@@ -143,7 +143,10 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
                                                     int seed_cap, int small, int *__restrict__ bmask) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
     __shared__ int s_mask[GT_Z / 8];
-    const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
+    // plane tiles are counted from the start of the table window (brick aligned; the whole grid on one GPU)
+    int x0 = g.wx0 + blockIdx.z * GT_X;
+    if (x0 >= g.nx) x0 -= g.nx;
+    const int y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
     if (threadIdx.x < GT_Z / 8) s_mask[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2); i += TPB) {
         const int ez = i % (GT_Z + 2);
@@ -259,6 +262,56 @@ __device__ __forceinline__ void move_ranges(const GradRec &rec, int lo[3], int h
     }
 }
 __device__ __forceinline__ int wrap_any(int v, int n) { v %= n; return v < 0 ? v + n : v; }
+
+// The same move intervals derived from rho directly (no table record needed): used for the seed cubes
+// when the table only covers a window of the grid (slabs).
+__device__ __forceinline__ void move_ranges_rho(const double *__restrict__ rho, const Grid &g, int x, int y, int z,
+                                                int lo[3], int hi[3]) {
+    const int v = lin3(g, x, y, z);
+    const double c = rho[v];
+    double max_val = c;
+    int og = XB_OG_SELF;
+    for (int ix = 0; ix < 3; ix++) {
+        const int tx = wrapi(x + ix - 1, g.nx);
+        for (int iy = 0; iy < 3; iy++) {
+            const int ty = wrapi(y + iy - 1, g.ny);
+            for (int iz = 0; iz < 3; iz++) {
+                const int tz = wrapi(z + iz - 1, g.nz);
+                double w = rho[lin3(g, tx, ty, tz)];
+                w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+                w += c;
+                if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
+            }
+        }
+    }
+    double d0, d1, d2;
+    if (ng_dir(rho, g, x, y, z, v, c, d0, d1, d2)) move_ranges_raw(XB_STAY_CODE, og, 0., 0., 0., lo, hi);
+    else {
+        const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
+        move_ranges_raw((i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4), og, d0 - (double)i0, d1 - (double)i1,
+                        d2 - (double)i2, lo, hi);
+    }
+}
+__global__ __launch_bounds__(TPB) void k_box_shells_rho(Grid g, const double *__restrict__ rho,
+                                                        const int *__restrict__ mxyz, const int *__restrict__ rcap,
+                                                        int rlo, int K, int *bad, int stride) {
+    const int m = blockIdx.y;
+    const int rhi = min(rlo + K, rcap[m]);
+    if (rhi < rlo) return;
+    const int w = 2 * rhi + 1;
+    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= (long long)w * w * w) return;
+    const int o[3] = {(int)(t / ((long long)w * w)) - rhi, (int)((t / w) % w) - rhi, (int)(t % w) - rhi};
+    const int d = max(max(abs(o[0]), abs(o[1])), abs(o[2]));
+    if (d < rlo) return;
+    int lo[3], hi[3];
+    move_ranges_rho(rho, g, wrap_any(mxyz[3 * m] + o[0], g.nx), wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
+                    wrap_any(mxyz[3 * m + 2] + o[2], g.nz), lo, hi);
+    int D = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));
+    for (int R = d; R < D; R++) bad[m * stride + R] = 1;
+}
 
 // Closed cubes around the maxima, found in batches of K shells: the launch visits, for box m, the
 // voxels at L-inf distance d in [rlo, rlo+K] of the maximum.  A voxel at distance d whose farthest
@@ -547,13 +600,14 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
             }
             if (moving) {
                 const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
-                const GradRec nr = fetch_rec(G, lq);
-                const int b = bl > 0 ? bl : key_box(nr.key);
+                const bool in_win = plane_in_window(g, qx);  // the table only exists inside the window (slabs)
+                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                const int b = bl > 0 ? bl : (in_win ? key_box(nr.key) : 0);
                 if (b) {  // arrived inside a trapping region (q cannot be an old path voxel: the
                     result = box_max[b - 1];  // trajectory would have stopped there already)
                     moving = false;
-                } else if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
-                    result = -2;  // membership undecidable from the window: exact slow kernel
+                } else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
+                    result = -2;  // left the table window / membership undecidable: exact slow kernel
                     moving = false;  // (ongrid moves are appended without a membership test, 305-315)
                 } else {
                     w.push(lq, nr.key);
@@ -1076,9 +1130,10 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                 }
             }
             if (moving) {
-                const GradRec nr = fetch_rec(G, lq);
-                if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
-                else if (!plane_valid(g, qx)) { result = -4; moving = false; }
+                const bool in_win = plane_in_window(g, qx);
+                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                if (!plane_valid(g, qx)) { result = -4; moving = false; }
+                else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
                 else if (known[lq] == 2) { result = lq; moving = false; }  // refinement.py:294-303
                 else {
                     w.push(lq, nr.key);
@@ -1384,6 +1439,10 @@ struct xb_ctx {
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
     int n_walk = 0;                // bricks on the walk list of the last assignment
+    int table_margin = -1;         // planes of table each side of the slab (slabs); -1: whole grid
+    bool table_prebuilt = false;   // xb_table_finish done: the next xb_assign_trace must not rebuild
+    int table_stage = 0;           // windowed build: 1 = records + masks done, 2 = trapping regions done
+    std::vector<int> window_seeds; // maxima found in the owned planes (windowed build)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
@@ -1421,6 +1480,7 @@ static GridL light(const Grid &g) {
     GridL l;
     l.nx = g.nx; l.ny = g.ny; l.nz = g.nz; l.nyz = g.nyz;
     l.x0 = g.x0; l.x1 = g.x1; l.vx0 = g.vx0; l.vlen = g.vlen;
+    l.wx0 = g.wx0; l.wlen = g.wlen;
     l.use24 = ((long long)g.nx * g.ny < (1 << 24)) && g.nz < (1 << 24);
     return l;
 }
@@ -1558,6 +1618,9 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     c->N = N;
     c->halo = (x0 == 0 && x1 == shape[0]) ? g.nx : 0;
     set_valid_range(c);
+    g.wx0 = 0; g.wlen = g.nx;      // table window: whole grid unless xb_set_table_window says otherwise
+    c->table_margin = -1;
+    c->table_stage = 0;
     c->has_grid = true;
     c->maxima_sorted.clear();
     if (!c->first_clean) {
@@ -1694,6 +1757,9 @@ enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 4352, BB_BOXM
 
 // (re)build the gradient-field table from the resident density; with `boxes`, also find and stamp
 // the trapping boxes around the 26-neighbour maxima (k_box_scan)
+static bool table_windowed(const xb_ctx *c) { return c->g.wlen < c->g.nx; }
+static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks);
+
 static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     if (c->grad_valid && !force) return XB_OK;
     const Grid &g = c->g;
@@ -1701,11 +1767,13 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     HIPCHK(hipMemsetAsync(c->counters + 9, 0, sizeof(int), c->stream));
     // brick growth needs a grid made of whole 8^3 bricks; its scratch is carved from `list`
     const bool bricks = boxes && c->opt_boxes && c->opt_bricks && g.nx % BRK == 0 && g.ny % BRK == 0 &&
-                        g.nz % BRK == 0 && 4LL * (c->N / (BRK * BRK * BRK)) <= c->N;
+                        g.nz % BRK == 0 && 5LL * (c->N / (BRK * BRK * BRK)) <= c->N;
     const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
+    if (table_windowed(c) && boxes && c->opt_boxes && !bricks)
+        return fail(XB_E_STATE, "a table window needs brick growth (grid of whole 8^3 bricks)");
     {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
-        dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+        dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.wlen + GT_X - 1) / GT_X);
         ScopedTimer tk(c, 5);
         k_grad_field<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
                                                  BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
@@ -1715,13 +1783,39 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
     c->n_boxes = 0;
     c->box_voxels = 0;
     c->blab = nullptr;
+    c->table_stage = 1;
     if (!boxes || !c->opt_boxes) return XB_OK;
     int ns = 0;
     if (int rc = read_counter(c, 9, &ns)) return rc;
-    if (ns < 1 || ns > XB_BOX_SEEDS_MAX) return XB_OK;  // many maxima (noisy data): plain tracing
-    std::vector<int> seeds(ns), mxyz(3 * ns), rcap(ns);
-    HIPCHK(hipMemcpyAsync(seeds.data(), c->boxbuf + BB_SEEDS, ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ns > BB_SEED_CAP) ns = XB_BOX_SEEDS_MAX + 1;  // list overflowed: far too many maxima for boxes anyway
+    std::vector<int> seeds(std::max(ns, 0));
+    if (ns > 0 && ns <= XB_BOX_SEEDS_MAX) {
+        HIPCHK(hipMemcpyAsync(seeds.data(), c->boxbuf + BB_SEEDS, ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (table_windowed(c)) {
+        // slabs: the trapping regions need the maxima and brick masks of ALL ranks; keep what this
+        // rank owns and let the scheduler exchange (xb_table_local_seeds / xb_brick_masks / xb_table_finish)
+        c->window_seeds.clear();
+        if (ns > XB_BOX_SEEDS_MAX) c->window_seeds.assign(XB_BOX_SEEDS_MAX + 1, -1);  // "too many" marker
+        else
+            for (int v : seeds)
+                if (v / g.nyz >= g.x0 && v / g.nyz < g.x1) c->window_seeds.push_back(v);
+        return XB_OK;
+    }
+    if (ns < 1 || ns > XB_BOX_SEEDS_MAX) { c->table_stage = 2; return XB_OK; }  // many maxima (noisy data): plain tracing
+    const int rc = table_regions(c, seeds, bricks);
+    c->table_stage = 2;
+    return rc;
+}
+
+// trapping regions from the list of all 26-neighbour maxima: closed seed cubes, then brick growth
+static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks) {
+    const Grid &g = c->g;
+    const int ns = (int)seeds.size();
+    const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
+    (void)nbr_all;
+    std::vector<int> mxyz(3 * ns), rcap(ns);
     std::sort(seeds.begin(), seeds.end());  // atomic append order is arbitrary: make box ids deterministic
     for (int m = 0; m < ns; m++) {
         mxyz[3 * m] = seeds[m] / g.nyz;
@@ -1758,8 +1852,12 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
         if (rtop < rlo) break;
         const long long w = 2LL * rtop + 1;
         dim3 grid(nblocks(w * w * w), ns);
-        k_box_shells<<<grid, TPB, 0, c->stream>>>(light(g), c->grad, c->boxbuf + BB_MXYZ, c->boxbuf + BB_RCAP, rlo, K,
-                                                  c->boxbuf + BB_BAD, stride);
+        if (table_windowed(c))  // a seed cube may lie outside this rank's table window: ranges from rho
+            k_box_shells_rho<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->boxbuf + BB_MXYZ, c->boxbuf + BB_RCAP, rlo, K,
+                                                          c->boxbuf + BB_BAD, stride);
+        else
+            k_box_shells<<<grid, TPB, 0, c->stream>>>(light(g), c->grad, c->boxbuf + BB_MXYZ, c->boxbuf + BB_RCAP, rlo, K,
+                                                      c->boxbuf + BB_BAD, stride);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(bad.data(), c->boxbuf + BB_BAD, bad.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1885,7 +1983,11 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
         // the table is a pure function of the resident density, but it is part of the assignment
         // work: rebuilt on every call, never carried over from a previous assignment
-        if (int rc = ensure_grad(c, true, true)) return rc;
+        if (c->table_prebuilt) c->table_prebuilt = false;   // built by xb_table_build/xb_table_finish just now
+        else {
+            if (table_windowed(c)) return fail(XB_E_STATE, "windowed table: call xb_table_build / xb_table_finish first");
+            if (int rc = ensure_grad(c, true, true)) return rc;
+        }
         {
             ScopedTimer t(c, 0);
             const int opt = c->opt_trace;
@@ -2339,6 +2441,60 @@ int xb_label_sum(xb_ctx *c, int64_t value, double *sum, int64_t *count) {
     if (sum) *sum = s;
     if (count) *count = (int64_t)n;
     return XB_OK;
+}
+
+int xb_set_table_window(xb_ctx *c, int64_t margin) {
+    NEED_GRID("xb_set_table_window");
+    Grid &g = c->g;
+    c->grad_valid = false;
+    c->table_stage = 0;
+    const int own = g.x1 - g.x0;
+    if (margin < 0 || own == g.nx) { g.wx0 = 0; g.wlen = g.nx; c->table_margin = -1; return XB_OK; }
+    if (g.nx % 8 || g.ny % 8 || g.nz % 8 || g.x0 % 8 || g.x1 % 8)
+        return fail(XB_E_ARG, "xb_set_table_window: grid and slab must be made of whole 8^3 bricks");
+    const int m8 = (int)((std::max<int64_t>(margin, c->halo) + 7) / 8) * 8;
+    if (own + 2 * m8 >= g.nx) { g.wx0 = 0; g.wlen = g.nx; c->table_margin = -1; return XB_OK; }
+    g.wx0 = ((g.x0 - m8) % g.nx + g.nx) % g.nx;
+    g.wlen = own + 2 * m8;
+    c->table_margin = m8;
+    return XB_OK;
+}
+int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
+    NEED_GRID("xb_table_build");
+    if (int rc = ensure_grad(c, true, true)) return rc;
+    if (n_local_seeds) *n_local_seeds = table_windowed(c) ? (int64_t)c->window_seeds.size() : 0;
+    return XB_OK;
+}
+int xb_table_local_seeds(xb_ctx *c, int64_t *out, int64_t capacity) {
+    NEED_GRID("xb_table_local_seeds");
+    if ((int64_t)c->window_seeds.size() > capacity) return fail(XB_E_ARG, "xb_table_local_seeds: capacity too small");
+    for (size_t i = 0; i < c->window_seeds.size(); i++) out[i] = c->window_seeds[i];
+    return XB_OK;
+}
+int xb_brick_masks(xb_ctx *c, void **dev_ptr, int64_t *n_bricks, int64_t *own_first, int64_t *own_count) {
+    NEED_GRID("xb_brick_masks");
+    const Grid &g = c->g;
+    if (g.nx % 8 || g.ny % 8 || g.nz % 8) return fail(XB_E_STATE, "xb_brick_masks: grid is not made of whole bricks");
+    const int64_t nbr = c->N / 512, per_plane = (int64_t)(g.ny / 8) * (g.nz / 8);
+    if (dev_ptr) *dev_ptr = (void *)(c->list + nbr);
+    if (n_bricks) *n_bricks = nbr;
+    if (own_first) *own_first = (g.x0 / 8) * per_plane;
+    if (own_count) *own_count = ((g.x1 - g.x0) / 8) * per_plane;
+    return XB_OK;
+}
+int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds) {
+    NEED_GRID("xb_table_finish");
+    if (c->table_stage < 1 || !c->grad_valid) return fail(XB_E_STATE, "xb_table_finish: call xb_table_build first");
+    int rc = XB_OK;
+    if (n_seeds >= 1 && n_seeds <= XB_BOX_SEEDS_MAX) {
+        std::vector<int> sv(n_seeds);
+        for (int64_t i = 0; i < n_seeds; i++) sv[i] = (int)seeds[i];
+        ScopedTimer t(c, 4);
+        rc = table_regions(c, sv, true);
+    }
+    c->table_stage = 2;
+    c->table_prebuilt = true;
+    return rc;
 }
 
 void *xb_labels_ptr(xb_ctx *c) { return c ? (void *)c->labels : nullptr; }

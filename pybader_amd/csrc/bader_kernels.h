@@ -12,6 +12,7 @@ struct Grid {
     int nyz;          // ny*nz (elements per x-plane)
     int x0, x1;       // owned slab: planes [x0, x1)
     int vx0, vlen;    // planes whose labels/known are valid: [vx0, vx0+vlen) modulo nx
+    int wx0, wlen;    // planes whose gradient-field table records exist: [wx0, wx0+wlen) modulo nx
     double T[9];      // T_grad, row-major (interface.py:285-290)
     double dist[27];  // dist_mat [3][3][3], index 2 == -1 (interface.py:242-259)
 };
@@ -20,6 +21,7 @@ struct Grid {
 struct GridL {
     int nx, ny, nz, nyz;
     int x0, x1, vx0, vlen;
+    int wx0, wlen;    // table window (see Grid)
     int use24;        // nx*ny < 2^24 and nz < 2^24: linear indices via 24-bit multiplies
 };
 
@@ -33,6 +35,12 @@ __device__ __forceinline__ bool plane_valid(const GT &g, int x) {
     int d = x - g.vx0;
     if (d < 0) d += g.nx;
     return d < g.vlen;
+}
+template <typename GT>
+__device__ __forceinline__ bool plane_in_window(const GT &g, int x) {
+    int d = x - g.wx0;
+    if (d < 0) d += g.nx;
+    return d < g.wlen;
 }
 // round-half-away-from-zero by a truncating cast: methods.py:347-350 / refinement.py:138-141
 __device__ __forceinline__ int rha(double x) { return x > 0 ? (int)(x + .5) : (int)(x - .5); }

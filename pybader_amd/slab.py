@@ -167,6 +167,24 @@ class TorchComm:
             tensor[xa:xb].copy_(buf)
         torch.cuda.synchronize(tensor.device)
 
+    def gather_chunks(self, tensor, chunks):
+        """tensor: 1-D array every rank holds in full size; chunks[r] = (first, count) is the part rank r has
+        computed.  Afterwards every rank holds every chunk (one broadcast per rank: chunks may differ in size)."""
+        import torch
+        if tensor.is_cuda and not self.device_p2p:
+            mine = tensor[chunks[self.rank][0]:chunks[self.rank][0] + chunks[self.rank][1]].cpu().numpy()
+            parts = self.allgather(mine)
+            for r, (first, count) in enumerate(chunks):
+                if r != self.rank and count:
+                    tensor[first:first + count].copy_(torch.from_numpy(parts[r]))
+            torch.cuda.synchronize(tensor.device)
+            return
+        for r, (first, count) in enumerate(chunks):
+            if count:
+                self.dist.broadcast(tensor[first:first + count], src=r)
+        if tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+
     def barrier(self):
         self.dist.barrier(group=self.host_group)
 
@@ -198,6 +216,13 @@ class GpuBackend:
         if self.sliced:
             self.ctx.set_halo(halo)
 
+    def mask_tensor(self):
+        """zero-copy view of the per-brick move masks + (first, count) of the bricks this rank computed"""
+        import torch
+        ptr, n, first, count = self.ctx.brick_masks()
+        t = torch.as_tensor(_DevArray(ptr, (n,), '<i4'), device=f'cuda:{self.device_index}')
+        return t, first, count
+
     def tensors(self):
         if self._views is None:
             import torch
@@ -228,8 +253,32 @@ class SlabRunner:
         self.n_maxima = 0
         self.n_fallbacks = 0
 
+    def enable_table_window(self, margin=32):
+        """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks
+        everywhere).  Returns whether the window is active."""
+        nx, ny, nz = self.shape
+        ok = (self.comm.size > 1 and hasattr(self.be, 'set_table_window') and nx % 8 == 0 and ny % 8 == 0 and nz % 8 == 0
+              and all(a % 8 == 0 and b % 8 == 0 for a, b in self.ranges)
+              and (self.x_range[1] - self.x_range[0]) + 2 * (max(margin, self.halo) + 7) // 8 * 8 < nx)
+        # every rank must take the same branch (collectives below)
+        ok = all(self.comm.allgather(bool(ok))) if self.comm.size > 1 else False
+        if ok:
+            self.be.set_table_window(max(margin, self.halo))
+        self.windowed = ok
+        return ok
+
     def assign(self, method):
         """thread_handlers.bader_calc: per-slab trajectories, then one tiny table merge for numbering."""
+        if getattr(self, 'windowed', False) and method == 'neargrid':
+            # windowed table: the trapping regions need every rank's maxima and brick masks
+            local = self.be.table_build()
+            seeds = sorted(set(int(v) for part in self.comm.allgather(np.asarray(local).tolist()) for v in part))
+            self.be.sync()
+            t, first, count = self.be.mask_tensor()
+            if getattr(self, '_chunks', None) is None:      # static for a given decomposition
+                self._chunks = self.comm.allgather((int(first), int(count)))
+            self.comm.gather_chunks(t, self._chunks)
+            self.be.table_finish(np.array(seeds, dtype=np.int64))
         m, f = self.be.assign_trace(method)
         if self.comm.size == 1:
             order = np.argsort(f, kind='stable')

@@ -46,11 +46,21 @@ class ThreadComm:
         torch.cuda.synchronize()
         self.sh.barrier.wait()
 
+    def gather_chunks(self, tensor, chunks):
+        import torch
+        self.sh.cur[self.rank] = tensor
+        self.sh.barrier.wait()
+        for r, (first, count) in enumerate(chunks):
+            if r != self.rank and count:
+                tensor[first:first + count].copy_(self.sh.cur[r][first:first + count])
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
+
     def barrier(self):
         self.sh.barrier.wait()
 
 
-def run_slabs(n, g, rho, method, mode, iters, halo, tol):
+def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True):
     sh = Shared(n)
     res = [None] * n
 
@@ -59,6 +69,7 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol):
             ctx = _lib.Context(0)
             comm = ThreadComm(sh, rank)
             runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), comm, rho.shape, g['dist_mat'], g['T_grad'], halo=halo)
+            win = runner.enable_table_window(8) if window else False
             ctx.upload_density(rho)
             ctx.vacuum_assign(tol, 1.0)
             nb = runner.assign(method)
@@ -67,7 +78,7 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol):
             log = runner.refine(mode, iters)
             post = ctx.download_labels(np.int32)[x0:x1].copy()
             ch, vo = ctx.charge_sum(1.0, nb)
-            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks)
+            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats())
             ctx.close()
         except Exception as e:  # noqa: BLE001
             sh.errors.append(repr(e))
@@ -84,6 +95,8 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol):
     post = np.concatenate([r[2] for r in res])
     ch = sum(r[5] for r in res)
     vo = sum(r[6] for r in res)
+    run_slabs.last_windowed = [r[8] for r in res]
+    run_slabs.last_slow = [r[9] for r in res]
     return pre, post, res[0][3], res[0][4], ch, vo, max(r[7] for r in res)
 
 
@@ -127,3 +140,15 @@ def test_ongrid_plus_refine_all_slabs_equal_oracle(n, name, halo):
     assert np.array_equal(post, v)
     if halo == 3:
         assert fb > 0, 'the narrow halo is meant to exercise the escape fallback'
+
+
+def test_windowed_table_is_used_and_exact():
+    """8 slabs of 8 planes on a 64^3 grid with a 8-plane table margin: every rank builds 24 of 64 planes of
+    the table; walkers that leave the window fall back to the exact slow kernel."""
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    pre, post, log, maxima, ch, vo, fb = run_slabs(8, g, rho, 'neargrid', 'changed', 2, 2, None)
+    assert all(run_slabs.last_windowed)
+    assert np.array_equal(pre, g['ng_F'].astype(np.int32)) and np.array_equal(post, g['ng_changed_2'].astype(np.int32))
+    pre2, post2, *_ = run_slabs(8, g, rho, 'neargrid', 'changed', 2, 2, None, window=False)
+    assert not any(run_slabs.last_windowed) and np.array_equal(pre, pre2) and np.array_equal(post, post2)
