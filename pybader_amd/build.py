@@ -5,8 +5,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'bader_hip.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'bader_kernels.h'),
-        os.path.join(os.path.dirname(HERE), 'include', 'bader_hip.h')]
+import glob
+
+DEPS = [SRC, os.path.join(os.path.dirname(HERE), 'include', 'bader_hip.h')] + glob.glob(os.path.join(HERE, 'csrc', '*.h'))
 LIB = os.path.join(HERE, 'libbader_hip.so')
 
 # -ffp-contract=off: the reference's float64 expressions are separate multiply/add;

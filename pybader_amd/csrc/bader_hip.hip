@@ -14,1385 +14,12 @@
 // =============================================================================================
 // kernels
 // =============================================================================================
-#define TPB 256
-
-template <typename T>
-__global__ void k_fill(T *p, T v, long long n) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) p[i] = v;
-}
-
-// Workload generator, bit-identical to pybader_amd/synth.py (IEEE basic ops, fixed order).
-__global__ __launch_bounds__(TPB) void k_synth_density(Grid g, const double *__restrict__ lat,
-                                                       const double *__restrict__ atoms, int n_atoms,
-                                                       double background, double *__restrict__ rho) {
-    const long long N = (long long)g.nx * g.nyz;
-    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= N) return;
-    const int i = (int)(v / g.nyz);
-    const int r = (int)(v - (long long)i * g.nyz);
-    const int j = r / g.nz, k = r - j * g.nz;
-    const double f0 = (double)i / (double)g.nx, f1 = (double)j / (double)g.ny, f2 = (double)k / (double)g.nz;
-    double acc = background;
-    for (int a = 0; a < n_atoms; a++) {
-        const double *A = atoms + 5 * a;
-        double d0 = f0 - A[0]; d0 = d0 - rint(d0);
-        double d1 = f1 - A[1]; d1 = d1 - rint(d1);
-        double d2 = f2 - A[2]; d2 = d2 - rint(d2);
-        double r2 = 0.;
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-            const double xm = (d0 * lat[m] + d1 * lat[3 + m]) + d2 * lat[6 + m];
-            const double sq = xm * xm;
-            r2 = (m == 0) ? sq : (r2 + sq);
-        }
-        double t = 1.0 - r2 / ((2048.0 * A[3]) * A[3]);
-        if (!(t > 0.0)) t = 0.0;
-#pragma unroll
-        for (int s = 0; s < 10; s++) t = t * t;
-        acc = acc + A[4] * t;
-    }
-    rho[v] = acc;
-}
-
-// utils.vacuum_assign (utils.py:382-401): labels = -1 where rho <= tol, 0 elsewhere, over the
-// whole grid; charge/volume partial sums over the owned slab only (block reduce + one atomic).
-__global__ __launch_bounds__(TPB) void k_vacuum_assign(Grid g, const double *__restrict__ rho,
-                                                       int *__restrict__ labels, double tol, double *sum_rho,
-                                                       unsigned long long *count) {
-    const long long N = (long long)g.nx * g.nyz;
-    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
-    double s = 0.;
-    unsigned int n = 0;
-    if (v < N) {
-        const double r = rho[v];
-        const bool vac = r <= tol;  // NaN tol (vacuum_tol=None, interface.py:459) => never
-        labels[v] = vac ? -1 : 0;
-        const int x = (int)(v / g.nyz);
-        if (vac && x >= g.x0 && x < g.x1) { s = r; n = 1; }
-    }
-    __shared__ double sh[TPB / XB_WAVE];
-    __shared__ unsigned int shn[TPB / XB_WAVE];
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); n += __shfl_down(n, o); }
-    const int w = threadIdx.x / XB_WAVE, l = threadIdx.x % XB_WAVE;
-    if (l == 0) { sh[w] = s; shn[w] = n; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.;
-        unsigned int m = 0;
-        for (int q = 0; q < TPB / XB_WAVE; q++) { t += sh[q]; m += shn[q]; }
-        if (m) { atomicAdd(sum_rho, t); atomicAdd(count, (unsigned long long)m); }
-    }
-}
-
-// Record a trajectory's maximum `m` for the numbering: first[m] = min owned voxel index reaching m;
-// the thread that lowers first[m] from INT_MAX appends m to the maxima list (exactly one does).
-__device__ __forceinline__ void note_maximum(int m, int v, int *first, int *max_list, int *max_count, int max_cap) {
-    if (__builtin_nontemporal_load(&first[m]) <= v) return;  // already at or below v: nothing to do
-    const int old = atomicMin(&first[m], v);
-    if (old == XB_INT_MAX) {
-        const int k = atomicAdd(max_count, 1);
-        if (k < max_cap) max_list[k] = m;
-    }
-}
-
-// Wave-aggregated note_maximum: per distinct maximum in the wave, one lane reports the smallest
-// voxel index of the lanes that reached it.
-__device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *first, int *max_list,
-                                                  int *max_count, int max_cap) {
-    unsigned long long todo = __ballot(has);
-    const int lane = threadIdx.x % XB_WAVE;
-    while (todo) {
-        const int leader = __ffsll((unsigned long long)todo) - 1;
-        const int lm = __shfl(m, leader);
-        const bool mine = has && m == lm;
-        int vmin = mine ? v : XB_INT_MAX;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmin = min(vmin, __shfl_xor(vmin, o));
-        if (lane == leader) note_maximum(lm, vmin, first, max_list, max_count, max_cap);
-        todo &= ~__ballot(mine);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Gradient-field table: per voxel the normalised neargrid step direction (refinement.py:89-143)
-// split into integer step + remainder, and the ongrid successor (methods.py:87-117), 32 B/voxel.
-// LDS-tiled: a block stages a 4x8x64 tile of rho plus a one-voxel periodic halo (6x10x66 doubles)
-// and every thread derives 8 records from the staged 3x3x3 neighbourhoods.  Neither quantity
-// depends on the carried remainder `dr`, so every trajectory step afterwards is ONE 32-byte gather.
-// 26-neighbour maxima (ongrid successor == self) are appended to `seeds`.
-// ---------------------------------------------------------------------------------------------
-#define GT_X 8
-#define GT_Y 8
-#define GT_Z 32
-// The tile is GT_Z/8 whole 8^3 bricks in a row along z; when the grid is made of whole bricks
-// (`bmask` != null) the block also reduces, per brick, which neighbour bricks any possible move of
-// its voxels can reach (the k_brick_* kernels below work on these masks alone).
-__device__ __forceinline__ void move_ranges_raw(int code, int og, double r0, double r1, double r2, int lo[3], int hi[3]) {
-    lo[0] = hi[0] = og / 9 - 1; lo[1] = hi[1] = (og / 3) % 3 - 1; lo[2] = hi[2] = og % 3 - 1;
-    if (code != XB_STAY_CODE) {
-        const int i0 = (code & 3) - 1, i1 = ((code >> 2) & 3) - 1, i2 = (code >> 4) - 1;
-        lo[0] = min(lo[0], i0 - (r0 < 1e-12)); hi[0] = max(hi[0], i0 + (r0 > -1e-12));
-        lo[1] = min(lo[1], i1 - (r1 < 1e-12)); hi[1] = max(hi[1], i1 + (r1 > -1e-12));
-        lo[2] = min(lo[2], i2 - (r2 < 1e-12)); hi[2] = max(hi[2], i2 + (r2 > -1e-12));
-    }
-}
-__global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__restrict__ rho,
-                                                    GradRec *__restrict__ G, int *seeds, int *seed_count,
-                                                    int seed_cap, int small, int *__restrict__ bmask) {
-    __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
-    __shared__ int s_mask[GT_Z / 8];
-    // plane tiles are counted from the start of the table window (brick aligned; the whole grid on one GPU)
-    int x0 = g.wx0 + blockIdx.z * GT_X;
-    if (x0 >= g.nx) x0 -= g.nx;
-    const int y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
-    if (threadIdx.x < GT_Z / 8) s_mask[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2); i += TPB) {
-        const int ez = i % (GT_Z + 2);
-        const int r = i / (GT_Z + 2);
-        const int ey = r % (GT_Y + 2), ex = r / (GT_Y + 2);
-        int X = x0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
-        if (small) {
-            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
-        } else {
-            X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
-        }
-        tile[ex][ey][ez] = rho[(X * g.ny + Y) * g.nz + Z];
-    }
-    __syncthreads();
-    const int tz = threadIdx.x & (GT_Z - 1), ty = threadIdx.x / GT_Z;   // 32 x 8 threads, 8 voxels (x) each
-    int mine = 0;  // move mask of this thread's voxels (all in brick tz >> 3 of the tile)
-#pragma unroll 1
-    for (int k = 0; k < GT_X; k++) {
-        const int tx = k;
-        const int x = x0 + tx, y = y0 + ty, z = z0 + tz;
-        if (x >= g.nx || y >= g.ny || z >= g.nz) continue;
-        const int v = (x * g.ny + y) * g.nz + z;
-        const double c = tile[tx + 1][ty + 1][tz + 1];
-        // ongrid successor: strict '>' first-wins scan in (ix,iy,iz) ascending order
-        double max_val = c;
-        int og = XB_OG_SELF;
-#pragma unroll
-        for (int ix = 0; ix < 3; ix++)
-#pragma unroll
-            for (int iy = 0; iy < 3; iy++)
-#pragma unroll
-                for (int iz = 0; iz < 3; iz++) {
-                    double w = tile[tx + ix][ty + iy][tz + iz];
-                    w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
-                    w += c;
-                    if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
-                }
-        GradRec o;
-        double d0, d1, d2;
-        int code;
-        if (ng_dir_vals(g, c, tile[tx + 2][ty + 1][tz + 1], tile[tx][ty + 1][tz + 1], tile[tx + 1][ty + 2][tz + 1],
-                        tile[tx + 1][ty][tz + 1], tile[tx + 1][ty + 1][tz + 2], tile[tx + 1][ty + 1][tz], d0, d1, d2)) {
-            // max_grad < 1E-14: a trajectory stays on p, p is on its path, so the reference resets dr
-            // and takes the ongrid step (refinement.py:200-235) -- which is the tabulated successor
-            o.r0 = o.r1 = o.r2 = 0.;
-            code = XB_STAY_CODE;
-        } else {
-            // refinement.py:138-143: int_grad = rha(grad_dir); the remainder grad_dir - int_grad is what
-            // every trajectory through p adds to its dr
-            const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
-            o.r0 = d0 - (double)i0;
-            o.r1 = d1 - (double)i1;
-            o.r2 = d2 - (double)i2;
-            code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
-        }
-        o.key = pack_key(c, code, og);
-        G[v] = o;
-        if (og == XB_OG_SELF) {
-            const int q = atomicAdd(seed_count, 1);
-            if (q < seed_cap) seeds[q] = v;
-            mine |= 1 << 27;
-        }
-        if (bmask) {  // which neighbour bricks can a move from this voxel reach (moves <= 2 voxels)
-            int lo[3], hi[3];
-            move_ranges_raw(code, og, o.r0, o.r1, o.r2, lo, hi);
-            const int ob[3] = {tx, ty, tz & 7};
-            int k0[3], k1[3];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                k0[j] = (ob[j] + lo[j] < 0) ? -1 : 0;
-                k1[j] = (ob[j] + hi[j] >= 8) ? 1 : 0;
-            }
-            for (int c0 = k0[0]; c0 <= k1[0]; c0++)
-                for (int c1 = k0[1]; c1 <= k1[1]; c1++)
-                    for (int c2 = k0[2]; c2 <= k1[2]; c2++) mine |= 1 << ((c0 + 1) * 9 + (c1 + 1) * 3 + (c2 + 1));
-        }
-    }
-    if (bmask) {
-        atomicOr(&s_mask[tz >> 3], mine);
-        __syncthreads();
-        if (threadIdx.x < GT_Z / 8 && z0 + threadIdx.x * 8 < g.nz) {
-            const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
-            bmask[((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x] = s_mask[threadIdx.x] & ~(1 << 13);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Trapping boxes.  For a 26-neighbour maximum m let B_R = {v : |v - m|_inf <= R} (minimum image).
-// B_R is CLOSED when no voxel of B_R can be left by (a) a neargrid move, for ANY carried remainder dr,
-// or (b) an ongrid move.  (a): per axis the move is int_grad + corr with corr = rha(dr + r),
-// |dr| <= 0.5 (+1 ulp): corr can be +1 only if r >= 0 and -1 only if r <= 0 (both when |r| < 1e-12),
-// so the reachable offsets are a per-axis interval read off the table record.  If B_R is closed and
-// m is its only 26-neighbour maximum, every trajectory that arrives at a voxel of B_R ends at m --
-// exactly, whatever its dr -- so the trace may stop there.  Moves are at most 2 voxels long, so a
-// voxel at distance d whose farthest successor is at distance D only violates the boxes d <= R < D.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int min_image_abs(int t, int n) {
-    int a = t < 0 ? -t : t;
-    if (a >= n) a -= n;
-    return min(a, n - a);
-}
-// Per-axis interval of the offsets any move from this voxel can have: the ongrid move plus the
-// conservative set of neargrid moves (see above).
-__device__ __forceinline__ void move_ranges(const GradRec &rec, int lo[3], int hi[3]) {
-    const int code = key_code(rec.key), og = key_og(rec.key);
-    lo[0] = hi[0] = og / 9 - 1; lo[1] = hi[1] = (og / 3) % 3 - 1; lo[2] = hi[2] = og % 3 - 1;
-    if (code != XB_STAY_CODE) {
-        const int i0 = (code & 3) - 1, i1 = ((code >> 2) & 3) - 1, i2 = (code >> 4) - 1;
-        lo[0] = min(lo[0], i0 - (rec.r0 < 1e-12)); hi[0] = max(hi[0], i0 + (rec.r0 > -1e-12));
-        lo[1] = min(lo[1], i1 - (rec.r1 < 1e-12)); hi[1] = max(hi[1], i1 + (rec.r1 > -1e-12));
-        lo[2] = min(lo[2], i2 - (rec.r2 < 1e-12)); hi[2] = max(hi[2], i2 + (rec.r2 > -1e-12));
-    }
-}
-__device__ __forceinline__ int wrap_any(int v, int n) { v %= n; return v < 0 ? v + n : v; }
-
-// The same move intervals derived from rho directly (no table record needed): used for the seed cubes
-// when the table only covers a window of the grid (slabs).
-__device__ __forceinline__ void move_ranges_rho(const double *__restrict__ rho, const Grid &g, int x, int y, int z,
-                                                int lo[3], int hi[3]) {
-    const int v = lin3(g, x, y, z);
-    const double c = rho[v];
-    double max_val = c;
-    int og = XB_OG_SELF;
-    for (int ix = 0; ix < 3; ix++) {
-        const int tx = wrapi(x + ix - 1, g.nx);
-        for (int iy = 0; iy < 3; iy++) {
-            const int ty = wrapi(y + iy - 1, g.ny);
-            for (int iz = 0; iz < 3; iz++) {
-                const int tz = wrapi(z + iz - 1, g.nz);
-                double w = rho[lin3(g, tx, ty, tz)];
-                w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
-                w += c;
-                if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
-            }
-        }
-    }
-    double d0, d1, d2;
-    if (ng_dir(rho, g, x, y, z, v, c, d0, d1, d2)) move_ranges_raw(XB_STAY_CODE, og, 0., 0., 0., lo, hi);
-    else {
-        const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
-        move_ranges_raw((i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4), og, d0 - (double)i0, d1 - (double)i1,
-                        d2 - (double)i2, lo, hi);
-    }
-}
-__global__ __launch_bounds__(TPB) void k_box_shells_rho(Grid g, const double *__restrict__ rho,
-                                                        const int *__restrict__ mxyz, const int *__restrict__ rcap,
-                                                        int rlo, int K, int *bad, int stride) {
-    const int m = blockIdx.y;
-    const int rhi = min(rlo + K, rcap[m]);
-    if (rhi < rlo) return;
-    const int w = 2 * rhi + 1;
-    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (t >= (long long)w * w * w) return;
-    const int o[3] = {(int)(t / ((long long)w * w)) - rhi, (int)((t / w) % w) - rhi, (int)(t % w) - rhi};
-    const int d = max(max(abs(o[0]), abs(o[1])), abs(o[2]));
-    if (d < rlo) return;
-    int lo[3], hi[3];
-    move_ranges_rho(rho, g, wrap_any(mxyz[3 * m] + o[0], g.nx), wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
-                    wrap_any(mxyz[3 * m + 2] + o[2], g.nz), lo, hi);
-    int D = 0;
-#pragma unroll
-    for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));
-    for (int R = d; R < D; R++) bad[m * stride + R] = 1;
-}
-
-// Closed cubes around the maxima, found in batches of K shells: the launch visits, for box m, the
-// voxels at L-inf distance d in [rlo, rlo+K] of the maximum.  A voxel at distance d whose farthest
-// successor is at distance D violates the cubes d <= R < D (moves are at most 2 voxels long, so
-// only the two outer shells of a cube can violate it).
-__global__ __launch_bounds__(TPB) void k_box_shells(GridL g, const GradRec *__restrict__ G,
-                                                    const int *__restrict__ mxyz, const int *__restrict__ rcap,
-                                                    int rlo, int K, int *bad, int stride) {
-    const int m = blockIdx.y;
-    const int rhi = min(rlo + K, rcap[m]);
-    if (rhi < rlo) return;
-    const int w = 2 * rhi + 1;
-    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (t >= (long long)w * w * w) return;
-    const int o[3] = {(int)(t / ((long long)w * w)) - rhi, (int)((t / w) % w) - rhi, (int)(t % w) - rhi};
-    const int d = max(max(abs(o[0]), abs(o[1])), abs(o[2]));
-    if (d < rlo) return;
-    const int x = wrap_any(mxyz[3 * m] + o[0], g.nx), y = wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
-              z = wrap_any(mxyz[3 * m + 2] + o[2], g.nz);
-    const GradRec rec = fetch_rec(G, (x * g.ny + y) * g.nz + z);
-    int lo[3], hi[3];
-    move_ranges(rec, lo, hi);
-    int D = 0;
-#pragma unroll
-    for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));
-    for (int R = d; R < D; R++) bad[m * stride + R] = 1;
-}
-// stamp box id `id` into the key of every voxel of the cube B_R(m)
-__global__ __launch_bounds__(TPB) void k_box_stamp(GridL g, GradRec *G, int mx, int my, int mz, int R, int id) {
-    const int w = 2 * R + 1;
-    const long long n = (long long)w * w * w;
-    const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (t >= n) return;
-    const int dz = (int)(t % w), dy = (int)((t / w) % w), dx = (int)(t / ((long long)w * w));
-    const int x = wrap_any(mx + dx - R, g.nx), y = wrap_any(my + dy - R, g.ny), z = wrap_any(mz + dz - R, g.nz);
-    long long *kp = reinterpret_cast<long long *>(&G[(x * g.ny + y) * g.nz + z].key);
-    *kp = (*kp & ~(0x3FFLL << 11)) | ((long long)id << 11);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Growing the trapping regions brick by brick (8x8x8 voxels).  Let U be a union of sets certain
-// for maximum m (closed boxes, earlier bricks).  A brick B without a 26-neighbour maximum whose
-// every possible move (any dr) from every voxel lands in B itself or in bricks that are certain
-// for the SAME m keeps U + B closed, and a trajectory cannot stay in B forever (it only ends on
-// a maximum), so it must enter U: B is certain for m as well.  One round tests the uncertain
-// bricks that touch the certain region of the previous round (deterministic: reads `blab` of the
-// previous round only) and stamps the ones that pass.
-// ---------------------------------------------------------------------------------------------
-#define BRK 8
-// blab: 0 unknown, id > 0 certain for box id, -1 never (holds a maximum)
-__global__ void k_brick_seed(GridL g, int nb0, int nb1, int nb2, int n_boxes, const int *__restrict__ mxyz,
-                             const int *__restrict__ radius, int *blab) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb0 * nb1 * nb2) return;
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int lab = 0;
-    for (int m = 0; m < n_boxes; m++) {
-        const int R = radius[m];
-        // the brick [8b, 8b+7] lies inside the cube iff both ends are within R of the maximum on
-        // every axis (minimum image; boxes never wrap onto themselves)
-        bool in = true;
-        const int n3[3] = {g.nx, g.ny, g.nz}, bb[3] = {b0, b1, b2};
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            int lo = bb[j] * BRK - mxyz[3 * m + j];
-            lo = ((lo % n3[j]) + n3[j]) % n3[j];
-            if (lo > n3[j] / 2) lo -= n3[j];
-            in &= (lo >= -R) && (lo + BRK - 1 <= R);
-        }
-        if (in) lab = m + 1;
-    }
-    blab[b] = lab;
-}
-// bmask[K] (built by k_grad_field): bit k (k = (d0+1)*9+(d1+1)*3+(d2+1), d = brick offset) is set
-// when some possible move of some voxel of brick K lands in the neighbour brick K+d; bit 27 is set
-// when the brick holds a 26-neighbour maximum.
-__device__ __forceinline__ int brick_nb(int b0, int b1, int b2, int k, int nb0, int nb1, int nb2) {
-    return (wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2);
-}
-// provisional labels: an unlabelled brick adopts the label of a labelled brick it can move into
-// (smallest label on ties); `plab` double-buffered by the caller.  Any guess is sound -- the kill
-// iterations below decide -- a good guess only makes the certain regions larger.
-__global__ void k_brick_propagate(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
-                                  const int *__restrict__ pin, int *__restrict__ pout, int *changed) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb0 * nb1 * nb2) return;
-    int l = pin[b];
-    if (l == 0 && !(bmask[b] >> 27)) {
-        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-        const int m = bmask[b];
-        int best = 0;
-        for (int k = 0; k < 27; k++)
-            if ((m >> k) & 1) {
-                const int q = pin[brick_nb(b0, b1, b2, k, nb0, nb1, nb2)];
-                if (q > 0 && (best == 0 || q < best)) best = q;
-            }
-        if (best) { l = best; *changed = 1; }
-    }
-    pout[b] = l;
-}
-// kill iterations (greatest fixpoint): a non-seed brick stays alive for its label m only while it
-// holds no maximum and every brick it can move into is alive with the same label.  What survives,
-// together with the seed cubes, is closed under every possible move: a trapping region of m.
-__global__ void k_brick_kill(int nb0, int nb1, int nb2, const int *__restrict__ bmask, const int *__restrict__ seed,
-                             const int *__restrict__ ain, int *__restrict__ aout, int *changed) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb0 * nb1 * nb2) return;
-    int l = ain[b];
-    if (l > 0 && seed[b] == 0) {
-        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-        const int m = bmask[b];
-        bool ok = !(m >> 27);
-        for (int k = 0; k < 27 && ok; k++)
-            if ((m >> k) & 1) ok = (ain[brick_nb(b0, b1, b2, k, nb0, nb1, nb2)] == l);
-        if (!ok) { l = 0; *changed = 1; }
-    }
-    aout[b] = l;
-}
-__global__ void k_count_positive(const int *__restrict__ a, int n, int *count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long b = __ballot(i < n && a[i] > 0);
-    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(count, __popcll(b));
-}
-
-// ---------------------------------------------------------------------------------------------
-// neargrid assignment: every owned non-vacuum voxel follows its own dr=0 trajectory
-// (refinement.py:17-322 stepping rules without the early stop) to the maximum it reaches.
-// One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
-// of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
-// ---------------------------------------------------------------------------------------------
-// Voxels inside a trapping region end at its maximum: fill their labels in one streaming sweep
-// (vacuum voxels keep -1; a region whose maximum is vacuum hands out -1, refinement.py:286) and note
-// the maxima for the numbering.  The uncertain bricks go to the work list of k_ng_trace.
-__global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__restrict__ blab, int nb1, int nb2,
-                                                      const int *__restrict__ box_max, int *labels, int *first,
-                                                      int *max_list, int *max_count, int max_cap) {
-    const int vbeg = g.x0 * g.nyz, vend = g.x1 * g.nyz;
-    const int v = vbeg + blockIdx.x * TPB + threadIdx.x;
-    const bool in = v < vend;
-    int result = -1;
-    bool has = false;
-    if (in) {
-        const int x = v / g.nyz;
-        const int r = v - x * g.nyz;
-        const int y = r / g.nz, z = r - y * g.nz;
-        const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
-        if (b > 0 && labels[v] != -1) {
-            result = box_max[b - 1];
-            if (result != v && labels[result] == -1) result = -1;
-            labels[v] = result;
-            has = result >= 0;
-        }
-    }
-    note_maximum_wave(has, result, in ? v : 0, first, max_list, max_count, max_cap);
-}
-// Without vacuum every voxel of a certain brick belongs to its maximum and the smallest voxel
-// index of a brick is its corner: the numbering needs one note per owned certain brick, and the
-// labels themselves are written by k_relabel_regions after the trace.
-__global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_lo, int b_hi,
-                                      const int *__restrict__ blab, const int *__restrict__ box_max, int *first,
-                                      int *max_list, int *max_count, int max_cap) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = (b < nb0 * nb1 * nb2 && b >= b_lo && b < b_hi) ? blab[b] : 0;
-    const bool has = l > 0;
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    // one atomic per distinct maximum per wave (a handful of maxima own all the bricks)
-    note_maximum_wave(has, has ? box_max[l - 1] : 0, ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list,
-                      max_count, max_cap);
-}
-// labels := rank of the maximum; voxels of certain bricks take it from the brick label, the others
-// from the maximum index the trace left in `labels`
-__global__ __launch_bounds__(TPB) void k_relabel_regions(GridL g, int *labels, const int *__restrict__ rank,
-                                                         const int *__restrict__ blab, int nb1, int nb2,
-                                                         const int *__restrict__ box_max) {
-    const int v = g.x0 * g.nyz + blockIdx.x * TPB + threadIdx.x;
-    if (v >= g.x1 * g.nyz) return;
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
-    if (b > 0) labels[v] = rank[box_max[b - 1]];
-    else {
-        const int m = labels[v];
-        if (m >= 0) labels[v] = rank[m];
-    }
-}
-__global__ void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab, int *walk, int *n_walk) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;   // bricks [b_lo, b_hi) are the owned slab
-    const bool hit = b < nbr && b >= b_lo && b < b_hi && blab[b] <= 0;
-    const unsigned long long m = __ballot(hit);
-    if (!m) return;
-    const int lane = threadIdx.x % XB_WAVE;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(n_walk, __popcll(m));
-    base = __shfl(base, 0);
-    if (hit) walk[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
-}
-
-__device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
-    ox = og / 9 - 1; oy = (og / 3) % 3 - 1; oz = og % 3 - 1;
-}
-
-template <int K>
-__global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
-                                                  const int *__restrict__ box_max, const int *__restrict__ blab,
-                                                  int nb1, int nb2, const int *__restrict__ walk, int n_walk,
-                                                  int *labels, int *first,
-                                                  int *max_list, int *max_count, int max_cap, int *ovf_list,
-                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt) {
-    // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
-    // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
-    // whose trajectories read the same table lines -- share one L2.
-    int blk = blockIdx.x;
-    if (opt & 2) {
-        const int per = gridDim.x >> 3;
-        if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
-    }
-    const int wpb = blockDim.x / XB_WAVE;  // waves per block (launch-time choice)
-    const int wave = blk * wpb + threadIdx.x / XB_WAVE;
-    const int lane = threadIdx.x % XB_WAVE;
-    int sx, sy, sz;
-    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (4x4x4 each) per brick
-        if ((wave >> 3) >= n_walk) return;
-        const int b = walk[wave >> 3], sub = wave & 7;
-        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-        sx = b0 * 8 + ((sub >> 2) << 2) + (lane >> 4);
-        sy = b1 * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
-        sz = b2 * 8 + ((sub & 1) << 2) + (lane & 3);
-        if (sx < g.x0 || sx >= g.x1) return;  // whole wave: 4 planes of one brick half, slab edges are brick aligned or not owned
-    } else if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
-        const int bz_n = (g.nz + 3) >> 2, by_n = (g.ny + 3) >> 2;
-        const int bx = wave / (by_n * bz_n);
-        const int brem = wave - bx * (by_n * bz_n);
-        const int by = brem / bz_n, bz = brem - by * bz_n;
-        sx = g.x0 + bx * 4 + (lane >> 4); sy = by * 4 + ((lane >> 2) & 3); sz = bz * 4 + (lane & 3);
-    } else {        // one wave = a run of 64 voxels along z
-        const int rz_n = (g.nz + 63) >> 6;
-        const int row = wave / rz_n;
-        sz = (wave - row * rz_n) * 64 + lane;
-        sx = g.x0 + row / g.ny;
-        sy = row - (row / g.ny) * g.ny;
-    }
-    const bool valid = sx < g.x1 && sy < g.ny && sz < g.nz;
-    const int v = valid ? (sx * g.ny + sy) * g.nz + sz : 0;
-    bool moving = false;
-    int result = -1;
-    int px = 0, py = 0, pz = 0, lp = 0, steps = 0;
-    double dr0 = 0., dr1 = 0., dr2 = 0.;
-    GradRec rec = {0., 0., 0., 0.};
-    PathWindow<K> w;
-    w.init(0, 0.);
-    if (valid && labels[v] != -1) {
-        px = sx; py = sy; pz = sz;
-        lp = v;
-        // trapping regions: brick labels (grids made of whole 8^3 bricks) or box ids in the keys
-        int b = blab ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
-        if (b <= 0) {
-            rec = fetch_rec(G, v);
-            b = key_box(rec.key);
-        }
-        if (b > 0) result = box_max[b - 1];  // starts inside a trapping region: ends at its maximum
-        else { w.init(v, rec.key); moving = true; }
-    }
-    while (__any(moving)) {
-        if (moving) {
-            const int bits = key_bits(rec.key);
-            const int code = bits & 63;
-            int qx, qy, qz, lq = 0;
-            // refinement.py:132-154: the gradient move (if the voxel has one)
-            bool og_move = (code == XB_STAY_CODE);
-            if (!og_move) {
-                ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
-                lq = lin3f(g, qx, qy, qz);
-                og_move = w.contains(lq);  // refinement.py:200: already been here on this path
-            }
-            if (og_move) {  // refinement.py:201-235: dr = 0 and one ongrid step from p (tabulated)
-                const int og = (bits >> 6) & 31;
-                if (og == XB_OG_SELF) { result = lp; moving = false; }  // break_flag: p is the maximum
-                else {
-                    int ox, oy, oz;
-                    og_offsets(og, ox, oy, oz);
-                    dr0 = dr1 = dr2 = 0.;
-                    qx = wrap_u(px + ox, g.nx); qy = wrap_u(py + oy, g.ny); qz = wrap_u(pz + oz, g.nz);
-                    lq = lin3f(g, qx, qy, qz);
-                }
-            }
-            if (moving) {
-                const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
-                const bool in_win = plane_in_window(g, qx);  // the table only exists inside the window (slabs)
-                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
-                const int b = bl > 0 ? bl : (in_win ? key_box(nr.key) : 0);
-                if (b) {  // arrived inside a trapping region (q cannot be an old path voxel: the
-                    result = box_max[b - 1];  // trajectory would have stopped there already)
-                    moving = false;
-                } else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
-                    result = -2;  // left the table window / membership undecidable: exact slow kernel
-                    moving = false;  // (ongrid moves are appended without a membership test, 305-315)
-                } else {
-                    w.push(lq, nr.key);
-                    px = qx; py = qy; pz = qz; lp = lq; rec = nr;
-                }
-            }
-        }
-    }
-    // a maximum that is itself vacuum hands its -1 to the start voxel (refinement.py:286)
-    if (valid && result >= 0 && result != v && labels[result] == -1) result = -1;
-    if (valid) labels[v] = result;
-    note_maximum_wave(valid && result >= 0, result, v, first, max_list, max_count, max_cap);
-    if (valid && result == -2) {
-        const int k = atomicAdd(ovf_count, 1);
-        if (k < ovf_cap) ovf_list[k] = v;
-    }
-}
-
-// Exact slow path for the (rare) trajectories whose path membership could not be decided from the
-// window: the whole path lives in global scratch and is scanned linearly.
-// mode 0: assignment (write maximum index, note it); mode 1: refinement retrace.
-__global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
-                             int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
-                             int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int v = list[t];
-    int *P = path + (size_t)t * lmax;
-    int np = 0;
-    int px = v / g.nyz;
-    int r = v - px * g.nyz;
-    int py = r / g.nz, pz = r - py * g.nz, lp = v;
-    double c = rho[v], dr0 = 0., dr1 = 0., dr2 = 0.;
-    const int vol_num = labels[v];
-    P[np++] = v;
-    int result = -3;
-    for (;;) {
-        int qx, qy, qz;
-        const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
-        int lq = lin3(g, qx, qy, qz);
-        bool on_path = stay;
-        for (int k = np - 1; k >= 0 && !on_path; k--) on_path = (P[k] == lq);
-        if (on_path) {
-            dr0 = dr1 = dr2 = 0.;
-            og_step(rho, g, g.dist, px, py, pz, c, qx, qy, qz);
-            lq = lin3(g, qx, qy, qz);
-            if (qx == px && qy == py && qz == pz) { result = lp; break; }
-        }
-        if (refine) {
-            if (!plane_valid(g, qx)) { known[v] = -6; atomicAdd(escaped, 1); return; }
-            if (known_ro[lq] == 2) { result = lq; break; }
-        }
-        if (np >= lmax) { atomicExch(err, 1); return; }
-        P[np++] = lq;
-        px = qx; py = qy; pz = qz; lp = lq; c = rho[lq];
-    }
-    if (refine) {
-        const int nv = labels[result];
-        if (nv != vol_num) { labels[v] = nv; known[v] = -2; atomicAdd(changed, 1); }
-        else known[v] = -1;
-    } else {
-        if (result != v && labels[result] == -1) result = -1;
-        labels[v] = result;
-        if (result >= 0) note_maximum(result, v, first, max_list, max_count, max_cap);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ongrid assignment (methods.py:15-219).  The ascent is memoryless, so the sequential path
-// compression of the reference equals: best-neighbour pointer per voxel, then pointer jumping.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_og_pointer(Grid g, const double *__restrict__ rho, int *labels) {
-    const long long N = (long long)g.nx * g.nyz;
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (vv >= N) return;
-    const int v = (int)vv;
-    if (labels[v] == -1) return;  // vacuum stays -1 (methods.py:73-74)
-    const int px = v / g.nyz;
-    const int r = v - px * g.nyz;
-    const int py = r / g.nz, pz = r - py * g.nz;
-    int qx, qy, qz;
-    og_step(rho, g, g.dist, px, py, pz, rho[v], qx, qy, qz);
-    labels[v] = lin3(g, qx, qy, qz);
-}
-// A chain that steps onto a vacuum voxel inherits -1 (methods.py:166-168).  In-place and
-// asynchronous: any value read is an ancestor of the root, so progress is monotone.
-__global__ __launch_bounds__(TPB) void k_og_jump(Grid g, int *labels, int *not_done) {
-    const long long N = (long long)g.nx * g.nyz;
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (vv >= N) return;
-    const int v = (int)vv;
-    int p = labels[v];
-    if (p < 0 || p == v) return;
-    int q = labels[p];
-    if (q == p) return;  // parent is a root
-    if (q >= 0) {
-        const int q2 = labels[q];  // two hops per sweep
-        if (q2 >= 0) q = q2;
-        else q = -1;
-    }
-    labels[v] = q;
-    if (q >= 0) *not_done = 1;
-}
-__global__ __launch_bounds__(TPB) void k_note_roots(Grid g, const int *labels, int *first, int *max_list,
-                                                    int *max_count, int max_cap) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    const bool valid = vv < vend;
-    const int v = valid ? (int)vv : 0;
-    const int m = valid ? labels[v] : -1;
-    note_maximum_wave(valid && m >= 0, m, v, first, max_list, max_count, max_cap);
-}
-
-// numbering helpers ---------------------------------------------------------------------------
-__global__ void k_gather_first(const int *first, const int *max_list, int n, int *out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = first[max_list[i]];
-}
-__global__ void k_set_rank(int *first, const int *max_sorted, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) first[max_sorted[i]] = i;
-}
-__global__ void k_reset_first(int *first, const int *max_list, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) first[max_list[i]] = XB_INT_MAX;
-}
-// labels[v] (maximum index) -> rank stored in first[maximum]
-__global__ __launch_bounds__(TPB) void k_relabel(Grid g, int *labels, const int *__restrict__ rank) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= vend) return;
-    const int m = labels[v];
-    if (m >= 0) labels[v] = rank[m];
-}
-
-// ---------------------------------------------------------------------------------------------
-// refinement.edge_find (refinement.py:326-405) on a fresh `known`, as two order-free passes.
-// Pass 1 (planes [x0-1, x1+1)): -2 if a non-vacuum neighbour carries another label and the voxel
-// is not a 26-neighbour density maximum; else 2 (non-vacuum) / 0 (vacuum).
-// Pass 2 (owned planes): voxels >= 0 with an edge in their 27-box become -1 (refinement.py:403-404,
-// which has no vacuum test).  Together these equal the sequential in-place sweep.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify27(const Grid &g, const double *__restrict__ rho,
-                                           const int *__restrict__ labels, int x, int y, int z, int v,
-                                           bool &is_edge, bool &is_max) {
-    const int vol_num = labels[v];
-    is_edge = false;
-    is_max = true;
-    int nb[27];
-    int k = 0;
-#pragma unroll
-    for (int ix = -1; ix < 2; ix++) {
-        const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-        for (int iy = -1; iy < 2; iy++) {
-            const int ty = wrapi(y + iy, g.ny);
-#pragma unroll
-            for (int iz = -1; iz < 2; iz++) {
-                const int tz = wrapi(z + iz, g.nz);
-                const int l = lin3(g, tx, ty, tz);
-                const int nv = labels[l];
-                nb[k++] = (nv == -1) ? -1 : l;
-                if (nv != -1 && nv != vol_num) is_edge = true;
-            }
-        }
-    }
-    if (!is_edge) return;  // is_max only matters for edges (refinement.py:376-383)
-    const double max_val = rho[v];
-#pragma unroll
-    for (k = 0; k < 27; k++)
-        if (nb[k] >= 0 && rho[nb[k]] > max_val) is_max = false;
-}
-
-// Block-wide exclusive scan of a small per-thread count (TPB threads); returns the offset of this
-// thread and the block total.
-__device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
-    __shared__ int wsum[TPB / XB_WAVE];
-    const int lane = threadIdx.x % XB_WAVE, w = threadIdx.x / XB_WAVE;
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < XB_WAVE; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == XB_WAVE - 1) wsum[w] = incl;
-    __syncthreads();
-    int base = 0;
-    total = 0;
-#pragma unroll
-    for (int q = 0; q < TPB / XB_WAVE; q++) {
-        if (q < w) base += wsum[q];
-        total += wsum[q];
-    }
-    __syncthreads();
-    return base + incl - cnt;
-}
-
-// buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
-// Lets the edge sweep skip tiles whose whole 3x3x3 surroundings carry one label (no edge possible).
-#define XB_MIXED (-2147483647 - 1)
-__global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__restrict__ labels, int nb1, int nb2,
-                                                       int *__restrict__ buni) {
-    __shared__ int s_min, s_max;
-    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
-    __syncthreads();
-    const int b = blockIdx.x;
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int lo = 2147483647, hi = XB_MIXED;
-    for (int t = threadIdx.x; t < 512; t += TPB) {
-        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
-        lo = min(lo, l); hi = max(hi, l);
-    }
-    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
-    __syncthreads();
-    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
-}
-// After an assignment without vacuum every certain brick is uniform by construction (all its voxels
-// carry the rank of the region's maximum): only the bricks of the walk list need the label scan.
-__global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
-                                    const int *__restrict__ rank, int *__restrict__ buni) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbr) return;
-    const int l = blab[b];
-    if (l > 0) buni[b] = rank[box_max[l - 1]];
-}
-__global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *__restrict__ labels, int nb1, int nb2,
-                                                            const int *__restrict__ walk, int n_walk,
-                                                            int *__restrict__ buni) {
-    __shared__ int s_min, s_max;
-    if ((int)blockIdx.x >= n_walk) return;
-    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
-    __syncthreads();
-    const int b = walk[blockIdx.x];
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int lo = 2147483647, hi = XB_MIXED;
-    for (int t = threadIdx.x; t < 512; t += TPB) {
-        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
-        lo = min(lo, l); hi = max(hi, l);
-    }
-    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
-    __syncthreads();
-    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
-}
-
-// refinement.py:385-404 as written there: every listed edge voxel turns the known >= 0 voxels of
-// its 27-box into -1 (all -2 flags are final before this kernel starts).
-__global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known, const int *__restrict__ list, int n) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n) return;
-    const int v = list[t];
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-#pragma unroll
-    for (int ix = -1; ix < 2; ix++) {
-        const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-        for (int iy = -1; iy < 2; iy++) {
-            const int ty = wrapi(y + iy, g.ny);
-#pragma unroll
-            for (int iz = -1; iz < 2; iz++) {
-                const int l = (tx * g.ny + ty) * g.nz + wrapi(z + iz, g.nz);
-                if (known[l] >= 0) known[l] = -1;
-            }
-        }
-    }
-}
-
-// LDS-tiled edge_find pass 1: a block stages the labels of a 4x8x64 tile plus a one-voxel periodic
-// halo (6x10x66 ints) in LDS, every thread classifies 8 voxels from the staged 3x3x3
-// neighbourhoods, and the block appends its owned edge voxels to the edge list with ONE atomic
-// (the list length is the edge count edge_find returns).  rho is only read for the few voxels
-// that have a foreign neighbour (the is_max test, refinement.py:374-375).
-#define ET_X 4
-#define ET_Y 8
-#define ET_Z 64
-__global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *__restrict__ rho,
-                                                         const int *__restrict__ labels,
-                                                         int8_t *__restrict__ known, int xa, int nplanes,
-                                                         int *__restrict__ list, int *list_count, int small,
-                                                         const int *__restrict__ buni,
-                                                         const GradRec *__restrict__ G) {
-    __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
-    const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
-    if (buni) {
-        // every brick that meets the tile or its one-voxel halo carries the same single label: no
-        // voxel of the tile has a foreign neighbour (2 x 3 x 10 bricks, one lookup per thread)
-        __shared__ int s_lab, s_mixed;
-        if (threadIdx.x == 0) { s_lab = XB_MIXED; s_mixed = 0; }
-        __syncthreads();
-        const int nb0 = g.nx >> 3, nb1 = g.ny >> 3, nb2 = g.nz >> 3;
-        const int bx_lo = (xa + tx0 - 1) >> 3, bx_n = ((xa + tx0 + ET_X) >> 3) - bx_lo + 1;  // arithmetic shift: -1 >> 3 == -1
-        const int by_lo = (y0 - 1) >> 3, by_n = ((y0 + ET_Y) >> 3) - by_lo + 1;
-        const int bz_lo = (z0 - 1) >> 3, bz_n = ((z0 + ET_Z) >> 3) - bz_lo + 1;
-        for (int t = threadIdx.x; t < bx_n * by_n * bz_n; t += TPB) {
-            const int q0 = wrap_any(bx_lo + t / (by_n * bz_n), nb0), q1 = wrap_any(by_lo + (t / bz_n) % by_n, nb1),
-                      q2 = wrap_any(bz_lo + t % bz_n, nb2);
-            const int l = buni[(q0 * nb1 + q1) * nb2 + q2];
-            if (l == XB_MIXED) s_mixed = 1;
-            else {
-                const int old = atomicCAS(&s_lab, XB_MIXED, l);
-                if (old != XB_MIXED && old != l) s_mixed = 1;
-            }
-        }
-        __syncthreads();
-        if (!s_mixed) {
-            const int8_t o = (s_lab == -1) ? 0 : 2;  // vacuum stays 0 (refinement.py:342-343), else "known"
-            const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int xr = tx0 + (k >> 1), y = y0 + tyb + ((k & 1) << 2), z = z0 + tz;
-                if (xr < nplanes && y < g.ny && z < g.nz) {
-                    int x = xa + xr;
-                    if (x >= g.nx) x -= g.nx;
-                    known[(x * g.ny + y) * g.nz + z] = o;
-                }
-            }
-            return;
-        }
-    }
-    for (int i = threadIdx.x; i < (ET_X + 2) * (ET_Y + 2) * (ET_Z + 2); i += TPB) {
-        const int ez = i % (ET_Z + 2);
-        const int r = i / (ET_Z + 2);
-        const int ey = r % (ET_Y + 2), ex = r / (ET_Y + 2);
-        int X = xa + tx0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
-        if (small) {
-            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
-        } else {
-            X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
-        }
-        tile[ex][ey][ez] = labels[(X * g.ny + Y) * g.nz + Z];
-    }
-    __syncthreads();
-    const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
-    int8_t out[8];
-    int vidx[8];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
-        const int xr = tx0 + tx, y = y0 + ty, z = z0 + tz;
-        out[k] = 1;  // 1 = outside the grid / the plane range: nothing to store
-        vidx[k] = -1;
-        if (xr < nplanes && y < g.ny && z < g.nz) {
-            int x = xa + xr;
-            if (x >= g.nx) x -= g.nx;
-            const int v = (x * g.ny + y) * g.nz + z;
-            const int lab = tile[tx + 1][ty + 1][tz + 1];
-            int8_t o = 0;  // vacuum voxels are not classified (refinement.py:342-343)
-            if (lab != -1) {
-                bool is_edge = false;
-#pragma unroll
-                for (int dx = 0; dx < 3; dx++)
-#pragma unroll
-                    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                        for (int dz = 0; dz < 3; dz++) {
-                            const int nv = tile[tx + dx][ty + dy][tz + dz];
-                            is_edge |= (nv != -1) & (nv != lab);
-                        }
-                o = 2;
-                if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
-                    bool is_max = true, decided = false;
-                    if (G) {
-                        // the table knows the best distance-weighted neighbour of v; if there is one
-                        // (and it is not vacuum) that neighbour is denser than v: not a maximum.
-                        // (weighted > rho(v) implies rho(n) > rho(v); the converse can fail by
-                        // rounding, so "no such neighbour" still takes the full test)
-                        const int og = key_og(G[v].key);
-                        if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
-                            is_max = false;
-                            decided = true;
-                        }
-                    }
-                    if (!decided) {
-                        const double c = rho[v];
-                        for (int dx = -1; dx < 2; dx++) {
-                            const int X = wrapi(x + dx, g.nx);
-                            for (int dy = -1; dy < 2; dy++) {
-                                const int Y = wrapi(y + dy, g.ny);
-                                for (int dz = -1; dz < 2; dz++) {
-                                    const int Z = wrapi(z + dz, g.nz);
-                                    if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 &&
-                                        rho[(X * g.ny + Y) * g.nz + Z] > c)
-                                        is_max = false;
-                                }
-                            }
-                        }
-                    }
-                    if (!is_max) {
-                        o = -2;
-                        if (x >= g.x0 && x < g.x1) { vidx[k] = v; cnt++; }
-                    }
-                }
-            }
-            out[k] = o;
-            known[v] = o;
-        }
-    }
-    int total;
-    const int off = block_scan_excl(cnt, total);
-    __shared__ int base_s;
-    if (threadIdx.x == 0) base_s = total ? atomicAdd(list_count, total) : 0;
-    __syncthreads();
-    int w = base_s + off;
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (vidx[k] >= 0) list[w++] = vidx[k];
-}
-
-// compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block
-__global__ __launch_bounds__(TPB) void k_compact_known16(GridL g, const int8_t *__restrict__ known, int value,
-                                                         int *__restrict__ list, int *count) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long base = vbeg + ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
-    int8_t b[16];
-    if (base + 16 <= vend && ((vbeg & 15) == 0)) {
-        *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(known + base);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) b[k] = (base + k < vend) ? known[base + k] : (int8_t)(value + 1);
-    }
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) cnt += (b[k] == value);
-    int total;
-    const int off = block_scan_excl(cnt, total);
-    __shared__ int base_s;
-    if (threadIdx.x == 0) base_s = total ? atomicAdd(count, total) : 0;
-    __syncthreads();
-    int w = base_s + off;
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (b[k] == value) list[w++] = (int)(base + k);
-}
-
-// known >= 0 with a `flag` voxel in the 27-box -> -1.  Used by edge_find (flag=-2) and edge_check
-// (flag=-3).  Reads test == flag only, writes only turn 0/2 into -1: safe in place.
-__global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int xa, int nplanes, int flag) {
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (vv >= (long long)nplanes * g.nyz) return;
-    const int xr = (int)(vv / g.nyz);
-    const int r = (int)(vv - (long long)xr * g.nyz);
-    int x = xa + xr;
-    if (x >= g.nx) x -= g.nx;
-    const int y = r / g.nz, z = r - y * g.nz;
-    const int v = lin3(g, x, y, z);
-    if (known[v] < 0) return;
-    bool near = false;
-#pragma unroll
-    for (int ix = -1; ix < 2; ix++) {
-        const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-        for (int iy = -1; iy < 2; iy++) {
-            const int ty = wrapi(y + iy, g.ny);
-#pragma unroll
-            for (int iz = -1; iz < 2; iz++) {
-                const int tz = wrapi(z + iz, g.nz);
-                near |= (known[lin3(g, tx, ty, tz)] == flag);
-            }
-        }
-    }
-    if (near) known[v] = -1;
-}
-
-// ---------------------------------------------------------------------------------------------
-// refinement.neargrid (refinement.py:17-322): retrace the listed edge voxels (known == -2).
-// Traces only read `known` for the == 2 test and `labels` at known==2 voxels / maxima, and only
-// write their own start voxel, so they are independent -- exactly as in the reference, where the
-// +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
-// ---------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
-                                                      int8_t *known, const int *__restrict__ list, int n,
-                                                      int *changed, int *escaped, int *ovf_list, int *ovf_count,
-                                                      int ovf_cap, int maxsteps) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    const bool valid = t < n;
-    const int v = valid ? list[t] : 0;
-    bool moving = false;
-    int result = -3;  // terminal voxel index; -2 overflow; -4 escaped
-    int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
-    double dr0 = 0., dr1 = 0., dr2 = 0.;
-    GradRec rec = {0., 0., 0., 0.};
-    PathWindow<K> w;
-    w.init(0, 0.);
-    if (valid) {
-        px = v / g.nyz;
-        const int r = v - px * g.nyz;
-        py = r / g.nz;
-        pz = r - py * g.nz;
-        lp = v;
-        rec = fetch_rec(G, v);
-        vol_num = labels[v];
-        w.init(v, rec.key);
-        moving = true;
-    }
-    while (__any(moving)) {
-        if (moving) {
-            const int bits = key_bits(rec.key);
-            const int code = bits & 63;
-            int qx, qy, qz, lq = 0;
-            bool og_move = (code == XB_STAY_CODE);
-            if (!og_move) {
-                ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
-                lq = lin3f(g, qx, qy, qz);
-                og_move = w.contains(lq);  // refinement.py:200
-            }
-            if (og_move) {  // refinement.py:201-235
-                const int og = (bits >> 6) & 31;
-                if (og == XB_OG_SELF) { result = lp; moving = false; }  // a maximum: refinement.py:283-292
-                else {
-                    int ox, oy, oz;
-                    og_offsets(og, ox, oy, oz);
-                    dr0 = dr1 = dr2 = 0.;
-                    qx = wrap_u(px + ox, g.nx); qy = wrap_u(py + oy, g.ny); qz = wrap_u(pz + oz, g.nz);
-                    lq = lin3f(g, qx, qy, qz);
-                }
-            }
-            if (moving) {
-                const bool in_win = plane_in_window(g, qx);
-                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
-                if (!plane_valid(g, qx)) { result = -4; moving = false; }
-                else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
-                else if (known[lq] == 2) { result = lq; moving = false; }  // refinement.py:294-303
-                else {
-                    w.push(lq, nr.key);
-                    px = qx; py = qy; pz = qz; lp = lq; rec = nr;
-                }
-            }
-        }
-    }
-    int ch = 0, es = 0;
-    if (valid) {
-        if (result >= 0) {
-            const int nv = labels[result];
-            if (nv != vol_num) { labels[v] = nv; known[v] = -2; ch = 1; }  // refinement.py:288-289
-            else known[v] = -1;                                             // refinement.py:291 (+5 +1 -5)
-        } else if (result == -2) {
-            const int k = atomicAdd(ovf_count, 1);
-            if (k < ovf_cap) ovf_list[k] = v;
-        } else if (result == -4) { known[v] = -6; es = 1; }  // left the valid slab: parked for the fallback
-    }
-    const unsigned long long bc = __ballot(ch), be = __ballot(es);
-    if (threadIdx.x % XB_WAVE == 0) {
-        if (bc) atomicAdd(changed, __popcll(bc));
-        if (be) atomicAdd(escaped, __popcll(be));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// refinement.edge_check (refinement.py:409-508).  The sequential scan re-classifies the 27-box of
-// every voxel that is still -2 when the scan reaches it; an earlier processed neighbour j < i
-// rewrites i to -1 / -3 unless i is an (edge & maximum) voxel, in which case i is processed too.
-// So the processed set P is the lexicographically-first greedy choice:
-//     i in P  <=>  class(i) == edge&max  or  no j in P with j < i, j in box(i).
-// P is resolved in rounds (a voxel decides once all earlier changed neighbours have decided);
-// the final `known` is then a pure function of P and the static classes.
-// temp codes in `known`: -2 undecided, -4 processed, -5 skipped.
-// ---------------------------------------------------------------------------------------------
-// One round: every still-undecided entry looks at its (at most 13) earlier neighbours.  Work
-// lists live on the device (`in` -> survivors appended to `out`), so rounds are queued
-// back-to-back without a host round trip; the host only polls the survivor count now and then.
-//   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
-//   an earlier neighbour is P -> skipped
-//   no earlier neighbour left undecided -> processed
-__global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
-                                                   const int *__restrict__ labels, int8_t *known,
-                                                   const int *__restrict__ list, int8_t *st,
-                                                   const int *__restrict__ in, const int *n_in, int *out,
-                                                   int *n_out, int first_round) {
-    const int n = *n_in;
-    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        const int t = first_round ? e : in[e];
-        const int v = list[t];
-        const int x = v / g.nyz;
-        const int r = v - x * g.nyz;
-        const int y = r / g.nz, z = r - y * g.nz;
-        bool blocked = false, has_proc = false;
-#pragma unroll
-        for (int ix = -1; ix < 2; ix++) {
-            const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-            for (int iy = -1; iy < 2; iy++) {
-                const int ty = wrapi(y + iy, g.ny);
-#pragma unroll
-                for (int iz = -1; iz < 2; iz++) {
-                    const int tz = wrapi(z + iz, g.nz);
-                    const int l = lin3(g, tx, ty, tz);
-                    if (l < v) {
-                        const int8_t k = __builtin_nontemporal_load(&known[l]);
-                        blocked |= (k == -2);
-                        has_proc |= (k == -4);
-                    }
-                }
-            }
-        }
-        int decision = 0;  // 0 wait, 1 processed, 2 skipped
-        if (!blocked && !has_proc) decision = 1;
-        else {
-            int8_t cls = st[t] >> 2;  // cached class: 1 = edge&max, 2 = other
-            if (cls == 0) {
-                bool is_edge, is_max;
-                classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-                cls = (is_edge && is_max) ? 1 : 2;
-            }
-            if (cls == 1) decision = 1;
-            else if (has_proc) decision = 2;
-            else st[t] = (int8_t)(cls << 2);  // still waiting: remember the class
-        }
-        if (decision) {
-            st[t] = (int8_t)decision;
-            known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
-        } else {
-            out[atomicAdd(n_out, 1)] = t;
-        }
-    }
-}
-// apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
-__global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
-                                                  const int *__restrict__ labels, int8_t *known,
-                                                  const int *__restrict__ list, int n, const int8_t *st,
-                                                  unsigned long long *checked) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n || st[t] != 1) return;
-    const int v = list[t];
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-    unsigned int nchk = 0;
-    for (int ex = -1; ex < 2; ex++) {
-        const int tx = wrapi(x + ex, g.nx);
-        for (int ey = -1; ey < 2; ey++) {
-            const int ty = wrapi(y + ey, g.ny);
-            for (int ez = -1; ez < 2; ez++) {
-                const int tz = wrapi(z + ez, g.nz);
-                const int l = lin3(g, tx, ty, tz);
-                // NB no vacuum test on the box voxel (bug-compatible)
-                bool is_edge, is_max;
-                classify27(g, rho, labels, tx, ty, tz, l, is_edge, is_max);
-                if (!is_edge) { known[l] = -1; nchk++; }
-                else if (!is_max) known[l] = -3;
-            }
-        }
-    }
-    if (nchk) atomicAdd(checked, (unsigned long long)nchk);
-}
-// restore processed edge&max voxels (untouched by their own box) to -2
-__global__ void k_ec_restore(int8_t *known, const int *list, int n) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int8_t k = known[list[t]];
-    if (k == -4 || k == -5) known[list[t]] = -2;
-}
-// count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread
-__global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges) {
-    const long long base = ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
-    unsigned int cnt = 0;
-    if (base + 16 <= N) {
-        uint4 w = *reinterpret_cast<const uint4 *>(known + base);
-        int8_t *b = reinterpret_cast<int8_t *>(&w);
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (b[k] == -3) { b[k] = -2; cnt++; }
-        if (cnt) *reinterpret_cast<uint4 *>(known + base) = w;
-    } else {
-        for (long long k = base; k < N; k++)
-            if (known[k] == -3) { known[k] = -2; cnt++; }
-    }
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if (threadIdx.x % XB_WAVE == 0 && cnt) atomicAdd(edges, (unsigned long long)cnt);
-}
-
-// ---------------------------------------------------------------------------------------------
-// utils.charge_sum (utils.py:235-252): per-label sums over the owned slab.  LDS-privatised bins
-// per block when the label count is small, global atomics otherwise.
-// ---------------------------------------------------------------------------------------------
-#define CS_BINS 1024
-__global__ __launch_bounds__(TPB) void k_charge_sum_lds(Grid g, const double *__restrict__ rho,
-                                                        const int *__restrict__ labels, int n_labels,
-                                                        double *charge, unsigned long long *count, int per_thread) {
-    __shared__ double sc[CS_BINS];
-    __shared__ unsigned int sn[CS_BINS];
-    for (int i = threadIdx.x; i < n_labels; i += TPB) { sc[i] = 0.; sn[i] = 0; }
-    __syncthreads();
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    long long v = vbeg + (long long)blockIdx.x * TPB * per_thread + threadIdx.x;
-    for (int k = 0; k < per_thread; k++, v += TPB) {
-        if (v < vend) {
-            const int a = labels[v];
-            if (a >= 0 && a < n_labels) { atomicAdd(&sc[a], rho[v]); atomicAdd(&sn[a], 1u); }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_labels; i += TPB)
-        if (sn[i]) { atomicAdd(&charge[i], sc[i]); atomicAdd(&count[i], (unsigned long long)sn[i]); }
-}
-__global__ __launch_bounds__(TPB) void k_charge_sum_glb(Grid g, const double *__restrict__ rho,
-                                                        const int *__restrict__ labels, int n_labels,
-                                                        double *charge, unsigned long long *count) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= vend) return;
-    const int a = labels[v];
-    if (a >= 0 && a < n_labels) { atomicAdd(&charge[a], rho[v]); atomicAdd(&count[a], 1ull); }
-}
-
-// utils.surface_dist (utils.py:320-379) over the edge list: squared minimum-image distance of every
-// edge voxel to the atom that owns it, reduced per atom with an integer atomicMin on the bit
-// pattern (non-negative doubles order like their bits), so the minimum is exact and order-free.
-__global__ __launch_bounds__(TPB) void k_surface_dist(GridL g, const int *__restrict__ labels,
-                                                      const int *__restrict__ list, int n,
-                                                      const double *__restrict__ lat, const double *__restrict__ atoms,
-                                                      int n_atoms, unsigned long long *min_d2) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n) return;
-    const int v = list[t];
-    const int a = labels[v];
-    if (a < 0 || a >= n_atoms) return;
-    const int p0 = v / g.nyz;
-    const int r = v - p0 * g.nyz;
-    const int p1 = r / g.nz, p2 = r - p1 * g.nz;
-    double pc[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {  // utils.py:357-359
-        pc[j] = lat[j] * (double)p0 / (double)g.nx;
-        pc[j] += lat[3 + j] * (double)p1 / (double)g.ny;
-        pc[j] += lat[6 + j] * (double)p2 / (double)g.nz;
-    }
-    double best = 1.7976931348623157e308;
-    for (int x = -1; x < 2; x++)
-        for (int y = -1; y < 2; y++)
-            for (int z = -1; z < 2; z++) {
-                double d2 = 0.;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {  // utils.py:369-374
-                    const double pbc = (lat[j] * (double)x + lat[3 + j] * (double)y) + lat[6 + j] * (double)z;
-                    const double e = pc[j] - (atoms[3 * a + j] + pbc);
-                    d2 = (j == 0) ? e * e : d2 + e * e;
-                }
-                if (d2 < best) best = d2;
-            }
-    atomicMin(&min_d2[a], (unsigned long long)__double_as_longlong(best));
-}
-// utils.volume_mask (utils.py:461-476)
-__global__ __launch_bounds__(TPB) void k_volume_mask(const double *__restrict__ rho, const int *__restrict__ labels,
-                                                     int vol_num, double *__restrict__ out, long long N) {
-    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v < N) out[v] = (labels[v] == vol_num) ? rho[v] : 0.;
-}
-// sum of rho and count over the owned voxels whose label equals `value` (vacuum sums with a
-// separate reference density, utils.py:396-400)
-__global__ __launch_bounds__(TPB) void k_label_sum(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
-                                                   int value, double *sum, unsigned long long *count) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    double s = 0.;
-    unsigned int n = 0;
-    if (v < vend && labels[v] == value) { s = rho[v]; n = 1; }
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); n += __shfl_down(n, o); }
-    if (threadIdx.x % XB_WAVE == 0 && n) { atomicAdd(sum, s); atomicAdd(count, (unsigned long long)n); }
-}
-
-// utils.volume_assign (utils.py:404-421)
-__global__ __launch_bounds__(TPB) void k_volume_assign(Grid g, int *labels, const int *__restrict__ swap, int n_swap) {
-    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= vend) return;
-    const int a = labels[v];
-    if (a >= 0 && a < n_swap) labels[v] = swap[a];
-}
-
-// utils.dtype_change (utils.py:255-259): widen / narrow between the boundary dtype and int32
-template <typename T>
-__global__ void k_widen(const T *__restrict__ in, int *__restrict__ out, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int)in[i];
-}
-template <typename T>
-__global__ void k_narrow(const int *__restrict__ in, T *__restrict__ out, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (T)in[i];
-}
+#include "k_common.h"
+#include "k_table.h"
+#include "k_trace.h"
+#include "k_ongrid.h"
+#include "k_edges.h"
+#include "k_sums.h"
 
 // =============================================================================================
 // host side

@@ -1,0 +1,104 @@
+// k_common.h -- device kernels of libbader_hip.so: shared helpers, workload generator, vacuum sweep, numbering notes.
+// Included by bader_hip.hip (one translation unit); see bader_kernels.h for the common device code.
+#pragma once
+
+#define TPB 256
+
+template <typename T>
+__global__ void k_fill(T *p, T v, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// Workload generator, bit-identical to pybader_amd/synth.py (IEEE basic ops, fixed order).
+__global__ __launch_bounds__(TPB) void k_synth_density(Grid g, const double *__restrict__ lat,
+                                                       const double *__restrict__ atoms, int n_atoms,
+                                                       double background, double *__restrict__ rho) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v >= N) return;
+    const int i = (int)(v / g.nyz);
+    const int r = (int)(v - (long long)i * g.nyz);
+    const int j = r / g.nz, k = r - j * g.nz;
+    const double f0 = (double)i / (double)g.nx, f1 = (double)j / (double)g.ny, f2 = (double)k / (double)g.nz;
+    double acc = background;
+    for (int a = 0; a < n_atoms; a++) {
+        const double *A = atoms + 5 * a;
+        double d0 = f0 - A[0]; d0 = d0 - rint(d0);
+        double d1 = f1 - A[1]; d1 = d1 - rint(d1);
+        double d2 = f2 - A[2]; d2 = d2 - rint(d2);
+        double r2 = 0.;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const double xm = (d0 * lat[m] + d1 * lat[3 + m]) + d2 * lat[6 + m];
+            const double sq = xm * xm;
+            r2 = (m == 0) ? sq : (r2 + sq);
+        }
+        double t = 1.0 - r2 / ((2048.0 * A[3]) * A[3]);
+        if (!(t > 0.0)) t = 0.0;
+#pragma unroll
+        for (int s = 0; s < 10; s++) t = t * t;
+        acc = acc + A[4] * t;
+    }
+    rho[v] = acc;
+}
+
+// utils.vacuum_assign (utils.py:382-401): labels = -1 where rho <= tol, 0 elsewhere, over the
+// whole grid; charge/volume partial sums over the owned slab only (block reduce + one atomic).
+__global__ __launch_bounds__(TPB) void k_vacuum_assign(Grid g, const double *__restrict__ rho,
+                                                       int *__restrict__ labels, double tol, double *sum_rho,
+                                                       unsigned long long *count) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long v = (long long)blockIdx.x * TPB + threadIdx.x;
+    double s = 0.;
+    unsigned int n = 0;
+    if (v < N) {
+        const double r = rho[v];
+        const bool vac = r <= tol;  // NaN tol (vacuum_tol=None, interface.py:459) => never
+        labels[v] = vac ? -1 : 0;
+        const int x = (int)(v / g.nyz);
+        if (vac && x >= g.x0 && x < g.x1) { s = r; n = 1; }
+    }
+    __shared__ double sh[TPB / XB_WAVE];
+    __shared__ unsigned int shn[TPB / XB_WAVE];
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); n += __shfl_down(n, o); }
+    const int w = threadIdx.x / XB_WAVE, l = threadIdx.x % XB_WAVE;
+    if (l == 0) { sh[w] = s; shn[w] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.;
+        unsigned int m = 0;
+        for (int q = 0; q < TPB / XB_WAVE; q++) { t += sh[q]; m += shn[q]; }
+        if (m) { atomicAdd(sum_rho, t); atomicAdd(count, (unsigned long long)m); }
+    }
+}
+
+// Record a trajectory's maximum `m` for the numbering: first[m] = min owned voxel index reaching m;
+// the thread that lowers first[m] from INT_MAX appends m to the maxima list (exactly one does).
+__device__ __forceinline__ void note_maximum(int m, int v, int *first, int *max_list, int *max_count, int max_cap) {
+    if (__builtin_nontemporal_load(&first[m]) <= v) return;  // already at or below v: nothing to do
+    const int old = atomicMin(&first[m], v);
+    if (old == XB_INT_MAX) {
+        const int k = atomicAdd(max_count, 1);
+        if (k < max_cap) max_list[k] = m;
+    }
+}
+
+// Wave-aggregated note_maximum: per distinct maximum in the wave, one lane reports the smallest
+// voxel index of the lanes that reached it.
+__device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *first, int *max_list,
+                                                  int *max_count, int max_cap) {
+    unsigned long long todo = __ballot(has);
+    const int lane = threadIdx.x % XB_WAVE;
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const int lm = __shfl(m, leader);
+        const bool mine = has && m == lm;
+        int vmin = mine ? v : XB_INT_MAX;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmin = min(vmin, __shfl_xor(vmin, o));
+        if (lane == leader) note_maximum(lm, vmin, first, max_list, max_count, max_cap);
+        todo &= ~__ballot(mine);
+    }
+}

@@ -1,0 +1,543 @@
+// k_edges.h -- device kernels of libbader_hip.so: refinement: edge_find, dilation, compaction, retrace, edge_check.
+// Included by bader_hip.hip (one translation unit); see bader_kernels.h for the common device code.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// refinement.edge_find (refinement.py:326-405) on a fresh `known`, as two order-free passes.
+// Pass 1 (planes [x0-1, x1+1)): -2 if a non-vacuum neighbour carries another label and the voxel
+// is not a 26-neighbour density maximum; else 2 (non-vacuum) / 0 (vacuum).
+// Pass 2 (owned planes): voxels >= 0 with an edge in their 27-box become -1 (refinement.py:403-404,
+// which has no vacuum test).  Together these equal the sequential in-place sweep.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void classify27(const Grid &g, const double *__restrict__ rho,
+                                           const int *__restrict__ labels, int x, int y, int z, int v,
+                                           bool &is_edge, bool &is_max) {
+    const int vol_num = labels[v];
+    is_edge = false;
+    is_max = true;
+    int nb[27];
+    int k = 0;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int tz = wrapi(z + iz, g.nz);
+                const int l = lin3(g, tx, ty, tz);
+                const int nv = labels[l];
+                nb[k++] = (nv == -1) ? -1 : l;
+                if (nv != -1 && nv != vol_num) is_edge = true;
+            }
+        }
+    }
+    if (!is_edge) return;  // is_max only matters for edges (refinement.py:376-383)
+    const double max_val = rho[v];
+#pragma unroll
+    for (k = 0; k < 27; k++)
+        if (nb[k] >= 0 && rho[nb[k]] > max_val) is_max = false;
+}
+
+// Block-wide exclusive scan of a small per-thread count (TPB threads); returns the offset of this
+// thread and the block total.
+__device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
+    __shared__ int wsum[TPB / XB_WAVE];
+    const int lane = threadIdx.x % XB_WAVE, w = threadIdx.x / XB_WAVE;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < XB_WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == XB_WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int q = 0; q < TPB / XB_WAVE; q++) {
+        if (q < w) base += wsum[q];
+        total += wsum[q];
+    }
+    __syncthreads();
+    return base + incl - cnt;
+}
+
+// buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
+// Lets the edge sweep skip tiles whose whole 3x3x3 surroundings carry one label (no edge possible).
+#define XB_MIXED (-2147483647 - 1)
+__global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__restrict__ labels, int nb1, int nb2,
+                                                       int *__restrict__ buni) {
+    __shared__ int s_min, s_max;
+    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int lo = 2147483647, hi = XB_MIXED;
+    for (int t = threadIdx.x; t < 512; t += TPB) {
+        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
+        lo = min(lo, l); hi = max(hi, l);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    __syncthreads();
+    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
+}
+// After an assignment without vacuum every certain brick is uniform by construction (all its voxels
+// carry the rank of the region's maximum): only the bricks of the walk list need the label scan.
+__global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
+                                    const int *__restrict__ rank, int *__restrict__ buni) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbr) return;
+    const int l = blab[b];
+    if (l > 0) buni[b] = rank[box_max[l - 1]];
+}
+__global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *__restrict__ labels, int nb1, int nb2,
+                                                            const int *__restrict__ walk, int n_walk,
+                                                            int *__restrict__ buni) {
+    __shared__ int s_min, s_max;
+    if ((int)blockIdx.x >= n_walk) return;
+    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
+    __syncthreads();
+    const int b = walk[blockIdx.x];
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int lo = 2147483647, hi = XB_MIXED;
+    for (int t = threadIdx.x; t < 512; t += TPB) {
+        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
+        lo = min(lo, l); hi = max(hi, l);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    __syncthreads();
+    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
+}
+
+// refinement.py:385-404 as written there: every listed edge voxel turns the known >= 0 voxels of
+// its 27-box into -1 (all -2 flags are final before this kernel starts).
+__global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known, const int *__restrict__ list, int n) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int l = (tx * g.ny + ty) * g.nz + wrapi(z + iz, g.nz);
+                if (known[l] >= 0) known[l] = -1;
+            }
+        }
+    }
+}
+
+// LDS-tiled edge_find pass 1: a block stages the labels of a 4x8x64 tile plus a one-voxel periodic
+// halo (6x10x66 ints) in LDS, every thread classifies 8 voxels from the staged 3x3x3
+// neighbourhoods, and the block appends its owned edge voxels to the edge list with ONE atomic
+// (the list length is the edge count edge_find returns).  rho is only read for the few voxels
+// that have a foreign neighbour (the is_max test, refinement.py:374-375).
+#define ET_X 4
+#define ET_Y 8
+#define ET_Z 64
+__global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *__restrict__ rho,
+                                                         const int *__restrict__ labels,
+                                                         int8_t *__restrict__ known, int xa, int nplanes,
+                                                         int *__restrict__ list, int *list_count, int small,
+                                                         const int *__restrict__ buni,
+                                                         const GradRec *__restrict__ G) {
+    __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
+    const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
+    if (buni) {
+        // every brick that meets the tile or its one-voxel halo carries the same single label: no
+        // voxel of the tile has a foreign neighbour (2 x 3 x 10 bricks, one lookup per thread)
+        __shared__ int s_lab, s_mixed;
+        if (threadIdx.x == 0) { s_lab = XB_MIXED; s_mixed = 0; }
+        __syncthreads();
+        const int nb0 = g.nx >> 3, nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        const int bx_lo = (xa + tx0 - 1) >> 3, bx_n = ((xa + tx0 + ET_X) >> 3) - bx_lo + 1;  // arithmetic shift: -1 >> 3 == -1
+        const int by_lo = (y0 - 1) >> 3, by_n = ((y0 + ET_Y) >> 3) - by_lo + 1;
+        const int bz_lo = (z0 - 1) >> 3, bz_n = ((z0 + ET_Z) >> 3) - bz_lo + 1;
+        for (int t = threadIdx.x; t < bx_n * by_n * bz_n; t += TPB) {
+            const int q0 = wrap_any(bx_lo + t / (by_n * bz_n), nb0), q1 = wrap_any(by_lo + (t / bz_n) % by_n, nb1),
+                      q2 = wrap_any(bz_lo + t % bz_n, nb2);
+            const int l = buni[(q0 * nb1 + q1) * nb2 + q2];
+            if (l == XB_MIXED) s_mixed = 1;
+            else {
+                const int old = atomicCAS(&s_lab, XB_MIXED, l);
+                if (old != XB_MIXED && old != l) s_mixed = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_mixed) {
+            const int8_t o = (s_lab == -1) ? 0 : 2;  // vacuum stays 0 (refinement.py:342-343), else "known"
+            const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int xr = tx0 + (k >> 1), y = y0 + tyb + ((k & 1) << 2), z = z0 + tz;
+                if (xr < nplanes && y < g.ny && z < g.nz) {
+                    int x = xa + xr;
+                    if (x >= g.nx) x -= g.nx;
+                    known[(x * g.ny + y) * g.nz + z] = o;
+                }
+            }
+            return;
+        }
+    }
+    for (int i = threadIdx.x; i < (ET_X + 2) * (ET_Y + 2) * (ET_Z + 2); i += TPB) {
+        const int ez = i % (ET_Z + 2);
+        const int r = i / (ET_Z + 2);
+        const int ey = r % (ET_Y + 2), ex = r / (ET_Y + 2);
+        int X = xa + tx0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
+        if (small) {
+            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
+        } else {
+            X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+        }
+        tile[ex][ey][ez] = labels[(X * g.ny + Y) * g.nz + Z];
+    }
+    __syncthreads();
+    const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+    int8_t out[8];
+    int vidx[8];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+        const int xr = tx0 + tx, y = y0 + ty, z = z0 + tz;
+        out[k] = 1;  // 1 = outside the grid / the plane range: nothing to store
+        vidx[k] = -1;
+        if (xr < nplanes && y < g.ny && z < g.nz) {
+            int x = xa + xr;
+            if (x >= g.nx) x -= g.nx;
+            const int v = (x * g.ny + y) * g.nz + z;
+            const int lab = tile[tx + 1][ty + 1][tz + 1];
+            int8_t o = 0;  // vacuum voxels are not classified (refinement.py:342-343)
+            if (lab != -1) {
+                bool is_edge = false;
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                        for (int dz = 0; dz < 3; dz++) {
+                            const int nv = tile[tx + dx][ty + dy][tz + dz];
+                            is_edge |= (nv != -1) & (nv != lab);
+                        }
+                o = 2;
+                if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
+                    bool is_max = true, decided = false;
+                    if (G) {
+                        // the table knows the best distance-weighted neighbour of v; if there is one
+                        // (and it is not vacuum) that neighbour is denser than v: not a maximum.
+                        // (weighted > rho(v) implies rho(n) > rho(v); the converse can fail by
+                        // rounding, so "no such neighbour" still takes the full test)
+                        const int og = key_og(G[v].key);
+                        if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
+                            is_max = false;
+                            decided = true;
+                        }
+                    }
+                    if (!decided) {
+                        const double c = rho[v];
+                        for (int dx = -1; dx < 2; dx++) {
+                            const int X = wrapi(x + dx, g.nx);
+                            for (int dy = -1; dy < 2; dy++) {
+                                const int Y = wrapi(y + dy, g.ny);
+                                for (int dz = -1; dz < 2; dz++) {
+                                    const int Z = wrapi(z + dz, g.nz);
+                                    if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 &&
+                                        rho[(X * g.ny + Y) * g.nz + Z] > c)
+                                        is_max = false;
+                                }
+                            }
+                        }
+                    }
+                    if (!is_max) {
+                        o = -2;
+                        if (x >= g.x0 && x < g.x1) { vidx[k] = v; cnt++; }
+                    }
+                }
+            }
+            out[k] = o;
+            known[v] = o;
+        }
+    }
+    int total;
+    const int off = block_scan_excl(cnt, total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(list_count, total) : 0;
+    __syncthreads();
+    int w = base_s + off;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (vidx[k] >= 0) list[w++] = vidx[k];
+}
+
+// compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block
+__global__ __launch_bounds__(TPB) void k_compact_known16(GridL g, const int8_t *__restrict__ known, int value,
+                                                         int *__restrict__ list, int *count) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long base = vbeg + ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
+    int8_t b[16];
+    if (base + 16 <= vend && ((vbeg & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(known + base);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = (base + k < vend) ? known[base + k] : (int8_t)(value + 1);
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cnt += (b[k] == value);
+    int total;
+    const int off = block_scan_excl(cnt, total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(count, total) : 0;
+    __syncthreads();
+    int w = base_s + off;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (b[k] == value) list[w++] = (int)(base + k);
+}
+
+// known >= 0 with a `flag` voxel in the 27-box -> -1.  Used by edge_find (flag=-2) and edge_check
+// (flag=-3).  Reads test == flag only, writes only turn 0/2 into -1: safe in place.
+__global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int xa, int nplanes, int flag) {
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= (long long)nplanes * g.nyz) return;
+    const int xr = (int)(vv / g.nyz);
+    const int r = (int)(vv - (long long)xr * g.nyz);
+    int x = xa + xr;
+    if (x >= g.nx) x -= g.nx;
+    const int y = r / g.nz, z = r - y * g.nz;
+    const int v = lin3(g, x, y, z);
+    if (known[v] < 0) return;
+    bool near = false;
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int tz = wrapi(z + iz, g.nz);
+                near |= (known[lin3(g, tx, ty, tz)] == flag);
+            }
+        }
+    }
+    if (near) known[v] = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement.neargrid (refinement.py:17-322): retrace the listed edge voxels (known == -2).
+// Traces only read `known` for the == 2 test and `labels` at known==2 voxels / maxima, and only
+// write their own start voxel, so they are independent -- exactly as in the reference, where the
+// +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
+                                                      int8_t *known, const int *__restrict__ list, int n,
+                                                      int *changed, int *escaped, int *ovf_list, int *ovf_count,
+                                                      int ovf_cap, int maxsteps) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    const bool valid = t < n;
+    const int v = valid ? list[t] : 0;
+    bool moving = false;
+    int result = -3;  // terminal voxel index; -2 overflow; -4 escaped
+    int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
+    double dr0 = 0., dr1 = 0., dr2 = 0.;
+    GradRec rec = {0., 0., 0., 0.};
+    PathWindow<K> w;
+    w.init(0, 0.);
+    if (valid) {
+        px = v / g.nyz;
+        const int r = v - px * g.nyz;
+        py = r / g.nz;
+        pz = r - py * g.nz;
+        lp = v;
+        rec = fetch_rec(G, v);
+        vol_num = labels[v];
+        w.init(v, rec.key);
+        moving = true;
+    }
+    while (__any(moving)) {
+        if (moving) {
+            const int bits = key_bits(rec.key);
+            const int code = bits & 63;
+            int qx, qy, qz, lq = 0;
+            bool og_move = (code == XB_STAY_CODE);
+            if (!og_move) {
+                ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
+                lq = lin3f(g, qx, qy, qz);
+                og_move = w.contains(lq);  // refinement.py:200
+            }
+            if (og_move) {  // refinement.py:201-235
+                const int og = (bits >> 6) & 31;
+                if (og == XB_OG_SELF) { result = lp; moving = false; }  // a maximum: refinement.py:283-292
+                else {
+                    int ox, oy, oz;
+                    og_offsets(og, ox, oy, oz);
+                    dr0 = dr1 = dr2 = 0.;
+                    qx = wrap_u(px + ox, g.nx); qy = wrap_u(py + oy, g.ny); qz = wrap_u(pz + oz, g.nz);
+                    lq = lin3f(g, qx, qy, qz);
+                }
+            }
+            if (moving) {
+                const bool in_win = plane_in_window(g, qx);
+                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                if (!plane_valid(g, qx)) { result = -4; moving = false; }
+                else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
+                else if (known[lq] == 2) { result = lq; moving = false; }  // refinement.py:294-303
+                else {
+                    w.push(lq, nr.key);
+                    px = qx; py = qy; pz = qz; lp = lq; rec = nr;
+                }
+            }
+        }
+    }
+    int ch = 0, es = 0;
+    if (valid) {
+        if (result >= 0) {
+            const int nv = labels[result];
+            if (nv != vol_num) { labels[v] = nv; known[v] = -2; ch = 1; }  // refinement.py:288-289
+            else known[v] = -1;                                             // refinement.py:291 (+5 +1 -5)
+        } else if (result == -2) {
+            const int k = atomicAdd(ovf_count, 1);
+            if (k < ovf_cap) ovf_list[k] = v;
+        } else if (result == -4) { known[v] = -6; es = 1; }  // left the valid slab: parked for the fallback
+    }
+    const unsigned long long bc = __ballot(ch), be = __ballot(es);
+    if (threadIdx.x % XB_WAVE == 0) {
+        if (bc) atomicAdd(changed, __popcll(bc));
+        if (be) atomicAdd(escaped, __popcll(be));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement.edge_check (refinement.py:409-508).  The sequential scan re-classifies the 27-box of
+// every voxel that is still -2 when the scan reaches it; an earlier processed neighbour j < i
+// rewrites i to -1 / -3 unless i is an (edge & maximum) voxel, in which case i is processed too.
+// So the processed set P is the lexicographically-first greedy choice:
+//     i in P  <=>  class(i) == edge&max  or  no j in P with j < i, j in box(i).
+// P is resolved in rounds (a voxel decides once all earlier changed neighbours have decided);
+// the final `known` is then a pure function of P and the static classes.
+// temp codes in `known`: -2 undecided, -4 processed, -5 skipped.
+// ---------------------------------------------------------------------------------------------
+// One round: every still-undecided entry looks at its (at most 13) earlier neighbours.  Work
+// lists live on the device (`in` -> survivors appended to `out`), so rounds are queued
+// back-to-back without a host round trip; the host only polls the survivor count now and then.
+//   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
+//   an earlier neighbour is P -> skipped
+//   no earlier neighbour left undecided -> processed
+__global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
+                                                   const int *__restrict__ labels, int8_t *known,
+                                                   const int *__restrict__ list, int8_t *st,
+                                                   const int *__restrict__ in, const int *n_in, int *out,
+                                                   int *n_out, int first_round) {
+    const int n = *n_in;
+    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        const int t = first_round ? e : in[e];
+        const int v = list[t];
+        const int x = v / g.nyz;
+        const int r = v - x * g.nyz;
+        const int y = r / g.nz, z = r - y * g.nz;
+        bool blocked = false, has_proc = false;
+#pragma unroll
+        for (int ix = -1; ix < 2; ix++) {
+            const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+            for (int iy = -1; iy < 2; iy++) {
+                const int ty = wrapi(y + iy, g.ny);
+#pragma unroll
+                for (int iz = -1; iz < 2; iz++) {
+                    const int tz = wrapi(z + iz, g.nz);
+                    const int l = lin3(g, tx, ty, tz);
+                    if (l < v) {
+                        const int8_t k = __builtin_nontemporal_load(&known[l]);
+                        blocked |= (k == -2);
+                        has_proc |= (k == -4);
+                    }
+                }
+            }
+        }
+        int decision = 0;  // 0 wait, 1 processed, 2 skipped
+        if (!blocked && !has_proc) decision = 1;
+        else {
+            int8_t cls = st[t] >> 2;  // cached class: 1 = edge&max, 2 = other
+            if (cls == 0) {
+                bool is_edge, is_max;
+                classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+                cls = (is_edge && is_max) ? 1 : 2;
+            }
+            if (cls == 1) decision = 1;
+            else if (has_proc) decision = 2;
+            else st[t] = (int8_t)(cls << 2);  // still waiting: remember the class
+        }
+        if (decision) {
+            st[t] = (int8_t)decision;
+            known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
+        } else {
+            out[atomicAdd(n_out, 1)] = t;
+        }
+    }
+}
+// apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
+__global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
+                                                  const int *__restrict__ labels, int8_t *known,
+                                                  const int *__restrict__ list, int n, const int8_t *st,
+                                                  unsigned long long *checked) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n || st[t] != 1) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    unsigned int nchk = 0;
+    for (int ex = -1; ex < 2; ex++) {
+        const int tx = wrapi(x + ex, g.nx);
+        for (int ey = -1; ey < 2; ey++) {
+            const int ty = wrapi(y + ey, g.ny);
+            for (int ez = -1; ez < 2; ez++) {
+                const int tz = wrapi(z + ez, g.nz);
+                const int l = lin3(g, tx, ty, tz);
+                // NB no vacuum test on the box voxel (bug-compatible)
+                bool is_edge, is_max;
+                classify27(g, rho, labels, tx, ty, tz, l, is_edge, is_max);
+                if (!is_edge) { known[l] = -1; nchk++; }
+                else if (!is_max) known[l] = -3;
+            }
+        }
+    }
+    if (nchk) atomicAdd(checked, (unsigned long long)nchk);
+}
+// restore processed edge&max voxels (untouched by their own box) to -2
+__global__ void k_ec_restore(int8_t *known, const int *list, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int8_t k = known[list[t]];
+    if (k == -4 || k == -5) known[list[t]] = -2;
+}
+// count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread
+__global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges) {
+    const long long base = ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
+    unsigned int cnt = 0;
+    if (base + 16 <= N) {
+        uint4 w = *reinterpret_cast<const uint4 *>(known + base);
+        int8_t *b = reinterpret_cast<int8_t *>(&w);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (b[k] == -3) { b[k] = -2; cnt++; }
+        if (cnt) *reinterpret_cast<uint4 *>(known + base) = w;
+    } else {
+        for (long long k = base; k < N; k++)
+            if (known[k] == -3) { known[k] = -2; cnt++; }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (threadIdx.x % XB_WAVE == 0 && cnt) atomicAdd(edges, (unsigned long long)cnt);
+}

@@ -1,0 +1,71 @@
+// k_ongrid.h -- device kernels of libbader_hip.so: ongrid assignment (pointer + jumping), numbering and relabel helpers.
+// Included by bader_hip.hip (one translation unit); see bader_kernels.h for the common device code.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// ongrid assignment (methods.py:15-219).  The ascent is memoryless, so the sequential path
+// compression of the reference equals: best-neighbour pointer per voxel, then pointer jumping.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_og_pointer(Grid g, const double *__restrict__ rho, int *labels) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= N) return;
+    const int v = (int)vv;
+    if (labels[v] == -1) return;  // vacuum stays -1 (methods.py:73-74)
+    const int px = v / g.nyz;
+    const int r = v - px * g.nyz;
+    const int py = r / g.nz, pz = r - py * g.nz;
+    int qx, qy, qz;
+    og_step(rho, g, g.dist, px, py, pz, rho[v], qx, qy, qz);
+    labels[v] = lin3(g, qx, qy, qz);
+}
+// A chain that steps onto a vacuum voxel inherits -1 (methods.py:166-168).  In-place and
+// asynchronous: any value read is an ancestor of the root, so progress is monotone.
+__global__ __launch_bounds__(TPB) void k_og_jump(Grid g, int *labels, int *not_done) {
+    const long long N = (long long)g.nx * g.nyz;
+    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (vv >= N) return;
+    const int v = (int)vv;
+    int p = labels[v];
+    if (p < 0 || p == v) return;
+    int q = labels[p];
+    if (q == p) return;  // parent is a root
+    if (q >= 0) {
+        const int q2 = labels[q];  // two hops per sweep
+        if (q2 >= 0) q = q2;
+        else q = -1;
+    }
+    labels[v] = q;
+    if (q >= 0) *not_done = 1;
+}
+__global__ __launch_bounds__(TPB) void k_note_roots(Grid g, const int *labels, int *first, int *max_list,
+                                                    int *max_count, int max_cap) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long vv = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    const bool valid = vv < vend;
+    const int v = valid ? (int)vv : 0;
+    const int m = valid ? labels[v] : -1;
+    note_maximum_wave(valid && m >= 0, m, v, first, max_list, max_count, max_cap);
+}
+
+// numbering helpers ---------------------------------------------------------------------------
+__global__ void k_gather_first(const int *first, const int *max_list, int n, int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = first[max_list[i]];
+}
+__global__ void k_set_rank(int *first, const int *max_sorted, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) first[max_sorted[i]] = i;
+}
+__global__ void k_reset_first(int *first, const int *max_list, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) first[max_list[i]] = XB_INT_MAX;
+}
+// labels[v] (maximum index) -> rank stored in first[maximum]
+__global__ __launch_bounds__(TPB) void k_relabel(Grid g, int *labels, const int *__restrict__ rank) {
+    const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
+    const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
+    if (v >= vend) return;
+    const int m = labels[v];
+    if (m >= 0) labels[v] = rank[m];
+}

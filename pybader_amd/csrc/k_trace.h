@@ -1,0 +1,242 @@
+// k_trace.h -- device kernels of libbader_hip.so: neargrid assignment: region fill, walker trace, exact slow path.
+// Included by bader_hip.hip (one translation unit); see bader_kernels.h for the common device code.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// neargrid assignment: every owned non-vacuum voxel follows its own dr=0 trajectory
+// (refinement.py:17-322 stepping rules without the early stop) to the maximum it reaches.
+// One lane per voxel, lanes along z (coalesced first loads).  labels: in 0/-1, out = linear index
+// of the maximum (-1 vacuum, -2 = handed to the exact slow kernel).
+// ---------------------------------------------------------------------------------------------
+// Voxels inside a trapping region end at its maximum: fill their labels in one streaming sweep
+// (vacuum voxels keep -1; a region whose maximum is vacuum hands out -1, refinement.py:286) and note
+// the maxima for the numbering.  The uncertain bricks go to the work list of k_ng_trace.
+__global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__restrict__ blab, int nb1, int nb2,
+                                                      const int *__restrict__ box_max, int *labels, int *first,
+                                                      int *max_list, int *max_count, int max_cap) {
+    const int vbeg = g.x0 * g.nyz, vend = g.x1 * g.nyz;
+    const int v = vbeg + blockIdx.x * TPB + threadIdx.x;
+    const bool in = v < vend;
+    int result = -1;
+    bool has = false;
+    if (in) {
+        const int x = v / g.nyz;
+        const int r = v - x * g.nyz;
+        const int y = r / g.nz, z = r - y * g.nz;
+        const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
+        if (b > 0 && labels[v] != -1) {
+            result = box_max[b - 1];
+            if (result != v && labels[result] == -1) result = -1;
+            labels[v] = result;
+            has = result >= 0;
+        }
+    }
+    note_maximum_wave(has, result, in ? v : 0, first, max_list, max_count, max_cap);
+}
+// Without vacuum every voxel of a certain brick belongs to its maximum and the smallest voxel
+// index of a brick is its corner: the numbering needs one note per owned certain brick, and the
+// labels themselves are written by k_relabel_regions after the trace.
+__global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_lo, int b_hi,
+                                      const int *__restrict__ blab, const int *__restrict__ box_max, int *first,
+                                      int *max_list, int *max_count, int max_cap) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = (b < nb0 * nb1 * nb2 && b >= b_lo && b < b_hi) ? blab[b] : 0;
+    const bool has = l > 0;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    // one atomic per distinct maximum per wave (a handful of maxima own all the bricks)
+    note_maximum_wave(has, has ? box_max[l - 1] : 0, ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list,
+                      max_count, max_cap);
+}
+// labels := rank of the maximum; voxels of certain bricks take it from the brick label, the others
+// from the maximum index the trace left in `labels`
+__global__ __launch_bounds__(TPB) void k_relabel_regions(GridL g, int *labels, const int *__restrict__ rank,
+                                                         const int *__restrict__ blab, int nb1, int nb2,
+                                                         const int *__restrict__ box_max) {
+    const int v = g.x0 * g.nyz + blockIdx.x * TPB + threadIdx.x;
+    if (v >= g.x1 * g.nyz) return;
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
+    if (b > 0) labels[v] = rank[box_max[b - 1]];
+    else {
+        const int m = labels[v];
+        if (m >= 0) labels[v] = rank[m];
+    }
+}
+__global__ void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab, int *walk, int *n_walk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;   // bricks [b_lo, b_hi) are the owned slab
+    const bool hit = b < nbr && b >= b_lo && b < b_hi && blab[b] <= 0;
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    const int lane = threadIdx.x % XB_WAVE;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(n_walk, __popcll(m));
+    base = __shfl(base, 0);
+    if (hit) walk[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+
+__device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
+    ox = og / 9 - 1; oy = (og / 3) % 3 - 1; oz = og % 3 - 1;
+}
+
+template <int K>
+__global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
+                                                  const int *__restrict__ box_max, const int *__restrict__ blab,
+                                                  int nb1, int nb2, const int *__restrict__ walk, int n_walk,
+                                                  int *labels, int *first,
+                                                  int *max_list, int *max_count, int max_cap, int *ovf_list,
+                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt) {
+    // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
+    // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
+    // whose trajectories read the same table lines -- share one L2.
+    int blk = blockIdx.x;
+    if (opt & 2) {
+        const int per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
+    }
+    const int wpb = blockDim.x / XB_WAVE;  // waves per block (launch-time choice)
+    const int wave = blk * wpb + threadIdx.x / XB_WAVE;
+    const int lane = threadIdx.x % XB_WAVE;
+    int sx, sy, sz;
+    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (4x4x4 each) per brick
+        if ((wave >> 3) >= n_walk) return;
+        const int b = walk[wave >> 3], sub = wave & 7;
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        sx = b0 * 8 + ((sub >> 2) << 2) + (lane >> 4);
+        sy = b1 * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
+        sz = b2 * 8 + ((sub & 1) << 2) + (lane & 3);
+        if (sx < g.x0 || sx >= g.x1) return;  // whole wave: 4 planes of one brick half, slab edges are brick aligned or not owned
+    } else if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
+        const int bz_n = (g.nz + 3) >> 2, by_n = (g.ny + 3) >> 2;
+        const int bx = wave / (by_n * bz_n);
+        const int brem = wave - bx * (by_n * bz_n);
+        const int by = brem / bz_n, bz = brem - by * bz_n;
+        sx = g.x0 + bx * 4 + (lane >> 4); sy = by * 4 + ((lane >> 2) & 3); sz = bz * 4 + (lane & 3);
+    } else {        // one wave = a run of 64 voxels along z
+        const int rz_n = (g.nz + 63) >> 6;
+        const int row = wave / rz_n;
+        sz = (wave - row * rz_n) * 64 + lane;
+        sx = g.x0 + row / g.ny;
+        sy = row - (row / g.ny) * g.ny;
+    }
+    const bool valid = sx < g.x1 && sy < g.ny && sz < g.nz;
+    const int v = valid ? (sx * g.ny + sy) * g.nz + sz : 0;
+    bool moving = false;
+    int result = -1;
+    int px = 0, py = 0, pz = 0, lp = 0, steps = 0;
+    double dr0 = 0., dr1 = 0., dr2 = 0.;
+    GradRec rec = {0., 0., 0., 0.};
+    PathWindow<K> w;
+    w.init(0, 0.);
+    if (valid && labels[v] != -1) {
+        px = sx; py = sy; pz = sz;
+        lp = v;
+        // trapping regions: brick labels (grids made of whole 8^3 bricks) or box ids in the keys
+        int b = blab ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
+        if (b <= 0) {
+            rec = fetch_rec(G, v);
+            b = key_box(rec.key);
+        }
+        if (b > 0) result = box_max[b - 1];  // starts inside a trapping region: ends at its maximum
+        else { w.init(v, rec.key); moving = true; }
+    }
+    while (__any(moving)) {
+        if (moving) {
+            const int bits = key_bits(rec.key);
+            const int code = bits & 63;
+            int qx, qy, qz, lq = 0;
+            // refinement.py:132-154: the gradient move (if the voxel has one)
+            bool og_move = (code == XB_STAY_CODE);
+            if (!og_move) {
+                ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
+                lq = lin3f(g, qx, qy, qz);
+                og_move = w.contains(lq);  // refinement.py:200: already been here on this path
+            }
+            if (og_move) {  // refinement.py:201-235: dr = 0 and one ongrid step from p (tabulated)
+                const int og = (bits >> 6) & 31;
+                if (og == XB_OG_SELF) { result = lp; moving = false; }  // break_flag: p is the maximum
+                else {
+                    int ox, oy, oz;
+                    og_offsets(og, ox, oy, oz);
+                    dr0 = dr1 = dr2 = 0.;
+                    qx = wrap_u(px + ox, g.nx); qy = wrap_u(py + oy, g.ny); qz = wrap_u(pz + oz, g.nz);
+                    lq = lin3f(g, qx, qy, qz);
+                }
+            }
+            if (moving) {
+                const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
+                const bool in_win = plane_in_window(g, qx);  // the table only exists inside the window (slabs)
+                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                const int b = bl > 0 ? bl : (in_win ? key_box(nr.key) : 0);
+                if (b) {  // arrived inside a trapping region (q cannot be an old path voxel: the
+                    result = box_max[b - 1];  // trajectory would have stopped there already)
+                    moving = false;
+                } else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
+                    result = -2;  // left the table window / membership undecidable: exact slow kernel
+                    moving = false;  // (ongrid moves are appended without a membership test, 305-315)
+                } else {
+                    w.push(lq, nr.key);
+                    px = qx; py = qy; pz = qz; lp = lq; rec = nr;
+                }
+            }
+        }
+    }
+    // a maximum that is itself vacuum hands its -1 to the start voxel (refinement.py:286)
+    if (valid && result >= 0 && result != v && labels[result] == -1) result = -1;
+    if (valid) labels[v] = result;
+    note_maximum_wave(valid && result >= 0, result, v, first, max_list, max_count, max_cap);
+    if (valid && result == -2) {
+        const int k = atomicAdd(ovf_count, 1);
+        if (k < ovf_cap) ovf_list[k] = v;
+    }
+}
+
+// Exact slow path for the (rare) trajectories whose path membership could not be decided from the
+// window: the whole path lives in global scratch and is scanned linearly.
+// mode 0: assignment (write maximum index, note it); mode 1: refinement retrace.
+__global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
+                             int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
+                             int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    int *P = path + (size_t)t * lmax;
+    int np = 0;
+    int px = v / g.nyz;
+    int r = v - px * g.nyz;
+    int py = r / g.nz, pz = r - py * g.nz, lp = v;
+    double c = rho[v], dr0 = 0., dr1 = 0., dr2 = 0.;
+    const int vol_num = labels[v];
+    P[np++] = v;
+    int result = -3;
+    for (;;) {
+        int qx, qy, qz;
+        const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
+        int lq = lin3(g, qx, qy, qz);
+        bool on_path = stay;
+        for (int k = np - 1; k >= 0 && !on_path; k--) on_path = (P[k] == lq);
+        if (on_path) {
+            dr0 = dr1 = dr2 = 0.;
+            og_step(rho, g, g.dist, px, py, pz, c, qx, qy, qz);
+            lq = lin3(g, qx, qy, qz);
+            if (qx == px && qy == py && qz == pz) { result = lp; break; }
+        }
+        if (refine) {
+            if (!plane_valid(g, qx)) { known[v] = -6; atomicAdd(escaped, 1); return; }
+            if (known_ro[lq] == 2) { result = lq; break; }
+        }
+        if (np >= lmax) { atomicExch(err, 1); return; }
+        P[np++] = lq;
+        px = qx; py = qy; pz = qz; lp = lq; c = rho[lq];
+    }
+    if (refine) {
+        const int nv = labels[result];
+        if (nv != vol_num) { labels[v] = nv; known[v] = -2; atomicAdd(changed, 1); }
+        else known[v] = -1;
+    } else {
+        if (result != v && labels[result] == -1) result = -1;
+        labels[v] = result;
+        if (result >= 0) note_maximum(result, v, first, max_list, max_count, max_cap);
+    }
+}
