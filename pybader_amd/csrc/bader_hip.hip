@@ -57,6 +57,7 @@ struct xb_ctx {
     GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
     double *dist_dev = nullptr; // dist_mat on the device
     int *boxbuf = nullptr;      // seeds / box tables of the table build (BB_* layout)
+    int *ec_stamp = nullptr;    // per-voxel round stamps of edge_check (allocated on first use)
     int n_boxes = 0;
     long long box_voxels = 0;
     int opt_boxes = 1;
@@ -165,7 +166,7 @@ int xb_create(int device, xb_ctx **out) {
 
 static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
-    hipFree(c->st); hipFree(c->stage); hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_stamp); c->ec_stamp = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
@@ -877,29 +878,34 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (checked) *checked = 0;
     if (edges) *edges = 0;
     if (!n) return XB_OK;
-    HIPCHK(hipMemsetAsync(c->st, 0, n, c->stream));
     {
-        // work lists: two halves of `first` would clash with the numbering table, so borrow the
-        // dtype staging buffer (N*8 bytes >= 2 lists of n ints); counters 6/7 ping-pong
-        int *wl[2] = {(int *)c->stage, (int *)c->stage + n};
+        // device scratch from the dtype staging buffer (N*8 bytes): per-voxel round stamps (N ints),
+        // then two work lists of n voxel indices each; counters 6/7 ping-pong the list lengths
+        if (!c->ec_stamp) HIPCHK(hipMalloc(&c->ec_stamp, c->N * sizeof(int)));  // only 'changed' refinement needs it
+        int *stamp = c->ec_stamp;
+        int *wl[2] = {(int *)c->stage, (int *)c->stage + n};   // 2n ints <= N*8 bytes
+        HIPCHK(hipMemsetAsync(stamp, 0, c->N * sizeof(int), c->stream));
+        HIPCHK(hipMemcpyAsync(wl[0], c->list, n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->counters + 6, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        int cur = 0;
-        const unsigned grid = (unsigned)std::min<long long>(nblocks(n), 2048);
-        for (int round = 0;; round++) {
+        int cur = 0, last_len = n;
+        for (int round = 1;; round++) {
             HIPCHK(hipMemsetAsync(c->counters + 6 + (1 - cur), 0, sizeof(int), c->stream));
-            k_ec_decide<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, c->st, wl[cur],
-                                                     c->counters + 6 + cur, wl[1 - cur], c->counters + 6 + (1 - cur),
-                                                     round == 0);
+            const unsigned grid = (unsigned)std::min<long long>(nblocks(std::max(last_len, 1)), 2048);
+            k_ec_decide<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, wl[cur], c->counters + 6 + cur,
+                                                     wl[1 - cur], c->counters + 6 + (1 - cur), stamp, round);
             cur = 1 - cur;
-            if ((round & 31) == 31 || round < 2) {
+            if ((round & 31) == 0 || round < 3) {
                 HIPCHK(hipGetLastError());
-                int und = 0;
-                if (int rc = read_counter(c, 6 + cur, &und)) return rc;
-                if (!und) break;
+                int len = 0;
+                if (int rc = read_counter(c, 6 + cur, &len)) return rc;
+                if (c->opt_dbg & 4) fprintf(stderr, "edge_check round %d work list %d of %d\n", round, len, n);
+                if (!len) break;
+                last_len = std::max(len * 4, 4096);  // the list can grow again between polls
             }
             if (round > n + 64 || round > 200000) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
         }
     }
+    k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st);
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1);
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);

@@ -429,25 +429,28 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 // the final `known` is then a pure function of P and the static classes.
 // temp codes in `known`: -2 undecided, -4 processed, -5 skipped.
 // ---------------------------------------------------------------------------------------------
-// One round: every still-undecided entry looks at its (at most 13) earlier neighbours.  Work
-// lists live on the device (`in` -> survivors appended to `out`), so rounds are queued
-// back-to-back without a host round trip; the host only polls the survivor count now and then.
+// Event-driven rounds.  A work list holds changed voxels worth (re-)evaluating: initially all of
+// them, afterwards only the later neighbours of voxels decided in the previous round -- a blocked voxel
+// is re-examined exactly when one of its blockers has been decided.  Lists live on the device
+// (`in` -> `out`, de-duplicated with a per-voxel round stamp) and rounds are queued back-to-back;
+// the host only polls the list length now and then.
 //   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
 //   an earlier neighbour is P -> skipped
 //   no earlier neighbour left undecided -> processed
 __global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
                                                    const int *__restrict__ labels, int8_t *known,
-                                                   const int *__restrict__ list, int8_t *st,
                                                    const int *__restrict__ in, const int *n_in, int *out,
-                                                   int *n_out, int first_round) {
+                                                   int *n_out, int *stamp, int round) {
     const int n = *n_in;
     for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        const int t = first_round ? e : in[e];
-        const int v = list[t];
+        const int v = in[e];
+        if (known[v] != -2) continue;
         const int x = v / g.nyz;
         const int r = v - x * g.nyz;
         const int y = r / g.nz, z = r - y * g.nz;
         bool blocked = false, has_proc = false;
+        int later[26];   // up to 26 with periodic wrap (a voxel on plane 0 has its x-1 neighbours on plane nx-1)
+        int n_later = 0;
 #pragma unroll
         for (int ix = -1; ix < 2; ix++) {
             const int tx = wrapi(x + ix, g.nx);
@@ -458,34 +461,33 @@ __global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restr
                 for (int iz = -1; iz < 2; iz++) {
                     const int tz = wrapi(z + iz, g.nz);
                     const int l = lin3(g, tx, ty, tz);
+                    const int8_t k = __builtin_nontemporal_load(&known[l]);
                     if (l < v) {
-                        const int8_t k = __builtin_nontemporal_load(&known[l]);
                         blocked |= (k == -2);
                         has_proc |= (k == -4);
-                    }
+                    } else if (l > v && k == -2) later[n_later++] = l;
                 }
             }
         }
-        int decision = 0;  // 0 wait, 1 processed, 2 skipped
+        int decision = 0;  // 0 wait (a blocker will wake this voxel), 1 processed, 2 skipped
         if (!blocked && !has_proc) decision = 1;
         else {
-            int8_t cls = st[t] >> 2;  // cached class: 1 = edge&max, 2 = other
-            if (cls == 0) {
-                bool is_edge, is_max;
-                classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-                cls = (is_edge && is_max) ? 1 : 2;
-            }
-            if (cls == 1) decision = 1;
+            bool is_edge, is_max;
+            classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+            if (is_edge && is_max) decision = 1;
             else if (has_proc) decision = 2;
-            else st[t] = (int8_t)(cls << 2);  // still waiting: remember the class
         }
-        if (decision) {
-            st[t] = (int8_t)decision;
-            known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
-        } else {
-            out[atomicAdd(n_out, 1)] = t;
-        }
+        if (!decision) continue;
+        known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
+        __threadfence();  // the status must be visible before the neighbours are woken
+        for (int k = 0; k < n_later; k++)
+            if (atomicExch(&stamp[later[k]], round) != round) out[atomicAdd(n_out, 1)] = later[k];
     }
+}
+// st[t] = 1 for the processed entries (the known codes get overwritten during the apply pass)
+__global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__restrict__ list, int n, int8_t *st) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) st[t] = (known[list[t]] == -4) ? 1 : 2;
 }
 // apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
 __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
