@@ -885,24 +885,42 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
         int *stamp = c->ec_stamp;
         int *wl[2] = {(int *)c->stage, (int *)c->stage + n};   // 2n ints <= N*8 bytes
         HIPCHK(hipMemsetAsync(stamp, 0, c->N * sizeof(int), c->stream));
+        HIPCHK(hipMemsetAsync(c->st, 0, c->N, c->stream));  // per-voxel class cache during the rounds
         HIPCHK(hipMemcpyAsync(wl[0], c->list, n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->counters + 6, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
         int cur = 0, last_len = n;
-        for (int round = 1;; round++) {
+        for (int round = 1;;) {
             HIPCHK(hipMemsetAsync(c->counters + 6 + (1 - cur), 0, sizeof(int), c->stream));
             const unsigned grid = (unsigned)std::min<long long>(nblocks(std::max(last_len, 1)), 2048);
             k_ec_decide<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, wl[cur], c->counters + 6 + cur,
-                                                     wl[1 - cur], c->counters + 6 + (1 - cur), stamp, round);
+                                                     wl[1 - cur], c->counters + 6 + (1 - cur), stamp, c->st, round);
             cur = 1 - cur;
-            if ((round & 31) == 0 || round < 3) {
+            round++;
+            if ((round & 15) == 0 || round < 4) {
                 HIPCHK(hipGetLastError());
                 int len = 0;
                 if (int rc = read_counter(c, 6 + cur, &len)) return rc;
                 if (c->opt_dbg & 4) fprintf(stderr, "edge_check round %d work list %d of %d\n", round, len, n);
                 if (!len) break;
                 last_len = std::max(len * 4, 4096);  // the list can grow again between polls
+                if (len <= 2048) {
+                    // short list: one workgroup loops the rounds with barriers (no launch per round)
+                    int io[3] = {len, cur, round};
+                    HIPCHK(hipMemcpyAsync(c->counters + 14, io, sizeof io, hipMemcpyHostToDevice, c->stream));
+                    k_ec_decide_local<<<1, EC_LOCAL_THREADS, 0, c->stream>>>(g, c->rho, c->labels, c->known, wl[0], wl[1], stamp,
+                                                                            c->st, c->counters + 14, 16384, 1 << 20);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(io, c->counters + 14, sizeof io, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    if (c->opt_dbg & 4) fprintf(stderr, "edge_check local rounds %d..%d, list %d\n", round, io[2], io[0]);
+                    if (!io[0]) break;
+                    cur = io[1];
+                    round = io[2];
+                    HIPCHK(hipMemcpyAsync(c->counters + 6 + cur, &io[0], sizeof(int), hipMemcpyHostToDevice, c->stream));
+                    last_len = std::max(io[0] * 4, 4096);
+                }
             }
-            if (round > n + 64 || round > 200000) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
+            if (round > 4 * (n + 64) || round > (1 << 22)) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
         }
     }
     k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st);

@@ -437,52 +437,100 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 //   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
 //   an earlier neighbour is P -> skipped
 //   no earlier neighbour left undecided -> processed
+template <bool FENCE>
+__device__ __forceinline__ void ec_process(const Grid &g, const double *__restrict__ rho,
+                                           const int *__restrict__ labels, int8_t *known, int v, int *out,
+                                           int *n_out, int *stamp, int8_t *cls_cache, int round) {
+    if (known[v] != -2) return;
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    bool blocked = false, has_proc = false;
+    int later[26];   // up to 26 with periodic wrap (a voxel on plane 0 has its x-1 neighbours on plane nx-1)
+    int n_later = 0;
+    const bool z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
+#pragma unroll
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) {
+            const int ty = wrapi(y + iy, g.ny);
+            const int row = (tx * g.ny + ty) * g.nz;
+            unsigned int w = 0;
+            if (z_inner) {  // one (unaligned) 32-bit load instead of three byte loads: this loop is TA-bound
+                w = __builtin_nontemporal_load(reinterpret_cast<const unsigned int *>(known + row + z - 1));
+            }
+#pragma unroll
+            for (int iz = -1; iz < 2; iz++) {
+                const int tz = z_inner ? z + iz : wrapi(z + iz, g.nz);
+                const int l = row + tz;
+                const int8_t k = z_inner ? (int8_t)((w >> (8 * (iz + 1))) & 0xff) : __builtin_nontemporal_load(&known[l]);
+                if (l < v) {
+                    blocked |= (k == -2);
+                    has_proc |= (k == -4);
+                } else if (l > v && k == -2) later[n_later++] = l;
+            }
+        }
+    }
+    int decision = 0;  // 0 wait (a blocker will wake this voxel), 1 processed, 2 skipped
+    if (!blocked && !has_proc) decision = 1;
+    else {
+        int8_t cls = cls_cache[v];  // 0 unknown, 1 edge&max, 2 other (static: labels/rho do not change here)
+        if (!cls) {
+            bool is_edge, is_max;
+            classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+            cls = (is_edge && is_max) ? 1 : 2;
+            cls_cache[v] = cls;
+        }
+        if (cls == 1) decision = 1;
+        else if (has_proc) decision = 2;
+    }
+    if (!decision) return;
+    known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
+    // the status must be visible before a woken neighbour is evaluated: across workgroups that takes an
+    // agent-scope fence (the next round is a new launch anyway); inside the single-workgroup loop the
+    // workgroup barrier between rounds is enough (one CU) and a fence per voxel would cost ~2 us each
+    if (FENCE) __threadfence();
+    for (int k = 0; k < n_later; k++)
+        if (atomicExch(&stamp[later[k]], round) != round) out[atomicAdd(n_out, 1)] = later[k];
+}
 __global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
                                                    const int *__restrict__ labels, int8_t *known,
                                                    const int *__restrict__ in, const int *n_in, int *out,
-                                                   int *n_out, int *stamp, int round) {
+                                                   int *n_out, int *stamp, int8_t *cls_cache, int round) {
     const int n = *n_in;
-    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        const int v = in[e];
-        if (known[v] != -2) continue;
-        const int x = v / g.nyz;
-        const int r = v - x * g.nyz;
-        const int y = r / g.nz, z = r - y * g.nz;
-        bool blocked = false, has_proc = false;
-        int later[26];   // up to 26 with periodic wrap (a voxel on plane 0 has its x-1 neighbours on plane nx-1)
-        int n_later = 0;
-#pragma unroll
-        for (int ix = -1; ix < 2; ix++) {
-            const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-            for (int iy = -1; iy < 2; iy++) {
-                const int ty = wrapi(y + iy, g.ny);
-#pragma unroll
-                for (int iz = -1; iz < 2; iz++) {
-                    const int tz = wrapi(z + iz, g.nz);
-                    const int l = lin3(g, tx, ty, tz);
-                    const int8_t k = __builtin_nontemporal_load(&known[l]);
-                    if (l < v) {
-                        blocked |= (k == -2);
-                        has_proc |= (k == -4);
-                    } else if (l > v && k == -2) later[n_later++] = l;
-                }
-            }
-        }
-        int decision = 0;  // 0 wait (a blocker will wake this voxel), 1 processed, 2 skipped
-        if (!blocked && !has_proc) decision = 1;
-        else {
-            bool is_edge, is_max;
-            classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-            if (is_edge && is_max) decision = 1;
-            else if (has_proc) decision = 2;
-        }
-        if (!decision) continue;
-        known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
-        __threadfence();  // the status must be visible before the neighbours are woken
-        for (int k = 0; k < n_later; k++)
-            if (atomicExch(&stamp[later[k]], round) != round) out[atomicAdd(n_out, 1)] = later[k];
+    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
+        ec_process<true>(g, rho, labels, known, in[e], out, n_out, stamp, cls_cache, round);
+}
+// Once the work list is short (long thin dependency chains), ONE workgroup runs the rounds in a
+// loop with workgroup barriers instead of kernel launches: ~2 us per round instead of ~40.
+// Leaves when the list is empty, or has grown past `cap` (back to the multi-block rounds).
+// io[0] = list length (in/out), io[1] = which buffer holds the list (in/out), io[2] = next round number.
+#define EC_LOCAL_THREADS 1024
+__global__ __launch_bounds__(EC_LOCAL_THREADS) void k_ec_decide_local(Grid g, const double *__restrict__ rho,
+                                                                      const int *__restrict__ labels, int8_t *known,
+                                                                      int *wl0, int *wl1, int *stamp, int8_t *cls_cache,
+                                                                      int *io, int cap, int max_rounds) {
+    __shared__ int s_n, s_out;
+    int cur = io[1], round = io[2];
+    if (threadIdx.x == 0) s_n = io[0];
+    __syncthreads();
+    for (int it = 0; it < max_rounds; it++) {
+        const int n = s_n;
+        if (n == 0 || n > cap) break;
+        if (threadIdx.x == 0) s_out = 0;
+        __syncthreads();
+        const int *in = cur ? wl1 : wl0;
+        int *out = cur ? wl0 : wl1;
+        for (int e = threadIdx.x; e < n; e += EC_LOCAL_THREADS)
+            ec_process<false>(g, rho, labels, known, in[e], out, &s_out, stamp, cls_cache, round);
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = s_out;
+        cur ^= 1;
+        round++;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) { io[0] = s_n; io[1] = cur; io[2] = round; }
 }
 // st[t] = 1 for the processed entries (the known codes get overwritten during the apply pass)
 __global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__restrict__ list, int n, int8_t *st) {
