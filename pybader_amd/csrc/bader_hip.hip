@@ -218,7 +218,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
         HIPCHK(hipMalloc(&c->rho, N * sizeof(double)));
         HIPCHK(hipMalloc(&c->grad, N * sizeof(GradRec)));
         HIPCHK(hipMalloc(&c->labels, N * sizeof(int)));
-        HIPCHK(hipMalloc(&c->known, N));
+        HIPCHK(hipMalloc(&c->known, N + 16));  // slack: k_ec_async reads/CASes whole aligned words
         HIPCHK(hipMalloc(&c->first, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->list, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->st, N));
@@ -878,6 +878,30 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (checked) *checked = 0;
     if (edges) *edges = 0;
     if (!n) return XB_OK;
+    if (!(c->opt_dbg & 8)) {
+        // asynchronous resolution (k_ec_async): seeds = the compacted edge list; queue overflows of one
+        // launch are the seeds of the next (two buffers of N ints in the dtype staging area)
+        HIPCHK(hipMemsetAsync(c->st, 0, c->N, c->stream));  // per-voxel class cache during the resolution
+        int *ov[2] = {(int *)c->stage, (int *)c->stage + c->N};
+        const int cap = (int)std::min<long long>(c->N, 1LL << 30);
+        const int *seeds = c->list;
+        int n_seeds = n;
+        for (int pass = 0; n_seeds > 0; pass++) {
+            if (pass > 64) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            const int waves = (int)std::min<long long>(((long long)n_seeds + 127) / 128, 8192);
+            const int per_wave = (n_seeds + waves - 1) / waves;
+            k_ec_async<<<waves, XB_WAVE, 0, c->stream>>>(g, c->rho, c->labels, c->known, seeds, n_seeds, per_wave,
+                                                         ov[pass & 1], c->counters + 6, cap, c->st);
+            HIPCHK(hipGetLastError());
+            int n_ovf = 0;
+            if (int rc = read_counter(c, 6, &n_ovf)) return rc;
+            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d seeds, %d overflowed\n", pass, n_seeds, n_ovf);
+            if (n_ovf > cap) return fail(XB_E_LIMIT, "xb_edge_check: overflow list too small");
+            seeds = ov[pass & 1];
+            n_seeds = n_ovf;
+        }
+    } else
     {
         // device scratch from the dtype staging buffer (N*8 bytes): per-voxel round stamps (N ints),
         // then two work lists of n voxel indices each; counters 6/7 ping-pong the list lengths
@@ -923,7 +947,13 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
             if (round > 4 * (n + 64) || round > (1 << 22)) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
         }
     }
-    k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st);
+    HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+    k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st, c->counters + 6);
+    {
+        int undecided = 0;
+        if (int rc = read_counter(c, 6, &undecided)) return rc;
+        if (undecided) return fail(XB_E_STATE, "xb_edge_check: %d edge voxels left undecided", undecided);
+    }
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1);
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);

@@ -441,13 +441,17 @@ template <bool FENCE>
 __device__ __forceinline__ void ec_process(const Grid &g, const double *__restrict__ rho,
                                            const int *__restrict__ labels, int8_t *known, int v, int *out,
                                            int *n_out, int *stamp, int8_t *cls_cache, int round) {
-    if (known[v] != -2) return;
+    // A round is latency-bound (a chain of dependent memory round trips), so the chain is kept short:
+    // the voxel's own status comes with the 27-box loads, the class cache is fetched alongside them,
+    // and the wake-up atomics are all in flight together.
+    int8_t cls = __builtin_nontemporal_load(&cls_cache[v]);  // 0 unknown, 1 edge&max, 2 other (static here)
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
     bool blocked = false, has_proc = false;
-    int later[26];   // up to 26 with periodic wrap (a voxel on plane 0 has its x-1 neighbours on plane nx-1)
-    int n_later = 0;
+    unsigned int later = 0;  // bit j: box voxel j comes later in C order and is still undecided (-2)
+    int8_t kc = 0;
+    int rows[9];
     const bool z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
 #pragma unroll
     for (int ix = -1; ix < 2; ix++) {
@@ -456,6 +460,7 @@ __device__ __forceinline__ void ec_process(const Grid &g, const double *__restri
         for (int iy = -1; iy < 2; iy++) {
             const int ty = wrapi(y + iy, g.ny);
             const int row = (tx * g.ny + ty) * g.nz;
+            rows[(ix + 1) * 3 + iy + 1] = row;
             unsigned int w = 0;
             if (z_inner) {  // one (unaligned) 32-bit load instead of three byte loads: this loop is TA-bound
                 w = __builtin_nontemporal_load(reinterpret_cast<const unsigned int *>(known + row + z - 1));
@@ -468,14 +473,16 @@ __device__ __forceinline__ void ec_process(const Grid &g, const double *__restri
                 if (l < v) {
                     blocked |= (k == -2);
                     has_proc |= (k == -4);
-                } else if (l > v && k == -2) later[n_later++] = l;
+                } else if (l > v) {
+                    if (k == -2) later |= 1u << ((ix + 1) * 9 + (iy + 1) * 3 + iz + 1);
+                } else kc = k;
             }
         }
     }
+    if (kc != -2) return;
     int decision = 0;  // 0 wait (a blocker will wake this voxel), 1 processed, 2 skipped
     if (!blocked && !has_proc) decision = 1;
     else {
-        int8_t cls = cls_cache[v];  // 0 unknown, 1 edge&max, 2 other (static: labels/rho do not change here)
         if (!cls) {
             bool is_edge, is_max;
             classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
@@ -491,8 +498,28 @@ __device__ __forceinline__ void ec_process(const Grid &g, const double *__restri
     // agent-scope fence (the next round is a new launch anyway); inside the single-workgroup loop the
     // workgroup barrier between rounds is enough (one CU) and a fence per voxel would cost ~2 us each
     if (FENCE) __threadfence();
-    for (int k = 0; k < n_later; k++)
-        if (atomicExch(&stamp[later[k]], round) != round) out[atomicAdd(n_out, 1)] = later[k];
+    if (!later) return;
+    int prev[27];
+#pragma unroll
+    for (int j = 0; j < 27; j++) {
+        prev[j] = round;
+        if ((later >> j) & 1u) {
+            const int tz = z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz);
+            prev[j] = atomicExch(&stamp[rows[j / 3] + tz], round);
+        }
+    }
+    unsigned int mine = 0;  // the wake-ups this thread was first to post this round
+#pragma unroll
+    for (int j = 0; j < 27; j++)
+        if (prev[j] != round) mine |= 1u << j;
+    if (!mine) return;
+    int at = atomicAdd(n_out, __popc(mine));
+#pragma unroll
+    for (int j = 0; j < 27; j++)
+        if ((mine >> j) & 1u) {
+            const int tz = z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz);
+            out[at++] = rows[j / 3] + tz;
+        }
 }
 __global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
                                                    const int *__restrict__ labels, int8_t *known,
@@ -532,10 +559,151 @@ __global__ __launch_bounds__(EC_LOCAL_THREADS) void k_ec_decide_local(Grid g, co
     }
     if (threadIdx.x == 0) { io[0] = s_n; io[1] = cur; io[2] = round; }
 }
+// ---- asynchronous resolution ------------------------------------------------------------------
+// The greedy decisions form dependency chains ~1000 voxels long (a voxel waits for its 13 C-order
+// earlier neighbours), so round-synchronous sweeps pay ~1000 x (launch or barrier + a full round).
+// Here every wave runs its own event loop with a queue in LDS and no global barrier: it evaluates
+// up to 64 candidates per iteration; a lane that decides a voxel (compare-and-swap on the aligned
+// word holding its status byte, so exactly one lane in the grid wins) queues the still undecided
+// later neighbours, which are evaluated in the wave's next iteration.  A candidate that is still
+// blocked is simply dropped: whoever decides its last blocker queues it again.  Every decision is
+// final whatever the timing (it depends only on statuses that are themselves final), so the result is
+// the sequential one.  Missed wake-ups: of two lanes deciding the two last blockers of w, the owner of
+// the later CAS must see the earlier one when it evaluates w.  Status bytes are therefore written only
+// by device-scope CAS and read only by device-scope (sc1) loads, and a lane's evaluations are issued
+// after its CAS has returned (the queue entry depends on it), so both resolve at the device coherence
+// point in program order.  No __threadfence(): on the 8-XCD gfx950 an agent-scope fence writes back
+// and invalidates the XCD's L2 (tens of microseconds with thousands of waves doing it), which made a
+// fenced version of this kernel 3x slower than the round-synchronous one.
+// Chain latency is one iteration (~2 memory round trips) per step.
+#define EC_Q 2048   // queue entries per wave (ring)
+__global__ __launch_bounds__(XB_WAVE) void k_ec_async(Grid g, const double *__restrict__ rho,
+                                                      const int *__restrict__ labels, int8_t *known,
+                                                      const int *__restrict__ seeds, int n_seeds, int per_wave,
+                                                      int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache) {
+    __shared__ int q[EC_Q];
+    const int lane = threadIdx.x;
+    int head = 0, tail = 0;  // wave-uniform
+    long long s_cur = (long long)blockIdx.x * per_wave;
+    const long long s_end = s_cur + per_wave < (long long)n_seeds ? s_cur + per_wave : (long long)n_seeds;
+    for (;;) {
+        const int take_q = tail - head < XB_WAVE ? tail - head : XB_WAVE;
+        int v = -1;
+        if (lane < take_q) v = q[(head + lane) & (EC_Q - 1)];
+        head += take_q;
+        if (take_q < XB_WAVE && s_cur < s_end) {  // spare lanes start fresh seeds
+            const long long s = s_cur + (lane - take_q);
+            if (lane >= take_q && s < s_end) v = seeds[s];
+            s_cur += XB_WAVE - take_q;
+        } else if (take_q == 0) break;
+        unsigned int later = 0;
+        int rows[9];
+        bool z_inner = false;
+        int z = 0;
+        bool won = false;
+        if (v >= 0) {
+            int8_t cls = cls_cache[v];  // 0 unknown, 1 edge&max, 2 other (static during the resolution)
+            const int x = v / g.nyz;
+            const int r = v - x * g.nyz;
+            const int y = r / g.nz;
+            z = r - y * g.nz;
+            bool blocked = false, has_proc = false;
+            int8_t kc = 0;
+            z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
+#pragma unroll
+            for (int ix = -1; ix < 2; ix++) {
+                const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+                for (int iy = -1; iy < 2; iy++) {
+                    const int ty = wrapi(y + iy, g.ny);
+                    const int row = (tx * g.ny + ty) * g.nz;
+                    rows[(ix + 1) * 3 + iy + 1] = row;
+                    unsigned int w = 0;
+                    if (z_inner)  // device-coherent load (sc1), no fence: see the note above the kernel
+                        w = __hip_atomic_load(reinterpret_cast<const unsigned int *>(known + row + z - 1), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int iz = -1; iz < 2; iz++) {
+                        const int tz = z_inner ? z + iz : wrapi(z + iz, g.nz);
+                        const int l = row + tz;
+                        const int8_t k = z_inner ? (int8_t)((w >> (8 * (iz + 1))) & 0xff)
+                                                 : __hip_atomic_load(known + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (l < v) {
+                            blocked |= (k == -2);
+                            has_proc |= (k == -4);
+                        } else if (l > v) {
+                            if (k == -2) later |= 1u << ((ix + 1) * 9 + (iy + 1) * 3 + iz + 1);
+                        } else kc = k;
+                    }
+                }
+            }
+            int decision = 0;  // 0 still blocked (dropped: the lane deciding its last blocker queues it again)
+            if (kc == -2) {
+                if (!blocked && !has_proc) decision = 1;
+                else {
+                    if (!cls) {
+                        bool is_edge, is_max;
+                        classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+                        cls = (is_edge && is_max) ? 1 : 2;
+                        cls_cache[v] = cls;
+                    }
+                    if (cls == 1) decision = 1;
+                    else if (has_proc) decision = 2;
+                }
+            }
+            if (decision) {
+                // claim + publish in one atomic on the aligned word that holds the status byte
+                unsigned int *wp = reinterpret_cast<unsigned int *>(known + (v & ~3));
+                const int sh = (v & 3) * 8;
+                const unsigned int code = decision == 1 ? 0xFCu : 0xFBu;  // -4 processed, -5 skipped
+                unsigned int old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    if (((old >> sh) & 0xffu) != 0xFEu) break;  // another lane decided it meanwhile
+                    const unsigned int nw = (old & ~(0xffu << sh)) | (code << sh);
+                    const unsigned int got = atomicCAS(wp, old, nw);
+                    if (got == old) { won = true; break; }
+                    old = got;
+                }
+            }
+        }
+        // queue the undecided later neighbours of the voxels this wave decided
+        const int cnt = won ? __popc(later) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < XB_WAVE; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, XB_WAVE - 1);
+        const int space = EC_Q - (tail - head);
+        if (cnt) {
+            int at = incl - cnt;
+#pragma unroll
+            for (int j = 0; j < 27; j++)
+                if ((later >> j) & 1u) {
+                    const int tz = z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz);
+                    const int l = rows[j / 3] + tz;
+                    if (at < space) q[(tail + at) & (EC_Q - 1)] = l;
+                    else {  // ring full: hand over to the next launch
+                        const int o = atomicAdd(n_ovf, 1);
+                        if (o < ovf_cap) ovf[o] = l;
+                    }
+                    at++;
+                }
+        }
+        tail += total < space ? total : space;
+        __syncthreads();  // one wave per block: orders the LDS queue writes before the next iteration's reads
+    }
+}
+// the voxels the resolution left undecided (must be none) are counted for a loud failure
 // st[t] = 1 for the processed entries (the known codes get overwritten during the apply pass)
-__global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__restrict__ list, int n, int8_t *st) {
+__global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__restrict__ list, int n, int8_t *st,
+                             int *undecided) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) st[t] = (known[list[t]] == -4) ? 1 : 2;
+    if (t >= n) return;
+    const int8_t k = known[list[t]];
+    st[t] = (k == -4) ? 1 : 2;
+    if (k == -2) atomicAdd(undecided, 1);
 }
 // apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
 __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,

@@ -35,17 +35,36 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
     if (x0 >= g.nx) x0 -= g.nx;
     const int y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
     if (threadIdx.x < GT_Z / 8) s_mask[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2); i += TPB) {
-        const int ez = i % (GT_Z + 2);
-        const int r = i / (GT_Z + 2);
-        const int ey = r % (GT_Y + 2), ex = r / (GT_Y + 2);
-        int X = x0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
-        if (small) {
-            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
-        } else {
-            X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+    {
+        // row-wise staging: a wave takes whole z-rows of the haloed tile (x,y wrap is wave-uniform scalar
+        // work, the z wrap is done once per lane), ~6 instructions per row instead of a div/mod chain per element
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
+        int Z = z0 + lane - 1;
+        if (small & 1) Z = ((Z % g.nz) + g.nz) % g.nz;
+        else Z = wrap_u(Z, g.nz);
+        // all of a wave's row loads are issued before the first wait (the unrolled loop keeps ROWS loads in
+        // flight; issued one at a time the kernel was bound by ROWS serial HBM latencies per block)
+        constexpr int ROWS = (GT_X + 2) * (GT_Y + 2) / (TPB / XB_WAVE);
+        static_assert(ROWS * (TPB / XB_WAVE) == (GT_X + 2) * (GT_Y + 2), "rows must divide evenly over the waves");
+        double val[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int r = wv + k * (TPB / XB_WAVE);
+            const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
+            int X = x0 + ex - 1, Y = y0 + ey - 1;
+            if (small & 1) {
+                X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny;
+            } else {
+                X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny);
+            }
+            val[k] = (lane < GT_Z + 2) ? rho[(X * g.ny + Y) * g.nz + Z] : 0.;
         }
-        tile[ex][ey][ez] = rho[(X * g.ny + Y) * g.nz + Z];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int r = wv + k * (TPB / XB_WAVE);
+            const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
+            if (lane < GT_Z + 2) tile[ex][ey][lane] = val[k];
+        }
     }
     __syncthreads();
     const int tz = threadIdx.x & (GT_Z - 1), ty = threadIdx.x / GT_Z;   // 32 x 8 threads, 8 voxels (x) each
@@ -69,7 +88,8 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
                     double w = tile[tx + ix][ty + iy][tz + iz];
                     w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
                     w += c;
-                    if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
+                    og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
+                    max_val = fmax(max_val, w);  // no NaNs in a density: same as the conditional assignment
                 }
         GradRec o;
         double d0, d1, d2;
@@ -99,16 +119,13 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
         if (bmask) {  // which neighbour bricks can a move from this voxel reach (moves <= 2 voxels)
             int lo[3], hi[3];
             move_ranges_raw(code, og, o.r0, o.r1, o.r2, lo, hi);
-            const int ob[3] = {tx, ty, tz & 7};
-            int k0[3], k1[3];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                k0[j] = (ob[j] + lo[j] < 0) ? -1 : 0;
-                k1[j] = (ob[j] + hi[j] >= 8) ? 1 : 0;
-            }
-            for (int c0 = k0[0]; c0 <= k1[0]; c0++)
-                for (int c1 = k0[1]; c1 <= k1[1]; c1++)
-                    for (int c2 = k0[2]; c2 <= k1[2]; c2++) mine |= 1 << ((c0 + 1) * 9 + (c1 + 1) * 3 + (c2 + 1));
+            // per axis the set of brick offsets {-1,0,+1} a move can reach (0 always, as bits 0..2), then the
+            // 27-bit outer product by two carry-free multiplications
+            const int pa = 2 | (tx + lo[0] < 0) | ((tx + hi[0] >= 8) << 2);
+            const int pb = 2 | (ty + lo[1] < 0) | ((ty + hi[1] >= 8) << 2);
+            const int pc = 2 | ((tz & 7) + lo[2] < 0) | (((tz & 7) + hi[2] >= 8) << 2);
+            const int yz = pc * (8 | (pb & 1) | ((pb & 4) << 4));
+            mine |= yz * (512 | (pa & 1) | ((pa & 4) << 16));
         }
     }
     if (bmask) {
