@@ -116,6 +116,8 @@ def main():
         ctx.set_option(3, int(os.environ['XB_OPT_DBG']))
     if 'XB_OPT_TPB' in os.environ:
         ctx.set_option(2, int(os.environ['XB_OPT_TPB']))
+    if 'XB_OPT_EC_GROUPS' in os.environ:
+        ctx.set_option(4, int(os.environ['XB_OPT_EC_GROUPS']))
 
     def step():
         ctx.vacuum_assign(None, voxel_volume)           # Bader.volumes_init: labels := 0 (no vacuum)

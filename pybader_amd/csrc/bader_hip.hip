@@ -57,12 +57,12 @@ struct xb_ctx {
     GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
     double *dist_dev = nullptr; // dist_mat on the device
     int *boxbuf = nullptr;      // seeds / box tables of the table build (BB_* layout)
-    int *ec_stamp = nullptr;    // per-voxel round stamps of edge_check (allocated on first use)
     int n_boxes = 0;
     long long box_voxels = 0;
     int opt_boxes = 1;
     int opt_bricks = 1;
     int opt_dbg = 0;
+    int opt_ec_groups = 64;     // workgroups of k_ec_chase
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
@@ -166,7 +166,7 @@ int xb_create(int device, xb_ctx **out) {
 
 static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
-    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_stamp); c->ec_stamp = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    hipFree(c->st); hipFree(c->stage); hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
@@ -218,7 +218,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
         HIPCHK(hipMalloc(&c->rho, N * sizeof(double)));
         HIPCHK(hipMalloc(&c->grad, N * sizeof(GradRec)));
         HIPCHK(hipMalloc(&c->labels, N * sizeof(int)));
-        HIPCHK(hipMalloc(&c->known, N + 16));  // slack: k_ec_async reads/CASes whole aligned words
+        HIPCHK(hipMalloc(&c->known, N + 16));  // slack: edge_check reads the 3 z-neighbours as one 32-bit word
         HIPCHK(hipMalloc(&c->first, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->list, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->st, N));
@@ -878,73 +878,30 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (checked) *checked = 0;
     if (edges) *edges = 0;
     if (!n) return XB_OK;
-    if (!(c->opt_dbg & 8)) {
-        // asynchronous resolution (k_ec_async): seeds = the compacted edge list; queue overflows of one
-        // launch are the seeds of the next (two buffers of N ints in the dtype staging area)
-        HIPCHK(hipMemsetAsync(c->st, 0, c->N, c->stream));  // per-voxel class cache during the resolution
-        int *ov[2] = {(int *)c->stage, (int *)c->stage + c->N};
-        const int cap = (int)std::min<long long>(c->N, 1LL << 30);
-        const int *seeds = c->list;
-        int n_seeds = n;
-        for (int pass = 0; n_seeds > 0; pass++) {
-            if (pass > 64) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
-            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-            const int waves = (int)std::min<long long>(((long long)n_seeds + 127) / 128, 8192);
-            const int per_wave = (n_seeds + waves - 1) / waves;
-            k_ec_async<<<waves, XB_WAVE, 0, c->stream>>>(g, c->rho, c->labels, c->known, seeds, n_seeds, per_wave,
-                                                         ov[pass & 1], c->counters + 6, cap, c->st);
-            HIPCHK(hipGetLastError());
-            int n_ovf = 0;
-            if (int rc = read_counter(c, 6, &n_ovf)) return rc;
-            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d seeds, %d overflowed\n", pass, n_seeds, n_ovf);
-            if (n_ovf > cap) return fail(XB_E_LIMIT, "xb_edge_check: overflow list too small");
-            seeds = ov[pass & 1];
-            n_seeds = n_ovf;
-        }
-    } else
     {
-        // device scratch from the dtype staging buffer (N*8 bytes): per-voxel round stamps (N ints),
-        // then two work lists of n voxel indices each; counters 6/7 ping-pong the list lengths
-        if (!c->ec_stamp) HIPCHK(hipMalloc(&c->ec_stamp, c->N * sizeof(int)));  // only 'changed' refinement needs it
-        int *stamp = c->ec_stamp;
-        int *wl[2] = {(int *)c->stage, (int *)c->stage + n};   // 2n ints <= N*8 bytes
-        HIPCHK(hipMemsetAsync(stamp, 0, c->N * sizeof(int), c->stream));
-        HIPCHK(hipMemsetAsync(c->st, 0, c->N, c->stream));  // per-voxel class cache during the rounds
-        HIPCHK(hipMemcpyAsync(wl[0], c->list, n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->counters + 6, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        int cur = 0, last_len = n;
-        for (int round = 1;;) {
-            HIPCHK(hipMemsetAsync(c->counters + 6 + (1 - cur), 0, sizeof(int), c->stream));
-            const unsigned grid = (unsigned)std::min<long long>(nblocks(std::max(last_len, 1)), 2048);
-            k_ec_decide<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, wl[cur], c->counters + 6 + cur,
-                                                     wl[1 - cur], c->counters + 6 + (1 - cur), stamp, c->st, round);
-            cur = 1 - cur;
-            round++;
-            if ((round & 15) == 0 || round < 4) {
-                HIPCHK(hipGetLastError());
-                int len = 0;
-                if (int rc = read_counter(c, 6 + cur, &len)) return rc;
-                if (c->opt_dbg & 4) fprintf(stderr, "edge_check round %d work list %d of %d\n", round, len, n);
-                if (!len) break;
-                last_len = std::max(len * 4, 4096);  // the list can grow again between polls
-                if (len <= 2048) {
-                    // short list: one workgroup loops the rounds with barriers (no launch per round)
-                    int io[3] = {len, cur, round};
-                    HIPCHK(hipMemcpyAsync(c->counters + 14, io, sizeof io, hipMemcpyHostToDevice, c->stream));
-                    k_ec_decide_local<<<1, EC_LOCAL_THREADS, 0, c->stream>>>(g, c->rho, c->labels, c->known, wl[0], wl[1], stamp,
-                                                                            c->st, c->counters + 14, 16384, 1 << 20);
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipMemcpyAsync(io, c->counters + 14, sizeof io, hipMemcpyDeviceToHost, c->stream));
-                    HIPCHK(hipStreamSynchronize(c->stream));
-                    if (c->opt_dbg & 4) fprintf(stderr, "edge_check local rounds %d..%d, list %d\n", round, io[2], io[0]);
-                    if (!io[0]) break;
-                    cur = io[1];
-                    round = io[2];
-                    HIPCHK(hipMemcpyAsync(c->counters + 6 + cur, &io[0], sizeof(int), hipMemcpyHostToDevice, c->stream));
-                    last_len = std::max(io[0] * 4, 4096);
-                }
-            }
-            if (round > 4 * (n + 64) || round > (1 << 22)) return fail(XB_E_LIMIT, "xb_edge_check: greedy resolution did not converge");
+        // greedy resolution (k_edges.h): round 1 over the whole edge list as one launch, then the dependency
+        // chains are chased asynchronously by a small grid of workgroups; queue overflows seed another launch.
+        // Scratch: the class cache in `st`, seed/overflow lists in the staging buffer (2 x N ints).
+        int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
+        const int cap = (int)std::min<long long>(c->N, 1LL << 30);
+        HIPCHK(hipMemsetAsync(c->st, 0, c->N, c->stream));
+        HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+        k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(
+            g, c->rho, c->labels, c->known, c->list, n, buf[0], c->counters + 6, cap, c->st);
+        HIPCHK(hipGetLastError());
+        int n_seeds = 0;
+        if (int rc = read_counter(c, 6, &n_seeds)) return rc;
+        for (int pass = 0; n_seeds > 0; pass++) {
+            if (n_seeds > cap) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
+            if (pass > 256) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            const int groups = (int)std::min<long long>(std::max(1, n_seeds / 512), c->opt_ec_groups);
+            k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->rho, c->labels, c->known, buf[pass & 1], n_seeds,
+                                                                   buf[1 - (pass & 1)], c->counters + 6, cap, c->st);
+            HIPCHK(hipGetLastError());
+            const int before = n_seeds;
+            if (int rc = read_counter(c, 6, &n_seeds)) return rc;
+            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d seeds, %d overflowed (%d groups)\n", pass, before, n_seeds, groups);
         }
     }
     HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
@@ -1201,6 +1158,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     if (key == 0) c->opt_trace = value;
     else if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
     else if (key == 3) c->opt_dbg = value;
+    else if (key == 4 && value >= 1 && value <= 4096) c->opt_ec_groups = value;
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;

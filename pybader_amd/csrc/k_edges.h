@@ -427,7 +427,11 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 //     i in P  <=>  class(i) == edge&max  or  no j in P with j < i, j in box(i).
 // P is resolved in rounds (a voxel decides once all earlier changed neighbours have decided);
 // the final `known` is then a pure function of P and the static classes.
-// temp codes in `known`: -2 undecided, -4 processed, -5 skipped.
+// temp codes in `known`: -2 (0xFE) undecided, -4 (0xFC) processed, -10 (0xF6) skipped -- both decisions
+// clear one bit of 0xFE, so a lane claims and publishes a decision with a single atomicAnd on the
+// aligned word holding the status byte (the returned word tells whether it was first).
+#define EC_PROC (-4)
+#define EC_SKIP (-10)
 // ---------------------------------------------------------------------------------------------
 // Event-driven rounds.  A work list holds changed voxels worth (re-)evaluating: initially all of
 // them, afterwards only the later neighbours of voxels decided in the previous round -- a blocked voxel
@@ -437,22 +441,29 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 //   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
 //   an earlier neighbour is P -> skipped
 //   no earlier neighbour left undecided -> processed
-template <bool FENCE>
-__device__ __forceinline__ void ec_process(const Grid &g, const double *__restrict__ rho,
-                                           const int *__restrict__ labels, int8_t *known, int v, int *out,
-                                           int *n_out, int *stamp, int8_t *cls_cache, int round) {
-    // A round is latency-bound (a chain of dependent memory round trips), so the chain is kept short:
-    // the voxel's own status comes with the 27-box loads, the class cache is fetched alongside them,
-    // and the wake-up atomics are all in flight together.
+// One evaluation of edge voxel v against the statuses of its 27-box (refinement.py:428-470 in
+// dependency order): returns 0 when v is not (or no longer) undecided or still has to wait for an
+// earlier neighbour, else the decision (1 processed / 2 skipped) and in `later` the box voxels that
+// come later in C order and are still undecided (bit j = (ix+1)*9+(iy+1)*3+(iz+1)) -- they may be
+// waiting for v.  A decision depends only on statuses that are themselves final, so it is the
+// sequential one whenever it can be taken.
+// COHERENT: the status bytes are read with device-scope (sc1) loads, which resolve at the device
+// coherence point (the workgroups of k_ec_chase sit on different XCDs, one L2 each).
+// EAGER_CLASS (round 1): classify v in any case, so that the chase never has a classification (two more
+// dependent round trips) on its critical path.
+template <bool COHERENT, bool EAGER_CLASS>
+__device__ __forceinline__ int ec_evaluate(const Grid &g, const double *__restrict__ rho,
+                                           const int *__restrict__ labels, const int8_t *known, int v,
+                                           int8_t *cls_cache, unsigned int &later, int rows[9], int &z, bool &z_inner) {
     int8_t cls = __builtin_nontemporal_load(&cls_cache[v]);  // 0 unknown, 1 edge&max, 2 other (static here)
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
+    const int y = r / g.nz;
+    z = r - y * g.nz;
     bool blocked = false, has_proc = false;
-    unsigned int later = 0;  // bit j: box voxel j comes later in C order and is still undecided (-2)
+    later = 0;
     int8_t kc = 0;
-    int rows[9];
-    const bool z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
+    z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
 #pragma unroll
     for (int ix = -1; ix < 2; ix++) {
         const int tx = wrapi(x + ix, g.nx);
@@ -462,237 +473,126 @@ __device__ __forceinline__ void ec_process(const Grid &g, const double *__restri
             const int row = (tx * g.ny + ty) * g.nz;
             rows[(ix + 1) * 3 + iy + 1] = row;
             unsigned int w = 0;
-            if (z_inner) {  // one (unaligned) 32-bit load instead of three byte loads: this loop is TA-bound
-                w = __builtin_nontemporal_load(reinterpret_cast<const unsigned int *>(known + row + z - 1));
+            if (z_inner) {  // one (unaligned) 32-bit load instead of three byte loads: the rounds are TA-bound
+                const unsigned int *wp = reinterpret_cast<const unsigned int *>(known + row + z - 1);
+                w = COHERENT ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __builtin_nontemporal_load(wp);
             }
 #pragma unroll
             for (int iz = -1; iz < 2; iz++) {
                 const int tz = z_inner ? z + iz : wrapi(z + iz, g.nz);
                 const int l = row + tz;
-                const int8_t k = z_inner ? (int8_t)((w >> (8 * (iz + 1))) & 0xff) : __builtin_nontemporal_load(&known[l]);
+                int8_t k;
+                if (z_inner) k = (int8_t)((w >> (8 * (iz + 1))) & 0xff);
+                else k = COHERENT ? __hip_atomic_load(&known[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : __builtin_nontemporal_load(&known[l]);
                 if (l < v) {
                     blocked |= (k == -2);
-                    has_proc |= (k == -4);
+                    has_proc |= (k == EC_PROC);
                 } else if (l > v) {
                     if (k == -2) later |= 1u << ((ix + 1) * 9 + (iy + 1) * 3 + iz + 1);
                 } else kc = k;
             }
         }
     }
-    if (kc != -2) return;
-    int decision = 0;  // 0 wait (a blocker will wake this voxel), 1 processed, 2 skipped
-    if (!blocked && !has_proc) decision = 1;
-    else {
-        if (!cls) {
-            bool is_edge, is_max;
-            classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-            cls = (is_edge && is_max) ? 1 : 2;
-            cls_cache[v] = cls;
-        }
-        if (cls == 1) decision = 1;
-        else if (has_proc) decision = 2;
+    if (kc != -2) return 0;
+    if (!EAGER_CLASS && !blocked && !has_proc) return 1;
+    if (!cls) {
+        bool is_edge, is_max;
+        classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
+        cls = (is_edge && is_max) ? 1 : 2;
+        cls_cache[v] = cls;  // racing writers store the same value
     }
-    if (!decision) return;
-    known[v] = decision == 1 ? (int8_t)-4 : (int8_t)-5;
-    // the status must be visible before a woken neighbour is evaluated: across workgroups that takes an
-    // agent-scope fence (the next round is a new launch anyway); inside the single-workgroup loop the
-    // workgroup barrier between rounds is enough (one CU) and a fence per voxel would cost ~2 us each
-    if (FENCE) __threadfence();
-    if (!later) return;
-    int prev[27];
+    if (cls == 1 || (!blocked && !has_proc)) return 1;
+    return has_proc ? 2 : 0;
+}
+__device__ __forceinline__ int ec_later_voxel(const Grid &g, const int rows[9], int z, bool z_inner, int j) {
+    return rows[j / 3] + (z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz));
+}
+// Round 1: every listed edge voxel once (one launch over the whole list; the kernel boundary publishes
+// the statuses).  The undecided later neighbours of the decided voxels are the seeds of k_ec_chase
+// (with duplicates: a voxel is listed once per decided earlier neighbour).
+__global__ __launch_bounds__(TPB) void k_ec_first(Grid g, const double *__restrict__ rho,
+                                                  const int *__restrict__ labels, int8_t *known,
+                                                  const int *__restrict__ in, int n, int *out, int *n_out, int out_cap,
+                                                  int8_t *cls_cache) {
+    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        const int v = in[e];
+        unsigned int later;
+        int rows[9], z;
+        bool z_inner;
+        const int d = ec_evaluate<false, false>(g, rho, labels, known, v, cls_cache, later, rows, z, z_inner);
+        if (!d) continue;
+        known[v] = d == 1 ? (int8_t)EC_PROC : (int8_t)EC_SKIP;
+        if (!later) continue;
+        int at = atomicAdd(n_out, __popc(later));
 #pragma unroll
-    for (int j = 0; j < 27; j++) {
-        prev[j] = round;
-        if ((later >> j) & 1u) {
-            const int tz = z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz);
-            prev[j] = atomicExch(&stamp[rows[j / 3] + tz], round);
-        }
+        for (int j = 0; j < 27; j++)
+            if ((later >> j) & 1u) {
+                if (at < out_cap) out[at] = ec_later_voxel(g, rows, z, z_inner, j);
+                at++;
+            }
     }
-    unsigned int mine = 0;  // the wake-ups this thread was first to post this round
-#pragma unroll
-    for (int j = 0; j < 27; j++)
-        if (prev[j] != round) mine |= 1u << j;
-    if (!mine) return;
-    int at = atomicAdd(n_out, __popc(mine));
-#pragma unroll
-    for (int j = 0; j < 27; j++)
-        if ((mine >> j) & 1u) {
-            const int tz = z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz);
-            out[at++] = rows[j / 3] + tz;
-        }
 }
-__global__ __launch_bounds__(TPB) void k_ec_decide(Grid g, const double *__restrict__ rho,
-                                                   const int *__restrict__ labels, int8_t *known,
-                                                   const int *__restrict__ in, const int *n_in, int *out,
-                                                   int *n_out, int *stamp, int8_t *cls_cache, int round) {
-    const int n = *n_in;
-    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
-        ec_process<true>(g, rho, labels, known, in[e], out, n_out, stamp, cls_cache, round);
-}
-// Once the work list is short (long thin dependency chains), ONE workgroup runs the rounds in a
-// loop with workgroup barriers instead of kernel launches: ~2 us per round instead of ~40.
-// Leaves when the list is empty, or has grown past `cap` (back to the multi-block rounds).
-// io[0] = list length (in/out), io[1] = which buffer holds the list (in/out), io[2] = next round number.
-#define EC_LOCAL_THREADS 1024
-__global__ __launch_bounds__(EC_LOCAL_THREADS) void k_ec_decide_local(Grid g, const double *__restrict__ rho,
-                                                                      const int *__restrict__ labels, int8_t *known,
-                                                                      int *wl0, int *wl1, int *stamp, int8_t *cls_cache,
-                                                                      int *io, int cap, int max_rounds) {
-    __shared__ int s_n, s_out;
-    int cur = io[1], round = io[2];
-    if (threadIdx.x == 0) s_n = io[0];
+// The rest of the resolution.  The dependency chains are ~1000 voxels long while only a few thousand
+// voxels are decidable at any time, so global rounds (a launch or a grid barrier each) cost 20-40 us
+// per chain step.  Here every workgroup chases its own share asynchronously -- no barrier, no waiting
+// on another workgroup: a round evaluates the workgroup's queue (LDS); a lane that decides a voxel
+// claims it with an atomicAnd on the aligned word holding its status byte (one winner in the whole
+// grid, so nothing is woken twice) and queues the voxel's still undecided later neighbours for the
+// workgroup's next round.  A candidate that is still blocked is dropped: whoever decides its last
+// blocker queues it again.  No wake-up is lost: of two lanes deciding the two last blockers of w, the one
+// whose atomic lands second evaluates w only after that atomic has returned, and its (sc1) loads then see the
+// first one's.  No __threadfence(): on the 8-XCD gfx950 an agent-scope fence writes back and invalidates
+// the XCD's L2 (~2 us each).  A chain step costs one workgroup round = two memory round trips.
+// Queue overflows go to `ovf` and seed the next launch.
+#define EC_CHASE_THREADS 1024
+#define EC_Q 6144   // queue entries per buffer (2 buffers, 48 KB of LDS)
+__global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const double *__restrict__ rho,
+                                                               const int *__restrict__ labels, int8_t *known,
+                                                               const int *__restrict__ seeds, int n_seeds,
+                                                               int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache) {
+    __shared__ int q[2][EC_Q];
+    __shared__ int s_n[2];
+    const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
+    int seed_cur = blockIdx.x * per;
+    const int seed_end = min(seed_cur + per, n_seeds);
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
-    for (int it = 0; it < max_rounds; it++) {
-        const int n = s_n;
-        if (n == 0 || n > cap) break;
-        if (threadIdx.x == 0) s_out = 0;
-        __syncthreads();
-        const int *in = cur ? wl1 : wl0;
-        int *out = cur ? wl0 : wl1;
-        for (int e = threadIdx.x; e < n; e += EC_LOCAL_THREADS)
-            ec_process<false>(g, rho, labels, known, in[e], out, &s_out, stamp, cls_cache, round);
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = s_out;
-        cur ^= 1;
-        round++;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { io[0] = s_n; io[1] = cur; io[2] = round; }
-}
-// ---- asynchronous resolution ------------------------------------------------------------------
-// The greedy decisions form dependency chains ~1000 voxels long (a voxel waits for its 13 C-order
-// earlier neighbours), so round-synchronous sweeps pay ~1000 x (launch or barrier + a full round).
-// Here every wave runs its own event loop with a queue in LDS and no global barrier: it evaluates
-// up to 64 candidates per iteration; a lane that decides a voxel (compare-and-swap on the aligned
-// word holding its status byte, so exactly one lane in the grid wins) queues the still undecided
-// later neighbours, which are evaluated in the wave's next iteration.  A candidate that is still
-// blocked is simply dropped: whoever decides its last blocker queues it again.  Every decision is
-// final whatever the timing (it depends only on statuses that are themselves final), so the result is
-// the sequential one.  Missed wake-ups: of two lanes deciding the two last blockers of w, the owner of
-// the later CAS must see the earlier one when it evaluates w.  Status bytes are therefore written only
-// by device-scope CAS and read only by device-scope (sc1) loads, and a lane's evaluations are issued
-// after its CAS has returned (the queue entry depends on it), so both resolve at the device coherence
-// point in program order.  No __threadfence(): on the 8-XCD gfx950 an agent-scope fence writes back
-// and invalidates the XCD's L2 (tens of microseconds with thousands of waves doing it), which made a
-// fenced version of this kernel 3x slower than the round-synchronous one.
-// Chain latency is one iteration (~2 memory round trips) per step.
-#define EC_Q 2048   // queue entries per wave (ring)
-__global__ __launch_bounds__(XB_WAVE) void k_ec_async(Grid g, const double *__restrict__ rho,
-                                                      const int *__restrict__ labels, int8_t *known,
-                                                      const int *__restrict__ seeds, int n_seeds, int per_wave,
-                                                      int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache) {
-    __shared__ int q[EC_Q];
-    const int lane = threadIdx.x;
-    int head = 0, tail = 0;  // wave-uniform
-    long long s_cur = (long long)blockIdx.x * per_wave;
-    const long long s_end = s_cur + per_wave < (long long)n_seeds ? s_cur + per_wave : (long long)n_seeds;
-    for (;;) {
-        const int take_q = tail - head < XB_WAVE ? tail - head : XB_WAVE;
-        int v = -1;
-        if (lane < take_q) v = q[(head + lane) & (EC_Q - 1)];
-        head += take_q;
-        if (take_q < XB_WAVE && s_cur < s_end) {  // spare lanes start fresh seeds
-            const long long s = s_cur + (lane - take_q);
-            if (lane >= take_q && s < s_end) v = seeds[s];
-            s_cur += XB_WAVE - take_q;
-        } else if (take_q == 0) break;
-        unsigned int later = 0;
-        int rows[9];
-        bool z_inner = false;
-        int z = 0;
-        bool won = false;
-        if (v >= 0) {
-            int8_t cls = cls_cache[v];  // 0 unknown, 1 edge&max, 2 other (static during the resolution)
-            const int x = v / g.nyz;
-            const int r = v - x * g.nyz;
-            const int y = r / g.nz;
-            z = r - y * g.nz;
-            bool blocked = false, has_proc = false;
-            int8_t kc = 0;
-            z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
-#pragma unroll
-            for (int ix = -1; ix < 2; ix++) {
-                const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-                for (int iy = -1; iy < 2; iy++) {
-                    const int ty = wrapi(y + iy, g.ny);
-                    const int row = (tx * g.ny + ty) * g.nz;
-                    rows[(ix + 1) * 3 + iy + 1] = row;
-                    unsigned int w = 0;
-                    if (z_inner)  // device-coherent load (sc1), no fence: see the note above the kernel
-                        w = __hip_atomic_load(reinterpret_cast<const unsigned int *>(known + row + z - 1), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int iz = -1; iz < 2; iz++) {
-                        const int tz = z_inner ? z + iz : wrapi(z + iz, g.nz);
-                        const int l = row + tz;
-                        const int8_t k = z_inner ? (int8_t)((w >> (8 * (iz + 1))) & 0xff)
-                                                 : __hip_atomic_load(known + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (l < v) {
-                            blocked |= (k == -2);
-                            has_proc |= (k == -4);
-                        } else if (l > v) {
-                            if (k == -2) later |= 1u << ((ix + 1) * 9 + (iy + 1) * 3 + iz + 1);
-                        } else kc = k;
-                    }
-                }
-            }
-            int decision = 0;  // 0 still blocked (dropped: the lane deciding its last blocker queues it again)
-            if (kc == -2) {
-                if (!blocked && !has_proc) decision = 1;
-                else {
-                    if (!cls) {
-                        bool is_edge, is_max;
-                        classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-                        cls = (is_edge && is_max) ? 1 : 2;
-                        cls_cache[v] = cls;
-                    }
-                    if (cls == 1) decision = 1;
-                    else if (has_proc) decision = 2;
-                }
-            }
-            if (decision) {
-                // claim + publish in one atomic on the aligned word that holds the status byte
-                unsigned int *wp = reinterpret_cast<unsigned int *>(known + (v & ~3));
-                const int sh = (v & 3) * 8;
-                const unsigned int code = decision == 1 ? 0xFCu : 0xFBu;  // -4 processed, -5 skipped
-                unsigned int old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (;;) {
-                    if (((old >> sh) & 0xffu) != 0xFEu) break;  // another lane decided it meanwhile
-                    const unsigned int nw = (old & ~(0xffu << sh)) | (code << sh);
-                    const unsigned int got = atomicCAS(wp, old, nw);
-                    if (got == old) { won = true; break; }
-                    old = got;
-                }
-            }
-        }
-        // queue the undecided later neighbours of the voxels this wave decided
-        const int cnt = won ? __popc(later) : 0;
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < XB_WAVE; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        const int total = __shfl(incl, XB_WAVE - 1);
-        const int space = EC_Q - (tail - head);
-        if (cnt) {
-            int at = incl - cnt;
+    for (int cur = 0;; cur ^= 1) {
+        const int n = min(s_n[cur], EC_Q);
+        const int take = n <= EC_Q / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
+        if (n + take == 0) break;
+        __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
+        if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
+        for (int e = threadIdx.x; e < n + take; e += EC_CHASE_THREADS) {
+            const int v = e < n ? q[cur][e] : seeds[seed_cur + e - n];
+            unsigned int later;
+            int rows[9], z;
+            bool z_inner;
+            const int d = ec_evaluate<true, false>(g, rho, labels, known, v, cls_cache, later, rows, z, z_inner);
+            if (!d) continue;
+            // claim + publish: one atomicAnd clears the decision's bit in the status byte; the lane that finds
+            // the byte still 0xFE in the returned word is the (only) winner
+            unsigned int *wp = reinterpret_cast<unsigned int *>(known + (v & ~3));
+            const int sh = (v & 3) * 8;
+            const unsigned int old = atomicAnd(wp, ~((d == 1 ? 0x02u : 0x08u) << sh));
+            const bool won = ((old >> sh) & 0xffu) == 0xFEu;
+            if (!won || !later) continue;
+            int at = atomicAdd(&s_n[cur ^ 1], __popc(later));
 #pragma unroll
             for (int j = 0; j < 27; j++)
                 if ((later >> j) & 1u) {
-                    const int tz = z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz);
-                    const int l = rows[j / 3] + tz;
-                    if (at < space) q[(tail + at) & (EC_Q - 1)] = l;
-                    else {  // ring full: hand over to the next launch
+                    const int l = ec_later_voxel(g, rows, z, z_inner, j);
+                    if (at < EC_Q) q[cur ^ 1][at] = l;
+                    else {
                         const int o = atomicAdd(n_ovf, 1);
                         if (o < ovf_cap) ovf[o] = l;
                     }
                     at++;
                 }
         }
-        tail += total < space ? total : space;
-        __syncthreads();  // one wave per block: orders the LDS queue writes before the next iteration's reads
+        seed_cur += take;
+        __syncthreads();  // the next round's queue is complete (every claim has returned: its result was used)
     }
 }
 // the voxels the resolution left undecided (must be none) are counted for a loud failure
@@ -702,7 +602,7 @@ __global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__rest
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int8_t k = known[list[t]];
-    st[t] = (k == -4) ? 1 : 2;
+    st[t] = (k == EC_PROC) ? 1 : 2;
     if (k == -2) atomicAdd(undecided, 1);
 }
 // apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
@@ -739,7 +639,7 @@ __global__ void k_ec_restore(int8_t *known, const int *list, int n) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int8_t k = known[list[t]];
-    if (k == -4 || k == -5) known[list[t]] = -2;
+    if (k == EC_PROC || k == EC_SKIP) known[list[t]] = -2;
 }
 // count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread
 __global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges) {
