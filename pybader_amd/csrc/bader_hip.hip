@@ -529,17 +529,17 @@ static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks) {
                                                              c->boxbuf + BB_RCAP, seed);
         HIPCHK(hipMemcpyAsync(buf[0], seed, nbr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
         int cur = 0;
-        const int max_rounds = 8 * ((2 * (nb0 + nb1 + nb2) + 15) / 8);  // a multiple of the polling period
+        // k_brick_grow: labels travel up to BG bricks per launch; a launch that changes nothing is the fixpoint
+        const int max_launches = 2 * (nb0 + nb1 + nb2) + 16;
+        const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         bool kill_converged = false;
         for (int phase = 0; phase < 2; phase++) {  // 0: propagate provisional labels, 1: kill violators
-            for (int round = 1; round <= max_rounds; round++) {
-                if ((round & 7) == 1) HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
-                if (phase == 0)
-                    k_brick_propagate<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, bmask, buf[cur], buf[1 - cur], c->counters + 11);
-                else
-                    k_brick_kill<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf[cur], buf[1 - cur], c->counters + 11);
+            for (int launch = 1; launch <= max_launches; launch++) {
+                if (launch & 1) HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
+                k_brick_grow<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf[cur], buf[1 - cur],
+                                                                 c->counters + 11, phase, BG);
                 cur = 1 - cur;
-                if ((round & 7) == 0) {  // poll the change flag of the last eight rounds
+                if (!(launch & 1)) {  // poll the change flag of the last two launches
                     HIPCHK(hipGetLastError());
                     int ch = 0;
                     if (int rc = read_counter(c, 11, &ch)) return rc;

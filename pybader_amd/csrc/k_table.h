@@ -334,6 +334,65 @@ __global__ void k_brick_kill(int nb0, int nb1, int nb2, const int *__restrict__ 
     }
     aout[b] = l;
 }
+// Both iterations, several rounds per launch: a workgroup keeps an 8x8x8 chunk of bricks plus a one-brick
+// (periodic) halo in LDS and iterates on it until nothing changes or `inner` rounds are done; the halo is
+// what the previous launch left.  Labels then travel up to `inner` bricks per launch instead of one.
+// The schedule does not matter for the result's soundness: a provisional label is only a guess, and the
+// kill iteration is monotone (stale neighbour labels can only delay a kill), so its fixpoint -- reached
+// when a whole launch changes nothing -- is the same greatest fixpoint.  phase 0: propagate, 1: kill.
+#define BG 8
+__global__ __launch_bounds__(BG * BG * BG) void k_brick_grow(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
+                                                             const int *__restrict__ seed, const int *__restrict__ in,
+                                                             int *__restrict__ out, int *changed, int phase, int inner) {
+    __shared__ int lab[2][BG + 2][BG + 2][BG + 2];
+    const int c0 = blockIdx.z * BG, c1 = blockIdx.y * BG, c2 = blockIdx.x * BG;
+    for (int i = threadIdx.x; i < (BG + 2) * (BG + 2) * (BG + 2); i += BG * BG * BG) {
+        const int e2 = i % (BG + 2), e1 = (i / (BG + 2)) % (BG + 2), e0 = i / ((BG + 2) * (BG + 2));
+        const int l = in[(wrap_any(c0 + e0 - 1, nb0) * nb1 + wrap_any(c1 + e1 - 1, nb1)) * nb2 + wrap_any(c2 + e2 - 1, nb2)];
+        lab[0][e0][e1][e2] = l;
+        lab[1][e0][e1][e2] = l;
+    }
+    const int t2 = threadIdx.x % BG, t1 = (threadIdx.x / BG) % BG, t0 = threadIdx.x / (BG * BG);
+    const int b0 = c0 + t0, b1 = c1 + t1, b2 = c2 + t2;
+    const bool active = b0 < nb0 && b1 < nb1 && b2 < nb2;
+    const int b = active ? (b0 * nb1 + b1) * nb2 + b2 : 0;
+    const int m = active ? bmask[b] : 0;
+    // bricks that never change: a maximum inside (propagate), seed cubes (kill)
+    const bool fixed = !active || (phase == 0 && (m >> 27)) || (phase == 1 && seed[b] != 0);
+    __syncthreads();
+    const int first = lab[0][t0 + 1][t1 + 1][t2 + 1];
+    int l = first, cur = 0;
+    for (int it = 0; it < inner; it++) {
+        int nl = l;
+        if (!fixed) {
+            if (phase == 0) {
+                if (l == 0) {
+                    int best = 0;
+                    for (int k = 0; k < 27; k++)
+                        if ((m >> k) & 1) {
+                            const int q = lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3];
+                            if (q > 0 && (best == 0 || q < best)) best = q;
+                        }
+                    nl = best;
+                }
+            } else if (l > 0) {
+                bool ok = !(m >> 27);
+                for (int k = 0; k < 27 && ok; k++)
+                    if ((m >> k) & 1) ok = (lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3] == l);
+                if (!ok) nl = 0;
+            }
+        }
+        lab[cur ^ 1][t0 + 1][t1 + 1][t2 + 1] = nl;
+        const int any = __syncthreads_or(nl != l);
+        l = nl;
+        cur ^= 1;
+        if (!any) break;
+    }
+    if (active) {
+        out[b] = l;
+        if (l != first) *changed = 1;
+    }
+}
 __global__ void k_count_positive(const int *__restrict__ a, int n, int *count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long b = __ballot(i < n && a[i] > 0);
