@@ -722,8 +722,12 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     }
     c->buni_valid = false;
     if (c->regions_pending && c->blab) {
-        k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
-                                                               c->boxbuf + BB_BOXMAX);
+        if (g.nz % 4 == 0)
+            k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
+                                                                    c->nbk[2], c->boxbuf + BB_BOXMAX);
+        else
+            k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
+                                                                   c->boxbuf + BB_BOXMAX);
         if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);

@@ -189,17 +189,49 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
             return;
         }
     }
-    for (int i = threadIdx.x; i < (ET_X + 2) * (ET_Y + 2) * (ET_Z + 2); i += TPB) {
-        const int ez = i % (ET_Z + 2);
-        const int r = i / (ET_Z + 2);
-        const int ey = r % (ET_Y + 2), ex = r / (ET_Y + 2);
-        int X = xa + tx0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
-        if (small) {
-            X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
-        } else {
-            X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+    {
+        // row-wise staging with every load of a wave in flight before the first wait (see k_grad_field): a
+        // wave takes whole z-rows (64 aligned labels per row, x/y wrap is wave-uniform scalar work); the two
+        // halo labels of each row are fetched by the first 2*rows threads
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
+        constexpr int NROW = (ET_X + 2) * (ET_Y + 2);
+        constexpr int ROWS = NROW / (TPB / XB_WAVE);
+        static_assert(ROWS * (TPB / XB_WAVE) == NROW && ET_Z == XB_WAVE && 2 * NROW <= TPB, "tile shape");
+        int Zc = z0 + lane;
+        if (small) Zc %= g.nz;
+        else Zc = wrap_u(Zc, g.nz);
+        int val[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int r = wv + k * (TPB / XB_WAVE);
+            const int ex = r / (ET_Y + 2), ey = r - ex * (ET_Y + 2);
+            int X = xa + tx0 + ex - 1, Y = y0 + ey - 1;
+            if (small) {
+                X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny;
+            } else {
+                X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny);
+            }
+            val[k] = labels[(X * g.ny + Y) * g.nz + Zc];
         }
-        tile[ex][ey][ez] = labels[(X * g.ny + Y) * g.nz + Z];
+        int hv = 0;
+        const int hr = threadIdx.x >> 1, hside = threadIdx.x & 1;
+        const int hex = hr / (ET_Y + 2), hey = hr - hex * (ET_Y + 2);
+        if (threadIdx.x < 2 * NROW) {
+            int X = xa + tx0 + hex - 1, Y = y0 + hey - 1, Z = hside ? z0 + ET_Z : z0 - 1;
+            if (small) {
+                X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
+            } else {
+                X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+            }
+            hv = labels[(X * g.ny + Y) * g.nz + Z];
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int r = wv + k * (TPB / XB_WAVE);
+            const int ex = r / (ET_Y + 2), ey = r - ex * (ET_Y + 2);
+            tile[ex][ey][lane + 1] = val[k];
+        }
+        if (threadIdx.x < 2 * NROW) tile[hex][hey][hside ? ET_Z + 1 : 0] = hv;
     }
     __syncthreads();
     const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
