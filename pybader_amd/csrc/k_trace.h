@@ -188,9 +188,9 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
                 }
             }
             if (moving) {
-                const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
                 const bool in_win = plane_in_window(g, qx);  // the table only exists inside the window (slabs)
-                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                const GradRec nr = fetch_rec(G, in_win ? lq : lp);  // issued before the brick label: both in flight
+                const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
                 const int b = bl > 0 ? bl : (in_win ? key_box(nr.key) : 0);
                 if (b) {  // arrived inside a trapping region (q cannot be an old path voxel: the
                     result = box_max[b - 1];  // trajectory would have stopped there already)
