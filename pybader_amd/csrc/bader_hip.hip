@@ -669,7 +669,9 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     } else if (method == XB_METHOD_ONGRID) {
         {
             ScopedTimer t(c, 1);
-            k_og_pointer<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->rho, c->labels);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+            k_og_pointer_tiled<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, c->has_vacuum ? 1 : 0);
         }
         HIPCHK(hipGetLastError());
         for (int it = 0; it < 64; it++) {

@@ -6,21 +6,9 @@
 // ongrid assignment (methods.py:15-219).  The ascent is memoryless, so the sequential path
 // compression of the reference equals: best-neighbour pointer per voxel, then pointer jumping.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_og_pointer(Grid g, const double *__restrict__ rho, int *labels) {
-    const long long N = (long long)g.nx * g.nyz;
-    const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (vv >= N) return;
-    const int v = (int)vv;
-    if (labels[v] == -1) return;  // vacuum stays -1 (methods.py:73-74)
-    const int px = v / g.nyz;
-    const int r = v - px * g.nyz;
-    const int py = r / g.nz, pz = r - py * g.nz;
-    int qx, qy, qz;
-    og_step(rho, g, g.dist, px, py, pz, rho[v], qx, qy, qz);
-    labels[v] = lin3(g, qx, qy, qz);
-}
 // A chain that steps onto a vacuum voxel inherits -1 (methods.py:166-168).  In-place and
 // asynchronous: any value read is an ancestor of the root, so progress is monotone.
+#define OG_HOPS 3
 __global__ __launch_bounds__(TPB) void k_og_jump(Grid g, int *labels, int *not_done) {
     const long long N = (long long)g.nx * g.nyz;
     const long long vv = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -30,10 +18,11 @@ __global__ __launch_bounds__(TPB) void k_og_jump(Grid g, int *labels, int *not_d
     if (p < 0 || p == v) return;
     int q = labels[p];
     if (q == p) return;  // parent is a root
-    if (q >= 0) {
-        const int q2 = labels[q];  // two hops per sweep
-        if (q2 >= 0) q = q2;
-        else q = -1;
+#pragma unroll
+    for (int hop = 0; hop < OG_HOPS && q >= 0; hop++) {  // a few more hops per sweep
+        const int q2 = labels[q];
+        if (q2 == q) break;
+        q = q2;
     }
     labels[v] = q;
     if (q >= 0) *not_done = 1;

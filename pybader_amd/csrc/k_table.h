@@ -138,6 +138,67 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
     }
 }
 
+// The ongrid pointer of every voxel (methods.py:84-117) from the same staged tile: labels[v] = linear
+// index of the best distance-weighted neighbour (v itself for a 26-neighbour maximum); vacuum voxels
+// (label -1) keep their -1 (methods.py:73-74).
+__global__ __launch_bounds__(TPB) void k_og_pointer_tiled(Grid g, const double *__restrict__ rho, int *labels,
+                                                          int small, int has_vacuum) {
+    __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
+    const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
+        int Z = z0 + lane - 1;
+        if (small & 1) Z = ((Z % g.nz) + g.nz) % g.nz;
+        else Z = wrap_u(Z, g.nz);
+        constexpr int ROWS = (GT_X + 2) * (GT_Y + 2) / (TPB / XB_WAVE);
+        double val[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int r = wv + k * (TPB / XB_WAVE);
+            const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
+            int X = x0 + ex - 1, Y = y0 + ey - 1;
+            if (small & 1) {
+                X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny;
+            } else {
+                X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny);
+            }
+            val[k] = (lane < GT_Z + 2) ? rho[(X * g.ny + Y) * g.nz + Z] : 0.;
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) {
+            const int r = wv + k * (TPB / XB_WAVE);
+            const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
+            if (lane < GT_Z + 2) tile[ex][ey][lane] = val[k];
+        }
+    }
+    __syncthreads();
+    const int tz = threadIdx.x & (GT_Z - 1), ty = threadIdx.x / GT_Z;
+#pragma unroll 1
+    for (int tx = 0; tx < GT_X; tx++) {
+        const int x = x0 + tx, y = y0 + ty, z = z0 + tz;
+        if (x >= g.nx || y >= g.ny || z >= g.nz) continue;
+        const int v = (x * g.ny + y) * g.nz + z;
+        if (has_vacuum && labels[v] == -1) continue;
+        const double c = tile[tx + 1][ty + 1][tz + 1];
+        double max_val = c;
+        int og = XB_OG_SELF;
+#pragma unroll
+        for (int ix = 0; ix < 3; ix++)
+#pragma unroll
+            for (int iy = 0; iy < 3; iy++)
+#pragma unroll
+                for (int iz = 0; iz < 3; iz++) {
+                    double w = tile[tx + ix][ty + iy][tz + iz];
+                    w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+                    w += c;
+                    og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
+                    max_val = fmax(max_val, w);
+                }
+        const int qx = wrapi(x + og / 9 - 1, g.nx), qy = wrapi(y + (og / 3) % 3 - 1, g.ny), qz = wrapi(z + og % 3 - 1, g.nz);
+        labels[v] = (qx * g.ny + qy) * g.nz + qz;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Trapping boxes.  For a 26-neighbour maximum m let B_R = {v : |v - m|_inf <= R} (minimum image).
 // B_R is CLOSED when no voxel of B_R can be left by (a) a neargrid move, for ANY carried remainder dr,
