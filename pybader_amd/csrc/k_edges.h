@@ -578,13 +578,15 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, const double *__restri
 // the XCD's L2 (~2 us each).  A chain step costs one workgroup round = two memory round trips.
 // Queue overflows go to `ovf` and seed the next launch.
 #define EC_CHASE_THREADS 1024
-#define EC_Q 6144   // queue entries per buffer (2 buffers, 48 KB of LDS)
+#define EC_Q 6000   // queue entries per buffer (2 buffers, 47 KB of LDS)
+#define EC_SEEN 4096  // direct-mapped filter of the voxels already queued for the next round (16 KB)
 __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const double *__restrict__ rho,
                                                                const int *__restrict__ labels, int8_t *known,
                                                                const int *__restrict__ seeds, int n_seeds,
                                                                int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache) {
     __shared__ int q[2][EC_Q];
     __shared__ int s_n[2];
+    __shared__ int seen[EC_SEEN];
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
     const int seed_end = min(seed_cur + per, n_seeds);
@@ -596,6 +598,8 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const dou
         if (n + take == 0) break;
         __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
         if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
+        for (int i = threadIdx.x; i < EC_SEEN; i += EC_CHASE_THREADS) seen[i] = -1;
+        __syncthreads();
         for (int e = threadIdx.x; e < n + take; e += EC_CHASE_THREADS) {
             const int v = e < n ? q[cur][e] : seeds[seed_cur + e - n];
             unsigned int later;
@@ -610,6 +614,15 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const dou
             const unsigned int old = atomicAnd(wp, ~((d == 1 ? 0x02u : 0x08u) << sh));
             const bool won = ((old >> sh) & 0xffu) == 0xFEu;
             if (!won || !later) continue;
+            // a voxel woken by several of its earlier neighbours in the same round is queued once (the filter
+            // may miss duplicates on a slot collision: they are only evaluated twice, see above)
+#pragma unroll
+            for (int j = 0; j < 27; j++)
+                if ((later >> j) & 1u) {
+                    const int l = ec_later_voxel(g, rows, z, z_inner, j);
+                    if (atomicExch(&seen[(unsigned)(l * 0x9E3779B1u) >> 20], l) == l) later &= ~(1u << j);
+                }
+            if (!later) continue;
             int at = atomicAdd(&s_n[cur ^ 1], __popc(later));
 #pragma unroll
             for (int j = 0; j < 27; j++)
