@@ -921,7 +921,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1);
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
     k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
-    k_ec_finish<<<nblocks((c->N + 15) / 16), TPB, 0, c->stream>>>(c->known, c->N, c->counters64);
+    k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64);
     HIPCHK(hipGetLastError());
     unsigned long long r[2];
     HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));

@@ -656,13 +656,13 @@ __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restri
                                                   const int *__restrict__ list, int n, const int8_t *st,
                                                   unsigned long long *checked) {
     const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n || st[t] != 1) return;
-    const int v = list[t];
+    const bool act = t < n && st[t] == 1;
+    const int v = act ? list[t] : 0;
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
     unsigned int nchk = 0;
-    for (int ex = -1; ex < 2; ex++) {
+    for (int ex = -1; ex < 2 && act; ex++) {
         const int tx = wrapi(x + ex, g.nx);
         for (int ey = -1; ey < 2; ey++) {
             const int ty = wrapi(y + ey, g.ny);
@@ -677,7 +677,8 @@ __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restri
             }
         }
     }
-    if (nchk) atomicAdd(checked, (unsigned long long)nchk);
+    for (int o = 32; o > 0; o >>= 1) nchk += __shfl_down(nchk, o);  // one atomic per wave (lanes that returned early hold 0)
+    if (threadIdx.x % XB_WAVE == 0 && nchk) atomicAdd(checked, (unsigned long long)nchk);
 }
 // restore processed edge&max voxels (untouched by their own box) to -2
 __global__ void k_ec_restore(int8_t *known, const int *list, int n) {
@@ -686,21 +687,29 @@ __global__ void k_ec_restore(int8_t *known, const int *list, int n) {
     const int8_t k = known[list[t]];
     if (k == EC_PROC || k == EC_SKIP) known[list[t]] = -2;
 }
-// count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread
+// count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread and step, one atomic per block
 __global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges) {
-    const long long base = ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
+    __shared__ unsigned int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     unsigned int cnt = 0;
-    if (base + 16 <= N) {
-        uint4 w = *reinterpret_cast<const uint4 *>(known + base);
-        int8_t *b = reinterpret_cast<int8_t *>(&w);
+    for (long long base = ((long long)blockIdx.x * TPB + threadIdx.x) * 16; base < N; base += (long long)gridDim.x * TPB * 16) {
+        if (base + 16 <= N) {
+            uint4 w = *reinterpret_cast<const uint4 *>(known + base);
+            int8_t *b = reinterpret_cast<int8_t *>(&w);
+            unsigned int c = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (b[k] == -3) { b[k] = -2; cnt++; }
-        if (cnt) *reinterpret_cast<uint4 *>(known + base) = w;
-    } else {
-        for (long long k = base; k < N; k++)
-            if (known[k] == -3) { known[k] = -2; cnt++; }
+            for (int k = 0; k < 16; k++)
+                if (b[k] == -3) { b[k] = -2; c++; }
+            if (c) *reinterpret_cast<uint4 *>(known + base) = w;
+            cnt += c;
+        } else {
+            for (long long k = base; k < N; k++)
+                if (known[k] == -3) { known[k] = -2; cnt++; }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if (threadIdx.x % XB_WAVE == 0 && cnt) atomicAdd(edges, (unsigned long long)cnt);
+    if (threadIdx.x % XB_WAVE == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(edges, (unsigned long long)s_cnt);
 }
