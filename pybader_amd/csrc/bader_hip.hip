@@ -554,7 +554,7 @@ static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks) {
         // the seed cubes, which are trapping regions on their own
         int *blab = kill_converged ? buf[cur] : seed;
         HIPCHK(hipMemsetAsync(c->counters + 11, 0, sizeof(int), c->stream));
-        k_count_positive<<<(nbr + 255) / 256, 256, 0, c->stream>>>(blab, nbr, c->counters + 11);
+        k_count_positive<<<64, TPB, 0, c->stream>>>(blab, nbr, c->counters + 11);
         int ncertain = 0;
         if (int rc = read_counter(c, 11, &ncertain)) return rc;
         c->box_voxels = (long long)ncertain * BRK * BRK * BRK;
@@ -626,7 +626,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
                 int *walk = c->blab + nbr;  // next scratch slice of `list` (see ensure_grad)
                 HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
-                k_brick_walk_list<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
+                k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
                                                                          (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, c->counters + 13);
                 if (c->has_vacuum) {
                     k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],

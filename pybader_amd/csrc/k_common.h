@@ -102,3 +102,27 @@ __device__ __forceinline__ void note_maximum_wave(bool has, int m, int v, int *f
         todo &= ~__ballot(mine);
     }
 }
+
+// Block-wide exclusive scan of a small per-thread count (TPB threads); returns the offset of this
+// thread and the block total.
+__device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
+    __shared__ int wsum[TPB / XB_WAVE];
+    const int lane = threadIdx.x % XB_WAVE, w = threadIdx.x / XB_WAVE;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < XB_WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == XB_WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int q = 0; q < TPB / XB_WAVE; q++) {
+        if (q < w) base += wsum[q];
+        total += wsum[q];
+    }
+    __syncthreads();
+    return base + incl - cnt;
+}

@@ -40,30 +40,6 @@ __device__ __forceinline__ void classify27(const Grid &g, const double *__restri
         if (nb[k] >= 0 && rho[nb[k]] > max_val) is_max = false;
 }
 
-// Block-wide exclusive scan of a small per-thread count (TPB threads); returns the offset of this
-// thread and the block total.
-__device__ __forceinline__ int block_scan_excl(int cnt, int &total) {
-    __shared__ int wsum[TPB / XB_WAVE];
-    const int lane = threadIdx.x % XB_WAVE, w = threadIdx.x / XB_WAVE;
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < XB_WAVE; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == XB_WAVE - 1) wsum[w] = incl;
-    __syncthreads();
-    int base = 0;
-    total = 0;
-#pragma unroll
-    for (int q = 0; q < TPB / XB_WAVE; q++) {
-        if (q < w) base += wsum[q];
-        total += wsum[q];
-    }
-    __syncthreads();
-    return base + incl - cnt;
-}
-
 // buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
 // Lets the edge sweep skip tiles whose whole 3x3x3 surroundings carry one label (no edge possible).
 #define XB_MIXED (-2147483647 - 1)
@@ -423,9 +399,11 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
             if (moving) {
                 const bool in_win = plane_in_window(g, qx);
                 const GradRec nr = fetch_rec(G, in_win ? lq : lp);
-                if (!plane_valid(g, qx)) { result = -4; moving = false; }
+                const bool ok_plane = plane_valid(g, qx);
+                const int8_t kq = known[ok_plane ? lq : lp];  // in flight together with the record
+                if (!ok_plane) { result = -4; moving = false; }
                 else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
-                else if (known[lq] == 2) { result = lq; moving = false; }  // refinement.py:294-303
+                else if (kq == 2) { result = lq; moving = false; }  // refinement.py:294-303
                 else {
                     w.push(lq, nr.key);
                     px = qx; py = qy; pz = qz; lp = lq; rec = nr;

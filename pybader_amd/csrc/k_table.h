@@ -454,8 +454,10 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow(int nb0, int nb1, i
         if (l != first) *changed = 1;
     }
 }
-__global__ void k_count_positive(const int *__restrict__ a, int n, int *count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long b = __ballot(i < n && a[i] > 0);
-    if (threadIdx.x % XB_WAVE == 0 && b) atomicAdd(count, __popcll(b));
+__global__ __launch_bounds__(TPB) void k_count_positive(const int *__restrict__ a, int n, int *count) {
+    int cnt = 0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) cnt += (a[i] > 0);
+    int total;
+    block_scan_excl(cnt, total);
+    if (threadIdx.x == 0 && total) atomicAdd(count, total);
 }

@@ -87,16 +87,25 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions4(GridL g, int *labels, 
         *p = m;
     }
 }
-__global__ void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab, int *walk, int *n_walk) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;   // bricks [b_lo, b_hi) are the owned slab
-    const bool hit = b < nbr && b >= b_lo && b < b_hi && blab[b] <= 0;
-    const unsigned long long m = __ballot(hit);
-    if (!m) return;
-    const int lane = threadIdx.x % XB_WAVE;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(n_walk, __popcll(m));
-    base = __shfl(base, 0);
-    if (hit) walk[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+// 16 bricks per thread, one atomic per block; the list keeps brick order inside a block's range
+__global__ __launch_bounds__(TPB) void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab,
+                                                         int *walk, int *n_walk) {
+    const int base = (blockIdx.x * TPB + threadIdx.x) * 16;   // bricks [b_lo, b_hi) are the owned slab
+    unsigned int hits = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int b = base + k;
+        if (b < nbr && b >= b_lo && b < b_hi && blab[b] <= 0) hits |= 1u << k;
+    }
+    int total;
+    const int off = block_scan_excl(__popc(hits), total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(n_walk, total) : 0;
+    __syncthreads();
+    int w = base_s + off;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if ((hits >> k) & 1u) walk[w++] = base + k;
 }
 
 __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
