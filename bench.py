@@ -147,23 +147,22 @@ def main():
     # HIP-event timings on the library's own stream (xb_kernel_time)
     tm = {name: ctx.kernel_time(i) for i, name in enumerate(
         ['assign_after_table(fill+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
-         'table_build(k_grad_field+trapping_regions)', 'k_grad_field'])}
+         'table_build(k_grad_field+trapping_regions)', 'k_grad_field', 'k_ng_trace'])}
     avg = {k: (ms / n if n else 0.0) for k, (ms, n) in tm.items()}
-    # the dominant single kernel of the path
+    # the dominant single kernel of the path (HIP events around that launch alone)
     if args.method == 'neargrid':
-        dom = 'k_grad_field' if avg['k_grad_field'] >= avg['assign_after_table(fill+k_ng_trace)'] else 'k_ng_trace'
-        k_avg = max(avg['k_grad_field'], avg['assign_after_table(fill+k_ng_trace)'])
-        k_n = tm['k_grad_field'][1]
+        dom = 'k_grad_field' if avg['k_grad_field'] >= avg['k_ng_trace'] else 'k_ng_trace'
+        k_avg, k_n = avg[dom], tm[dom][1]
         own_frac = (runner.x_range[1] - runner.x_range[0]) / shape[0]
         units = nvox * own_frac   # voxels this rank labels (its k_grad_field also covers the window margin)
     else:
         dom, k_avg, k_n, units = 'k_og_pointer', avg['k_og_pointer'], tm['k_og_pointer'][1], nvox
     achieved = BYTES_ASSIGN * units / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (same command, 512^3):
-    # profiles/r1_final_pmc_fetch_write_512_neargrid.txt -- FETCH_SIZE + WRITE_SIZE as reported
+    # profiles/r1_final_pmc_fetch_write_512_neargrid.txt -- FETCH_SIZE + WRITE_SIZE as reported (KB)
     traffic = None
     if args.size == 512 and args.method == 'neargrid' and world == 1:
-        traffic = {'k_grad_field': (1306675 + 4196352) * 1024.0, 'k_ng_trace': (4043183 + 215972) * 1024.0}[dom]
+        traffic = {'k_grad_field': (1314837 + 4196359) * 1024.0, 'k_ng_trace': (4143464 + 213697) * 1024.0}[dom]
 
     out = {
         'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',

@@ -147,12 +147,13 @@ int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that ho
 /* HIP-event timing of the dominant kernel, measured on the context's stream: accumulated
  * milliseconds and launch count since the last reset.  which: 0 neargrid assignment after the table
  * (region fill + walker trace), 1 ongrid pointer, 2 edge_find, 3 refine trace, 4 whole table build
- * (gradient field + trapping regions), 5 k_grad_field alone. */
+ * (gradient field + trapping regions), 5 k_grad_field alone, 6 k_ng_trace alone. */
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);
 /* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order;
- * key 1: trapping boxes on/off) */
+ * key 1: trapping boxes bit0 / brick growth bit1; key 2: trace threads per block; key 3: debug prints;
+ * key 4: workgroups of the edge_check chase) */
 int xb_set_option(xb_ctx *c, int key, int value);
 /* statistics of the last assignment: trapping boxes found and voxels they cover */
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);

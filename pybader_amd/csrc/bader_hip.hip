@@ -99,7 +99,7 @@ struct xb_ctx {
     bool list_valid = false;   // ... when this is set (by xb_edge_find)
     bool timing = false;
     int opt_trace = 1;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
-    TimedKernel tk[6];
+    TimedKernel tk[8];
     long long n_alloc = 0;
 };
 
@@ -644,6 +644,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 c->n_walk = nwalk;
                 if (nwalk) {
                     const long long waves = 8LL * nwalk;
+                    ScopedTimer tw(c, 6);
                     k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
                         light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
                         c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
@@ -1199,7 +1200,7 @@ int xb_kernel_time_reset(xb_ctx *c) {
     return XB_OK;
 }
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches) {
-    if (!c || which < 0 || which > 5) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
+    if (!c || which < 0 || which > 7) return fail(XB_E_ARG, "xb_kernel_time: bad argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     TimedKernel &t = c->tk[which];
