@@ -63,6 +63,7 @@ struct xb_ctx {
     int opt_bricks = 1;
     int opt_dbg = 0;
     int opt_ec_groups = 64;     // workgroups of k_ec_chase
+    int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
@@ -904,7 +905,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
             HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
             const int groups = (int)std::min<long long>(std::max(1, n_seeds / 512), c->opt_ec_groups);
             k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->rho, c->labels, c->known, buf[pass & 1], n_seeds,
-                                                                   buf[1 - (pass & 1)], c->counters + 6, cap, c->st);
+                                                                   buf[1 - (pass & 1)], c->counters + 6, cap, c->st, c->opt_ec_qcap);
             HIPCHK(hipGetLastError());
             const int before = n_seeds;
             if (int rc = read_counter(c, 6, &n_seeds)) return rc;
@@ -1166,6 +1167,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
     else if (key == 3) c->opt_dbg = value;
     else if (key == 4 && value >= 1 && value <= 4096) c->opt_ec_groups = value;
+    else if (key == 5 && value >= 2 && value <= EC_Q) c->opt_ec_qcap = value;
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;

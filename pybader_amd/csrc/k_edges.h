@@ -561,7 +561,8 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, const double *__restri
 __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const double *__restrict__ rho,
                                                                const int *__restrict__ labels, int8_t *known,
                                                                const int *__restrict__ seeds, int n_seeds,
-                                                               int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache) {
+                                                               int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache,
+                                                               int qcap) {
     __shared__ int q[2][EC_Q];
     __shared__ int s_n[2];
     __shared__ int seen[EC_SEEN];
@@ -571,8 +572,8 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const dou
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
     for (int cur = 0;; cur ^= 1) {
-        const int n = min(s_n[cur], EC_Q);
-        const int take = n <= EC_Q / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
+        const int n = min(s_n[cur], qcap);  // qcap <= EC_Q (smaller only to exercise the overflow path in tests)
+        const int take = n <= qcap / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
         if (n + take == 0) break;
         __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
         if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const dou
             for (int j = 0; j < 27; j++)
                 if ((later >> j) & 1u) {
                     const int l = ec_later_voxel(g, rows, z, z_inner, j);
-                    if (at < EC_Q) q[cur ^ 1][at] = l;
+                    if (at < qcap) q[cur ^ 1][at] = l;
                     else {
                         const int o = atomicAdd(n_ovf, 1);
                         if (o < ovf_cap) ovf[o] = l;

@@ -240,6 +240,23 @@ def test_against_oracle_seeded(ctx, seed, shape, tol):
         assert np.array_equal(ctx.download_labels(omain.dtype), v), mode
 
 
+@pytest.mark.parametrize('groups,qcap', [(1, 2), (2, 16), (64, 6000)])
+def test_edge_check_queue_overflow_hand_over(ctx, groups, qcap):
+    """The chase kernel's LDS queues, shrunk to a few entries, spill into the overflow list that seeds
+    the next launch: logs, map and flags must still equal the reference's (golden 'changed' run)."""
+    g, rho = setup_case(ctx, 'c64_cubic')
+    ctx.set_option(4, groups)
+    ctx.set_option(5, qcap)
+    try:
+        ctx.upload_labels(g['ng_main'])
+        log = ctx.refine('changed', -1)
+        assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['ng_changed_inf_log'])
+        assert np.array_equal(ctx.download_labels(g['ng_changed_inf'].dtype), g['ng_changed_inf'])
+    finally:
+        ctx.set_option(4, 64)
+        ctx.set_option(5, 6000)
+
+
 def test_edge_check_kernel_level(ctx):
     """edge_check alone on a hand-made `known`: every voxel of a random subset flagged changed."""
     import oracle
