@@ -135,6 +135,8 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.kernel_time_reset()
+    if runner.timing is not None:
+        runner.timing.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -196,6 +198,10 @@ def main():
                      'stage_ms_avg': avg},
     }
 
+    out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
+    out['config']['refine_escape_fallbacks'] = runner.n_fallbacks
+    if runner.timing is not None:   # XB_SLAB_TIMING=1: wall-clock per scheduler phase (adds a device sync around each)
+        out['config']['slab_phase_ms_avg'] = {k: v / args.steps * 1e3 for k, v in runner.timing.items()}
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, (rho_s, dm_s, tg_s, want, bmax) = cpu_baseline(args.cpu_size, args.method, mode, iters,
                                                            lattice, atoms, background)

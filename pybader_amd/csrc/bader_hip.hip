@@ -158,7 +158,7 @@ int xb_create(int device, xb_ctx **out) {
     HIPCHK(hipMalloc(&c->counters, 64 * sizeof(int)));
     HIPCHK(hipMalloc(&c->counters64, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->dsum, 16 * sizeof(double)));
-    HIPCHK(hipMalloc(&c->dist_dev, 27 * sizeof(double)));
+    HIPCHK(hipMalloc(&c->dist_dev, 36 * sizeof(double)));  // dist_mat (27) then T_grad (9): make_rec_rho
     HIPCHK(hipMalloc(&c->boxbuf, (size_t)(1 << 20) * sizeof(int)));
     HIPCHK(hipHostMalloc(&c->host_ints, 64 * sizeof(long long)));
     *out = c;
@@ -241,6 +241,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     if (dist_mat) {
         memcpy(g.dist, dist_mat, sizeof g.dist);
         HIPCHK(hipMemcpyAsync(c->dist_dev, dist_mat, sizeof g.dist, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->dist_dev + 27, T_grad, sizeof g.T, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (T_grad && memcmp(g.T, T_grad, sizeof g.T) != 0) { memcpy(g.T, T_grad, sizeof g.T); c->grad_valid = false; }
@@ -646,19 +647,19 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 if (nwalk) {
                     const long long waves = 8LL * nwalk;
                     ScopedTimer tw(c, 6);
-                    k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
+                    (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
                         light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
                         c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                        maxsteps, opt);
+                        maxsteps, opt, c->rho, c->dist_dev);
                 }
             } else {
                 const long long waves = (opt & 1)
                     ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
                     : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
-                k_ng_trace<2><<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
+                (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
                     light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], nullptr, 0, c->labels,
                     c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                    maxsteps, opt);
+                    maxsteps, opt, c->rho, c->dist_dev);
             }
         }
         HIPCHK(hipGetLastError());
@@ -856,9 +857,9 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
         if (int rc = ensure_grad(c, false, false)) return rc;
         {
             ScopedTimer t(c, 3);
-            k_refine_trace<2><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n,
+            (table_windowed(c) ? k_refine_trace<2, true> : k_refine_trace<2, false>)<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n,
                                                                 c->counters + 2, c->counters + 3, c->ovf_list,
-                                                                c->counters + 1, c->ovf_cap, maxsteps);
+                                                                c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev);
         }
         HIPCHK(hipGetLastError());
         int novf = 0;

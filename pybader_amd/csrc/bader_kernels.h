@@ -202,4 +202,51 @@ struct PathWindow {
     }
 };
 
+// The table record of voxel (x,y,z) derived from rho on the spot -- the arithmetic of k_grad_field, operation
+// for operation -- for the few trajectories that leave the table window of a slab (multi-GPU): they carry
+// on with ~33 loads per step instead of one gather, and never need the exact slow kernel for that.
+// gc: dist_mat (27 doubles) followed by T_grad (9 doubles) in device memory.
+struct TGradView { double T[9]; };
+__device__ __noinline__ GradRec make_rec_rho(const GridL &g, const double *__restrict__ rho,
+                                             const double *__restrict__ gc, int x, int y, int z) {
+    const int v = (x * g.ny + y) * g.nz + z;
+    const double c = rho[v];
+    double max_val = c;
+    int og = XB_OG_SELF;
+    for (int ix = 0; ix < 3; ix++) {
+        const int tx = wrapi(x + ix - 1, g.nx);
+        for (int iy = 0; iy < 3; iy++) {
+            const int ty = wrapi(y + iy - 1, g.ny);
+            for (int iz = 0; iz < 3; iz++) {
+                const int tz = wrapi(z + iz - 1, g.nz);
+                double w = rho[(tx * g.ny + ty) * g.nz + tz];
+                w = (w - c) * gc[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+                w += c;
+                if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
+            }
+        }
+    }
+    TGradView t;
+    for (int k = 0; k < 9; k++) t.T[k] = gc[27 + k];
+    const int xp = wrapi(x + 1, g.nx), xm = wrapi(x - 1, g.nx);
+    const int yp = wrapi(y + 1, g.ny), ym = wrapi(y - 1, g.ny);
+    const int zp = wrapi(z + 1, g.nz), zm = wrapi(z - 1, g.nz);
+    GradRec o;
+    double d0, d1, d2;
+    int code;
+    if (ng_dir_vals(t, c, rho[(xp * g.ny + y) * g.nz + z], rho[(xm * g.ny + y) * g.nz + z], rho[(x * g.ny + yp) * g.nz + z],
+                    rho[(x * g.ny + ym) * g.nz + z], rho[(x * g.ny + y) * g.nz + zp], rho[(x * g.ny + y) * g.nz + zm], d0, d1, d2)) {
+        o.r0 = o.r1 = o.r2 = 0.;
+        code = XB_STAY_CODE;
+    } else {
+        const int i0 = rha_cs(d0), i1 = rha_cs(d1), i2 = rha_cs(d2);
+        o.r0 = d0 - (double)i0;
+        o.r1 = d1 - (double)i1;
+        o.r2 = d2 - (double)i2;
+        code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
+    }
+    o.key = pack_key(c, code, og);
+    return o;
+}
+
 enum { TR_STEP = 0, TR_NEED_OG = 1, TR_DONE = 2 };

@@ -348,11 +348,12 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int 
 // write their own start voxel, so they are independent -- exactly as in the reference, where the
 // +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool WIN>
 __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n,
                                                       int *changed, int *escaped, int *ovf_list, int *ovf_count,
-                                                      int ovf_cap, int maxsteps) {
+                                                      int ovf_cap, int maxsteps, const double *__restrict__ rho,
+                                                      const double *__restrict__ gc) {
     const int t = blockIdx.x * TPB + threadIdx.x;
     const bool valid = t < n;
     const int v = valid ? list[t] : 0;
@@ -398,11 +399,12 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
             }
             if (moving) {
                 const bool in_win = plane_in_window(g, qx);
-                const GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                GradRec nr = fetch_rec(G, in_win ? lq : lp);
                 const bool ok_plane = plane_valid(g, qx);
                 const int8_t kq = known[ok_plane ? lq : lp];  // in flight together with the record
+                if (WIN && ok_plane && !in_win) nr = make_rec_rho(g, rho, gc, qx, qy, qz);  // outside the table window: from rho
                 if (!ok_plane) { result = -4; moving = false; }
-                else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
+                else if ((!WIN && !in_win) || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
                 else if (kq == 2) { result = lq; moving = false; }  // refinement.py:294-303
                 else {
                     w.push(lq, nr.key);

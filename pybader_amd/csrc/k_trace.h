@@ -112,13 +112,16 @@ __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
     ox = og / 9 - 1; oy = (og / 3) % 3 - 1; oz = og % 3 - 1;
 }
 
-template <int K>
+// WIN: the table covers only a window of the grid (slabs); records outside it are derived from rho on the
+// spot.  The single-GPU instantiation leaves that (register hungry) path out.
+template <int K, bool WIN>
 __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
                                                   const int *__restrict__ box_max, const int *__restrict__ blab,
                                                   int nb1, int nb2, const int *__restrict__ walk, int n_walk,
                                                   int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
-                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt) {
+                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt,
+                                                  const double *__restrict__ rho, const double *__restrict__ gc) {
     // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
     // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
     // whose trajectories read the same table lines -- share one L2.
@@ -198,14 +201,15 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
             }
             if (moving) {
                 const bool in_win = plane_in_window(g, qx);  // the table only exists inside the window (slabs)
-                const GradRec nr = fetch_rec(G, in_win ? lq : lp);  // issued before the brick label: both in flight
+                GradRec nr = fetch_rec(G, in_win ? lq : lp);  // issued before the brick label: both in flight
                 const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
-                const int b = bl > 0 ? bl : (in_win ? key_box(nr.key) : 0);
+                if (WIN && !in_win && bl <= 0) nr = make_rec_rho(g, rho, gc, qx, qy, qz);  // outside the window: from rho
+                const int b = bl > 0 ? bl : key_box(nr.key);
                 if (b) {  // arrived inside a trapping region (q cannot be an old path voxel: the
                     result = box_max[b - 1];  // trajectory would have stopped there already)
                     moving = false;
-                } else if (!in_win || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
-                    result = -2;  // left the table window / membership undecidable: exact slow kernel
+                } else if ((!WIN && !in_win) || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) {
+                    result = -2;  // membership undecidable: exact slow kernel
                     moving = false;  // (ongrid moves are appended without a membership test, 305-315)
                 } else {
                     w.push(lq, nr.key);

@@ -12,6 +12,9 @@ tests) before every edge sweep.  Collectives: only tiny ones (maxima tables, cou
 
 The scheduler is written against a small backend interface so that the CPU tests can drive it with a
 host backend; the product backend is `GpuBackend` (libbader_hip.so)."""
+import os
+import time
+
 import numpy as np
 
 
@@ -120,6 +123,34 @@ class TorchComm:
         flags = [None] * self.size
         self.dist.all_gather_object(flags, ok, group=self.host_group)
         return all(flags)
+
+    def selftest_views(self, views):
+        """Second stage of the self-test, on the arrays that will really travel: zero-copy views of memory the
+        library allocated (not torch).  Plane 0 goes round the ring into the neighbour's plane 1; any
+        failure (exception or wrong payload on any rank) switches every rank to the host-staged transport.
+        Called once, right after the arrays were allocated (their contents do not matter yet)."""
+        if not self.device_p2p or self.size < 2:
+            return
+        import torch
+        ok = True
+        try:
+            nxt, prv = (self.rank + 1) % self.size, (self.rank - 1) % self.size
+            for t in views:
+                if t.shape[0] < 2:
+                    continue
+                t[0].fill_(self.rank + 1)
+                t[1].fill_(0)
+                torch.cuda.synchronize(t.device)
+                ops = [self.dist.P2POp(self.dist.irecv, t[1:2], prv), self.dist.P2POp(self.dist.isend, t[0:1], nxt)]
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+                torch.cuda.synchronize(t.device)
+                ok = ok and bool((t[1] == prv + 1).all().item())
+        except Exception:  # noqa: BLE001
+            ok = False
+        if not all(self.allgather(bool(ok))):
+            self.device_p2p = False
+            self.transport = 'host-staged-gloo'
 
     def allgather(self, obj):
         out = [None] * self.size
@@ -239,6 +270,24 @@ class GpuBackend:
         return getattr(self.ctx, name)
 
 
+class _Phase:
+    """optional wall-clock accounting of the scheduler's phases (XB_SLAB_TIMING=1; bench.py reports it)"""
+
+    def __init__(self, runner, name):
+        self.r, self.name = runner, name
+
+    def __enter__(self):
+        if self.r.timing is not None:
+            self.r.be.sync()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.r.timing is not None:
+            self.r.be.sync()
+            self.r.timing[self.name] = self.r.timing.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
 class SlabRunner:
     """bader_calc + refine over slabs; with one rank it degenerates to the single-GPU calls."""
 
@@ -252,6 +301,10 @@ class SlabRunner:
         self.sends, self.recvs = halo_plan(self.ranges, comm.rank, self.halo, self.shape[0])
         self.n_maxima = 0
         self.n_fallbacks = 0
+        self.timing = {} if os.environ.get('XB_SLAB_TIMING') else None
+        if comm.size > 1 and hasattr(comm, 'selftest_views') and hasattr(self.be, 'tensors'):
+            self.be.sync()
+            comm.selftest_views(self.be.tensors())
 
     def enable_table_window(self, margin=32):
         """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks
@@ -271,29 +324,37 @@ class SlabRunner:
         """thread_handlers.bader_calc: per-slab trajectories, then one tiny table merge for numbering."""
         if getattr(self, 'windowed', False) and method == 'neargrid':
             # windowed table: the trapping regions need every rank's maxima and brick masks
-            local = self.be.table_build()
-            seeds = sorted(set(int(v) for part in self.comm.allgather(np.asarray(local).tolist()) for v in part))
-            self.be.sync()
-            t, first, count = self.be.mask_tensor()
-            if getattr(self, '_chunks', None) is None:      # static for a given decomposition
-                self._chunks = self.comm.allgather((int(first), int(count)))
-            self.comm.gather_chunks(t, self._chunks)
-            self.be.table_finish(np.array(seeds, dtype=np.int64))
-        m, f = self.be.assign_trace(method)
-        if self.comm.size == 1:
-            order = np.argsort(f, kind='stable')
-            maxima = np.asarray(m)[order]
-        else:
-            maxima = merge_maxima_tables(self.comm.allgather((np.asarray(m), np.asarray(f))))
-        self.be.assign_finish(maxima)
+            with _Phase(self, 'table_build'):
+                local = self.be.table_build()
+            with _Phase(self, 'seeds_allgather'):
+                seeds = sorted(set(int(v) for part in self.comm.allgather(np.asarray(local).tolist()) for v in part))
+            with _Phase(self, 'mask_exchange'):
+                self.be.sync()
+                t, first, count = self.be.mask_tensor()
+                if getattr(self, '_chunks', None) is None:      # static for a given decomposition
+                    self._chunks = self.comm.allgather((int(first), int(count)))
+                self.comm.gather_chunks(t, self._chunks)
+            with _Phase(self, 'table_finish'):
+                self.be.table_finish(np.array(seeds, dtype=np.int64))
+        with _Phase(self, 'assign_trace'):
+            m, f = self.be.assign_trace(method)
+        with _Phase(self, 'maxima_merge'):
+            if self.comm.size == 1:
+                order = np.argsort(f, kind='stable')
+                maxima = np.asarray(m)[order]
+            else:
+                maxima = merge_maxima_tables(self.comm.allgather((np.asarray(m), np.asarray(f))))
+        with _Phase(self, 'assign_finish'):
+            self.be.assign_finish(maxima)
         self.n_maxima = int(maxima.shape[0])
         self.maxima = maxima
         return self.n_maxima
 
     def exchange_label_halo(self):
         if self.comm.size > 1:
-            self.be.sync()
-            self.comm.exchange(self.be.tensors()[0], self.sends, self.recvs)
+            with _Phase(self, 'label_halo'):
+                self.be.sync()
+                self.comm.exchange(self.be.tensors()[0], self.sends, self.recvs)
 
     def gather_all_planes(self):
         """Fallback exchange: every rank receives every other rank's owned label and known planes."""
@@ -304,11 +365,13 @@ class SlabRunner:
             self.comm.exchange(t, sends, recvs)
 
     def _trace(self):
-        changed, escaped = self.be.refine_trace()
+        with _Phase(self, 'refine_trace'):
+            changed, escaped = self.be.refine_trace()
         if self.comm.size == 1:
             assert escaped == 0
             return changed
-        changed, escaped = self.comm.sum(changed, escaped)
+        with _Phase(self, 'sums'):
+            changed, escaped = self.comm.sum(changed, escaped)
         if escaped:
             # Some retraces walked out of [x0-halo+2, x1+halo-2) before meeting a known==2 voxel.
             # They were parked (known == -6) untouched.  Make the whole grid valid on every rank --
@@ -330,9 +393,11 @@ class SlabRunner:
         if iters == 0:
             return log
         self.exchange_label_halo()
-        edges = self.be.edge_find()
+        with _Phase(self, 'edge_find'):
+            edges = self.be.edge_find()
         if self.comm.size > 1:
-            edges, = self.comm.sum(edges)
+            with _Phase(self, 'sums'):
+                edges, = self.comm.sum(edges)
         if edges == 0:
             return log
         changed = self._trace()
