@@ -59,7 +59,9 @@ def main():
     ap.add_argument('--refine', default='changed:2')
     ap.add_argument('--cpu-size', type=int, default=320)
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--halo', type=int, default=8)
+    ap.add_argument('--halo', type=int, default=None,
+                    help='label planes valid each side of a slab (default 64 for N > 1: retraces glide along the '
+                         'dividing surfaces for tens of planes; the rest is finished by remote path queries)')
     ap.add_argument('--table-margin', type=int, default=32,
                     help='planes of gradient-field table each side of a slab (N > 1)')
     args = ap.parse_args()
@@ -106,7 +108,8 @@ def main():
 
     dev_index = dev_index if world > 1 else 0
     ctx = _lib.Context(dev_index)
-    runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=args.halo)
+    halo = args.halo if args.halo is not None else (64 if world > 1 else 8)
+    runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=halo)
     windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
     ctx.enable_timing(True)

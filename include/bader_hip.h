@@ -95,6 +95,18 @@ int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped);
 /* slab fallback: escaped traces are parked as known == -6; after the scheduler made the whole grid
  * valid on this rank (all-gather of labels + known, xb_set_halo(nx)) this call retraces exactly them. */
 int xb_refine_trace_escaped(xb_ctx *c, int64_t *changed, int64_t *escaped);
+/* slab scheduler, escaped retraces without bulk traffic: the dr=0 trajectory of every parked voxel
+ * (known == -6) of the owned slab -- it depends on the replicated rho only -- from the point where it first
+ * leaves this rank's valid planes (the fast retrace already walked the part before without finding a stop).
+ * The scheduler asks the owners of the path voxels for (label, known) with xb_gather_voxels, finds the first
+ * known == 2 voxel (refinement.py:294-303) or the maximum, and writes the outcome back with
+ * xb_scatter_voxels.  Layout: offsets has n_paths + 1 entries; voxels[offsets[i]] is the start voxel of path
+ * i, the rest of path i follows (linear indices).  Trajectories are followed for at most max_len voxels;
+ * complete[i] = 1 when path i reached its maximum, else ask again with a larger max_len. */
+int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_voxels);
+int xb_escaped_paths_fetch(xb_ctx *c, int64_t *starts, int64_t *offsets, int64_t *voxels, int8_t *complete);
+int xb_gather_voxels(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *labels_out, int8_t *known_out);
+int xb_scatter_voxels(xb_ctx *c, const int64_t *idx, int64_t n, const int32_t *labels_in, const int8_t *known_in);
 /* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels) */
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
 /* thread_handlers.refine (thread_handlers.py:128-236): the iteration driver on one GPU.

@@ -48,6 +48,8 @@ def lib():
         L.orc_refine_neargrid.argtypes = [_i8p, _i8p, _f64p, _i64p, _i32p, _f64p, _f64p]
         L.orc_own_trajectory.restype = None
         L.orc_own_trajectory.argtypes = [_f64p, _i64p, _i32p, _f64p, _f64p, _i64p]
+        L.orc_trajectory_path.restype = C.c_int64
+        L.orc_trajectory_path.argtypes = [_f64p, _i64p, _f64p, _f64p, C.c_int64, _i64p, C.c_int64]
         L.orc_vacuum_assign.restype = None
         L.orc_vacuum_assign.argtypes = [_f64p, _i32p, C.c_double, _f64p, C.c_double, C.c_int64,
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -179,6 +181,16 @@ def own_trajectory_map(density, volumes, dist_mat, T_grad):
     lib().orc_own_trajectory(_c(density, np.float64), _shape(density), _c(volumes, np.int32),
                              _c(dist_mat, np.float64), _c(T_grad, np.float64), out)
     return out
+
+
+def trajectory_path(density, dist_mat, T_grad, start, cap=1 << 16):
+    """Linear voxel indices of the own (dr=0) trajectory of `start`, maximum last."""
+    out = np.empty(cap, dtype=np.int64)
+    n = lib().orc_trajectory_path(_c(density, np.float64), _shape(density), _c(dist_mat, np.float64),
+                                  _c(T_grad, np.float64), int(start), out, cap)
+    if n < 0:
+        raise RuntimeError('trajectory longer than the buffer')
+    return out[:n].copy()
 
 
 def vacuum_assign(reference, volumes, vac_tol, density, voxel_volume):

@@ -417,6 +417,34 @@ void orc_own_trajectory(const double *rho, const int64_t shape[3], const lab_t *
     free(mark); free(path.v);
 }
 
+/* The voxels of one own (dr=0) trajectory, start voxel first, maximum last -- the same stepping as
+ * orc_own_trajectory.  Returns the path length (or -1 when it does not fit `cap`).  Test infrastructure for
+ * the slab scheduler's remote path queries (pybader_amd/slab.py:_resolve_escaped). */
+int64_t orc_trajectory_path(const double *rho, const int64_t shape[3], const double *dist, const double *T,
+                            int64_t start, int64_t *out, int64_t cap) {
+    grid_t g; grid_init(&g, rho, shape, dist, T);
+    int64_t p[3] = {start / (shape[1] * shape[2]), (start / shape[2]) % shape[1], start % shape[2]}, pd[3];
+    double dr[3] = {0., 0., 0.};
+    int64_t n = 0;
+    if (cap < 1) return -1;
+    out[n++] = start;
+    for (;;) {
+        ng_step(&g, 1, p, dr, pd);
+        int64_t lpk = lin(&g, pd);
+        int seen = 0;
+        for (int64_t j = n - 1; j >= 0 && !seen; j--) seen = (out[j] == lpk);
+        if (seen) {
+            dr[0] = dr[1] = dr[2] = 0.;
+            og_step(&g, p, pd);
+            lpk = lin(&g, pd);
+            if (pd[0] == p[0] && pd[1] == p[1] && pd[2] == p[2]) return n;
+        }
+        if (n >= cap) return -1;
+        p[0] = pd[0]; p[1] = pd[1]; p[2] = pd[2];
+        out[n++] = lpk;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * utils.* helpers on the path
  * ---------------------------------------------------------------------------------------- */

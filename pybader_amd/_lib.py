@@ -39,6 +39,10 @@ SYMBOLS = {
     'xb_edge_find': (_int, [_vp, _pi64]),
     'xb_refine_trace': (_int, [_vp, _pi64, _pi64]),
     'xb_refine_trace_escaped': (_int, [_vp, _pi64, _pi64]),
+    'xb_escaped_paths': (_int, [_vp, _i64, _pi64, _pi64]),
+    'xb_escaped_paths_fetch': (_int, [_vp, _vp, _vp, _vp, _vp]),
+    'xb_gather_voxels': (_int, [_vp, _vp, _i64, _vp, _vp]),
+    'xb_scatter_voxels': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'xb_edge_check': (_int, [_vp, _pi64, _pi64]),
     'xb_refine': (_int, [_vp, _int, _i64, _vp, _i64, _pi64]),
     'xb_charge_sum': (_int, [_vp, _dbl, _i64, _vp, _vp]),
@@ -221,6 +225,32 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_refine_trace_escaped(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def escaped_paths(self, max_len=1 << 15):
+        """(starts, offsets, voxels, complete): for every parked (known == -6) voxel of the owned slab its start
+        voxel followed by its trajectory from the first voxel outside the valid planes on; trajectories are
+        followed for at most max_len voxels, complete[i] tells whether path i reached its maximum"""
+        n, m = C.c_int64(), C.c_int64()
+        check(self.lib.xb_escaped_paths(self.h, int(max_len), C.byref(n), C.byref(m)))
+        starts = np.zeros(n.value, np.int64)
+        offsets = np.zeros(n.value + 1, np.int64)
+        vox = np.zeros(m.value, np.int64)
+        complete = np.zeros(n.value, np.int8)
+        check(self.lib.xb_escaped_paths_fetch(self.h, _ptr(starts), _ptr(offsets), _ptr(vox), _ptr(complete)))
+        return starts, offsets, vox, complete.astype(bool)
+
+    def gather_voxels(self, idx):
+        idx = np.ascontiguousarray(idx, np.int64)
+        lab = np.zeros(idx.size, np.int32)
+        kn = np.zeros(idx.size, np.int8)
+        check(self.lib.xb_gather_voxels(self.h, _ptr(idx), idx.size, _ptr(lab), _ptr(kn)))
+        return lab, kn
+
+    def scatter_voxels(self, idx, labels, known):
+        idx = np.ascontiguousarray(idx, np.int64)
+        lab = np.ascontiguousarray(labels, np.int32)
+        kn = np.ascontiguousarray(known, np.int8)
+        check(self.lib.xb_scatter_voxels(self.h, _ptr(idx), idx.size, _ptr(lab), _ptr(kn)))
 
     def edge_check(self):
         a, b = C.c_int64(), C.c_int64()

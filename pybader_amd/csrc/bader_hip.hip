@@ -64,6 +64,8 @@ struct xb_ctx {
     int opt_dbg = 0;
     int opt_ec_groups = 64;     // workgroups of k_ec_chase
     int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
+    std::vector<int64_t> esc_starts, esc_offsets, esc_vox;  // xb_escaped_paths -> xb_escaped_paths_fetch
+    std::vector<int8_t> esc_complete;
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
@@ -586,7 +588,7 @@ static int run_slow(xb_ctx *c, int n, int refine) {
         k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
                                                          c->ovf_list + o, m, path, lmax, refine, c->first,
                                                          c->max_list, c->counters + 0, c->max_cap,
-                                                         c->counters + 2, c->counters + 3, c->counters + 8);
+                                                         c->counters + 2, c->counters + 3, c->counters + 8, nullptr);
     }
     hipError_t e = hipGetLastError();
     int err = 0;
@@ -838,6 +840,112 @@ static int compact(xb_ctx *c, int value, int *n_out) {
     k_compact_known16<<<nblocks((own + 15) / 16), TPB, 0, c->stream>>>(light(g), c->known, value, c->list, c->counters + 5);
     HIPCHK(hipGetLastError());
     return read_counter(c, 5, n_out);
+}
+
+// ---- remote path queries (slab scheduler) -------------------------------------------------------
+// A retrace that left the valid planes of its rank was parked (known == -6).  Its path depends on rho
+// only (replicated), so the owner can record it in full; which voxel of the path stops the retrace
+// (the first known == 2 one, refinement.py:294-303) is then asked of the ranks that own those voxels.
+int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_voxels) {
+    NEED_GRID("xb_escaped_paths");
+    c->esc_starts.clear(); c->esc_offsets.assign(1, 0); c->esc_vox.clear(); c->esc_complete.clear();
+    int n = 0;
+    if (int rc = compact(c, -6, &n)) return rc;
+    c->list_valid = false;
+    if (n) {
+        if (max_len < 2 || max_len > (1 << 15)) return fail(XB_E_ARG, "xb_escaped_paths: max_len out of range");
+        const int lmax = (int)max_len, chunk = (int)std::max<int64_t>(256, std::min<int64_t>(8192, (32LL << 20) / max_len));
+        int *path = nullptr, *dlen = nullptr, *packed = nullptr;
+        HIPCHK(hipMalloc(&path, (size_t)chunk * lmax * sizeof(int)));
+        HIPCHK(hipMalloc(&dlen, 3 * chunk * sizeof(int)));   // lengths, first out-of-range indices, offsets
+        std::vector<int> starts(n), len(2 * chunk), off(chunk), buf;
+        HIPCHK(hipMemcpyAsync(starts.data(), c->list, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int rc = XB_OK;
+        for (int o = 0; o < n && rc == XB_OK; o += chunk) {
+            const int m = std::min(chunk, n - o);
+            int *dfirst = dlen + m, *doff = dlen + 2 * chunk;
+            k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, c->list + o, m, path,
+                                                             lmax, 2, c->first, c->max_list, c->counters + 0, c->max_cap,
+                                                             c->counters + 2, c->counters + 3, c->counters + 8, dlen);
+            hipError_t e = hipMemcpyAsync(len.data(), dlen, 2 * m * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = fail(XB_E_HIP, "xb_escaped_paths: %s", hipGetErrorString(e)); break; }
+            int total = 0;
+            std::vector<int> alen(m);
+            for (int i = 0; i < m; i++) {
+                alen[i] = std::abs(len[i]);          // negative: cut at max_len
+                off[i] = total;
+                total += 1 + alen[i] - len[m + i];   // start voxel + the part from the first out-of-range voxel on
+            }
+            buf.resize(total);
+            e = hipMalloc(&packed, (size_t)std::max(total, 1) * sizeof(int));
+            if (e == hipSuccess) e = hipMemcpyAsync(doff, off.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dlen, alen.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                k_path_pack<<<m, 64, 0, c->stream>>>(path, lmax, doff, dlen, dfirst, packed);
+                e = hipMemcpyAsync(buf.data(), packed, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipFree(packed); packed = nullptr;
+            if (e != hipSuccess) { rc = fail(XB_E_HIP, "xb_escaped_paths: %s", hipGetErrorString(e)); break; }
+            for (int i = 0; i < m; i++) {
+                c->esc_starts.push_back(starts[o + i]);
+                const int cnt = 1 + alen[i] - len[m + i];
+                for (int k = 0; k < cnt; k++) c->esc_vox.push_back(buf[off[i] + k]);
+                c->esc_offsets.push_back((int64_t)c->esc_vox.size());
+                c->esc_complete.push_back(len[i] > 0 ? 1 : 0);
+            }
+        }
+        hipFree(path); hipFree(dlen);
+        if (rc != XB_OK) return rc;
+    }
+    if (n_paths) *n_paths = (int64_t)c->esc_starts.size();
+    if (n_voxels) *n_voxels = (int64_t)c->esc_vox.size();
+    return XB_OK;
+}
+int xb_escaped_paths_fetch(xb_ctx *c, int64_t *starts, int64_t *offsets, int64_t *voxels, int8_t *complete) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    std::copy(c->esc_starts.begin(), c->esc_starts.end(), starts);
+    std::copy(c->esc_offsets.begin(), c->esc_offsets.end(), offsets);
+    std::copy(c->esc_vox.begin(), c->esc_vox.end(), voxels);
+    std::copy(c->esc_complete.begin(), c->esc_complete.end(), complete);
+    return XB_OK;
+}
+// labels / known at arbitrary voxels (linear indices), and the write-back of retrace results
+static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8_t *kn, bool scatter) {
+    NEED_GRID("xb_gather_voxels");
+    if (n <= 0) return XB_OK;
+    std::vector<int> i32(n);
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= c->N) return fail(XB_E_ARG, "voxel index out of range");
+        i32[k] = (int)idx[k];
+    }
+    int *d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)n * (2 * sizeof(int) + 1)));
+    int *dlab = d + n;
+    int8_t *dkn = reinterpret_cast<int8_t *>(d + 2 * n);
+    hipError_t e = hipMemcpyAsync(d, i32.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (scatter) {
+        if (e == hipSuccess) e = hipMemcpyAsync(dlab, lab, n * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dkn, kn, n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) k_scatter_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, dlab, dkn, c->labels, c->known);
+        c->list_valid = false;
+        c->buni_valid = false;
+    } else {
+        if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
+        if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(kn, dkn, n, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(XB_E_HIP, "xb_gather/scatter_voxels: %s", hipGetErrorString(e));
+    return XB_OK;
+}
+int xb_gather_voxels(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *labels_out, int8_t *known_out) {
+    return voxel_io(c, idx, n, labels_out, known_out, false);
+}
+int xb_scatter_voxels(xb_ctx *c, const int64_t *idx, int64_t n, const int32_t *labels_in, const int8_t *known_in) {
+    return voxel_io(c, idx, n, const_cast<int32_t *>(labels_in), const_cast<int8_t *>(known_in), true);
 }
 
 static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *escaped);

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
                 o = 2;
                 if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
                     bool is_max = true, decided = false;
-                    if (G) {
+                    if (G && plane_in_window(g, x)) {  // (slabs: the table covers a window of planes only)
                         // the table knows the best distance-weighted neighbour of v; if there is one
                         // (and it is not vacuum) that neighbour is denser than v: not a maximum.
                         // (weighted > rho(v) implies rho(n) > rho(v); the converse can fail by

@@ -228,12 +228,34 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     }
 }
 
+// helpers of the remote path queries (slab scheduler)
+// packed path of walker t: its start voxel, then the voxels from index first[t] on
+__global__ void k_path_pack(const int *__restrict__ path, int lmax, const int *__restrict__ off, const int *__restrict__ len,
+                            const int *__restrict__ first, int *__restrict__ packed) {
+    const int t = blockIdx.x;
+    const int *P = path + (size_t)t * lmax;
+    if (threadIdx.x == 0) packed[off[t]] = P[0];
+    for (int k = first[t] + threadIdx.x; k < len[t]; k += blockDim.x) packed[off[t] + 1 + k - first[t]] = P[k];
+}
+__global__ void k_gather_voxels(const int *__restrict__ idx, int n, const int *__restrict__ labels,
+                                const int8_t *__restrict__ known, int *lab_out, int8_t *kn_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { lab_out[t] = labels[idx[t]]; kn_out[t] = known[idx[t]]; }
+}
+__global__ void k_scatter_voxels(const int *__restrict__ idx, int n, const int *__restrict__ lab_in,
+                                 const int8_t *__restrict__ kn_in, int *labels, int8_t *known) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { labels[idx[t]] = lab_in[t]; known[idx[t]] = kn_in[t]; }
+}
+
 // Exact slow path for the (rare) trajectories whose path membership could not be decided from the
 // window: the whole path lives in global scratch and is scanned linearly.
-// mode 0: assignment (write maximum index, note it); mode 1: refinement retrace.
+// mode 0: assignment (write maximum index, note it); mode 1: refinement retrace; mode 2: only record the
+// whole trajectory up to its maximum (path + length), for the slab scheduler's remote path queries.
 __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
                              int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
-                             int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err) {
+                             int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err,
+                             int *lens) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int v = list[t];
@@ -258,13 +280,32 @@ __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels
             lq = lin3(g, qx, qy, qz);
             if (qx == px && qy == py && qz == pz) { result = lp; break; }
         }
-        if (refine) {
+        if (refine == 1) {
             if (!plane_valid(g, qx)) { known[v] = -6; atomicAdd(escaped, 1); return; }
             if (known_ro[lq] == 2) { result = lq; break; }
         }
-        if (np >= lmax) { atomicExch(err, 1); return; }
+        if (np >= lmax) {
+            if (refine == 2) {  // truncated dump: the scheduler asks again with a longer cap
+                lens[t] = -np;
+                int fo = np;
+                for (int k = 1; k < np && fo == np; k++)
+                    if (!plane_valid(g, P[k] / g.nyz)) fo = k;
+                lens[n + t] = fo;
+                return;
+            }
+            atomicExch(err, 1);
+            return;
+        }
         P[np++] = lq;
         px = qx; py = qy; pz = qz; lp = lq; c = rho[lq];
+    }
+    if (refine == 2) {  // length, and where the path first leaves this rank's valid planes (the part before is known
+        lens[t] = np;   // to hold no stop voxel: the fast retrace walked it)
+        int fo = np;
+        for (int k = 1; k < np && fo == np; k++)
+            if (!plane_valid(g, P[k] / g.nyz)) fo = k;
+        lens[n + t] = fo;
+        return;
     }
     if (refine) {
         const int nv = labels[result];

@@ -13,6 +13,7 @@ tests) before every edge sweep.  Collectives: only tiny ones (maxima tables, cou
 The scheduler is written against a small backend interface so that the CPU tests can drive it with a
 host backend; the product backend is `GpuBackend` (libbader_hip.so)."""
 import os
+import sys
 import time
 
 import numpy as np
@@ -312,11 +313,11 @@ class SlabRunner:
         nx, ny, nz = self.shape
         ok = (self.comm.size > 1 and hasattr(self.be, 'set_table_window') and nx % 8 == 0 and ny % 8 == 0 and nz % 8 == 0
               and all(a % 8 == 0 and b % 8 == 0 for a, b in self.ranges)
-              and (self.x_range[1] - self.x_range[0]) + 2 * (max(margin, self.halo) + 7) // 8 * 8 < nx)
+              and (self.x_range[1] - self.x_range[0]) + 2 * (margin + 7) // 8 * 8 < nx)
         # every rank must take the same branch (collectives below)
         ok = all(self.comm.allgather(bool(ok))) if self.comm.size > 1 else False
         if ok:
-            self.be.set_table_window(max(margin, self.halo))
+            self.be.set_table_window(margin)   # walks beyond it derive their records from rho on the spot
         self.windowed = ok
         return ok
 
@@ -356,14 +357,6 @@ class SlabRunner:
                 self.be.sync()
                 self.comm.exchange(self.be.tensors()[0], self.sends, self.recvs)
 
-    def gather_all_planes(self):
-        """Fallback exchange: every rank receives every other rank's owned label and known planes."""
-        sends = [(peer, self.x_range[0], self.x_range[1]) for peer in range(self.comm.size) if peer != self.comm.rank]
-        recvs = [(peer, a, b) for peer, (a, b) in enumerate(self.ranges) if peer != self.comm.rank]
-        self.be.sync()
-        for t in self.be.tensors():
-            self.comm.exchange(t, sends, recvs)
-
     def _trace(self):
         with _Phase(self, 'refine_trace'):
             changed, escaped = self.be.refine_trace()
@@ -373,19 +366,75 @@ class SlabRunner:
         with _Phase(self, 'sums'):
             changed, escaped = self.comm.sum(changed, escaped)
         if escaped:
-            # Some retraces walked out of [x0-halo+2, x1+halo-2) before meeting a known==2 voxel.
-            # They were parked (known == -6) untouched.  Make the whole grid valid on every rank --
-            # traces only read labels at known==2 voxels / maxima, which no retrace rewrites, so the
-            # exchange is safe in the middle of an iteration -- and retrace exactly those voxels.
+            # Some retraces walked out of [x0-halo+2, x1+halo-2) before meeting a known==2 voxel (they slide
+            # along a dividing surface for tens of planes).  They were parked (known == -6) untouched.
             self.n_fallbacks += 1
-            self.gather_all_planes()
-            self.be.set_halo(self.shape[0])
-            ch2, es2 = self.be.refine_trace_escaped()
-            self.be.set_halo(self.halo)
-            ch2, es2 = self.comm.sum(ch2, es2)
-            assert es2 == 0
+            with _Phase(self, 'escaped_path_queries'):
+                ch2 = self._resolve_escaped()
+            with _Phase(self, 'sums'):
+                ch2, = self.comm.sum(ch2)
             changed += ch2
         return changed
+
+    def _resolve_escaped(self):
+        """Finish the parked retraces without moving planes: a retrace's path depends on rho only (replicated),
+        so its owner records the whole trajectory up to the maximum; the ranks owning the path voxels answer
+        (label, known) for them; the retrace ends on the first known == 2 voxel of its path
+        (refinement.py:294-303) or on the maximum (283-292) and takes that voxel's label.  Traces only read
+        labels at known==2 voxels / maxima, which no retrace rewrites, so asking in the middle of an
+        iteration is safe.  Two small all-gathers instead of every rank's planes."""
+        total = 0
+        # most retraces stop a few voxels beyond the halo: ask about short tails first
+        for max_len in (self.halo + 16, self.halo + 64, 1024, 1 << 15):
+            t0 = time.perf_counter()
+            starts, offsets, vox, complete = self.be.escaped_paths(max_len)
+            t1 = time.perf_counter()
+            moved, open_ = self._ask_owners(starts, offsets, vox, complete)
+            if os.environ.get('XB_SLAB_DEBUG'):
+                print(f'[rank {self.comm.rank}] path queries max_len {max_len}: {starts.size} paths, {vox.size} voxels, '
+                      f'dump {1e3 * (t1 - t0):.1f} ms, ask {1e3 * (time.perf_counter() - t1):.1f} ms, open {open_}',
+                      file=sys.stderr, flush=True)
+            total += moved
+            if self.comm.sum(open_)[0] == 0:
+                return total
+        raise RuntimeError('escaped retraces unresolved after full-length path queries')
+
+    def _ask_owners(self, starts, offsets, vox, complete):
+        nyz = self.shape[1] * self.shape[2]
+        bounds = np.array([b for _, b in self.ranges], np.int64)           # rank r owns planes [a_r, b_r)
+        uniq = np.unique(vox)
+        owner = np.searchsorted(bounds, uniq // nyz, side='right')
+        ask = {int(r): uniq[owner == r] for r in np.unique(owner)}           # what I ask of each owner
+        all_asks = self.comm.allgather(ask)
+        mine = {src: self.be.gather_voxels(q[self.comm.rank]) for src, q in enumerate(all_asks) if self.comm.rank in q}
+        all_answers = self.comm.allgather(mine)
+        if starts.size == 0:
+            return 0, 0
+        lab = np.zeros(uniq.size, np.int32)
+        kn = np.zeros(uniq.size, np.int8)
+        for r, q in ask.items():
+            a_lab, a_kn = all_answers[r][self.comm.rank]
+            pos = np.searchsorted(uniq, q)
+            lab[pos], kn[pos] = a_lab, a_kn
+        pos = np.searchsorted(uniq, vox)
+        p_lab, p_kn = lab[pos], kn[pos]
+        # first known == 2 voxel after the start of each path (segmented search)
+        is2 = p_kn == 2
+        is2[offsets[:-1]] = False
+        idx2 = np.flatnonzero(is2)
+        first2 = np.searchsorted(idx2, offsets[:-1])                        # position in idx2 of the first hit >= path start
+        hit = (first2 < idx2.size)
+        stop = np.where(hit, idx2[np.minimum(first2, max(idx2.size - 1, 0))] if idx2.size else 0, 0)
+        hit &= stop < offsets[1:]
+        done = hit | complete
+        stop = np.where(hit, stop, offsets[1:] - 1)
+        old = p_lab[offsets[:-1]]
+        new_lab = p_lab[stop]
+        moved = done & (new_lab != old)
+        sel = np.flatnonzero(done)
+        # refinement.py:288-291: a relabelled voxel stays flagged (-2), the others become plain near-edge (-1)
+        self.be.scatter_voxels(starts[sel], np.where(moved, new_lab, old)[sel], np.where(moved, -2, -1).astype(np.int8)[sel])
+        return int(moved.sum()), int((~done).sum())
 
     def refine(self, mode, iters):
         """thread_handlers.refine (thread_handlers.py:128-236) across slabs.  Returns [(edges, changed)]."""

@@ -120,8 +120,37 @@ class OracleSlabBackend:
     def refine_trace(self):
         return self._retrace(-2)
 
-    def refine_trace_escaped(self):
-        return self._retrace(-6)
+    def escaped_paths(self, max_len=1 << 15):
+        import oracle
+        mask = np.zeros(self.shape, bool)
+        mask[self.x0:self.x1] = True
+        starts = np.flatnonzero((self.known == -6) & mask).astype(np.int64)
+        nyz = self.shape[1] * self.shape[2]
+        valid = np.zeros(self.shape[0], bool)
+        valid[self.valid] = True
+        paths, complete = [], []
+        for v in starts:
+            full = oracle.trajectory_path(self.rho, self.dm, self.tg, v)
+            complete.append(full.size <= max_len)
+            p = full[:max_len]
+            out = np.flatnonzero(~valid[p // nyz])
+            out = out[out >= 1]
+            first = out[0] if out.size else p.size
+            paths.append(np.concatenate([p[:1], p[first:]]))
+        offsets = np.zeros(starts.size + 1, np.int64)
+        offsets[1:] = np.cumsum([p.size for p in paths])
+        vox = np.concatenate(paths) if paths else np.zeros(0, np.int64)
+        return starts, offsets, vox, np.array(complete, bool)
+
+    def gather_voxels(self, idx):
+        # answers come from OWNED planes only: anything else would hide a scheduler that asks the wrong rank
+        planes = np.asarray(idx) // (self.shape[1] * self.shape[2])
+        assert np.all((planes >= self.x0) & (planes < self.x1))
+        return self.labels.reshape(-1)[idx].copy(), self.known.reshape(-1)[idx].copy()
+
+    def scatter_voxels(self, idx, labels, known):
+        self.labels.reshape(-1)[idx] = labels
+        self.known.reshape(-1)[idx] = known
 
     def edge_check(self):
         import oracle
