@@ -437,22 +437,17 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 // rewrites i to -1 / -3 unless i is an (edge & maximum) voxel, in which case i is processed too.
 // So the processed set P is the lexicographically-first greedy choice:
 //     i in P  <=>  class(i) == edge&max  or  no j in P with j < i, j in box(i).
-// P is resolved in rounds (a voxel decides once all earlier changed neighbours have decided);
-// the final `known` is then a pure function of P and the static classes.
+// P is resolved in dependency order (a voxel decides once all earlier changed neighbours have decided,
+// k_ec_first + k_ec_chase below); the final `known` is then a pure function of P and the static classes:
+//   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
+//   an earlier neighbour is P -> skipped
+//   no earlier neighbour left undecided -> processed
 // temp codes in `known`: -2 (0xFE) undecided, -4 (0xFC) processed, -10 (0xF6) skipped -- both decisions
 // clear one bit of 0xFE, so a lane claims and publishes a decision with a single atomicAnd on the
 // aligned word holding the status byte (the returned word tells whether it was first).
 #define EC_PROC (-4)
 #define EC_SKIP (-10)
 // ---------------------------------------------------------------------------------------------
-// Event-driven rounds.  A work list holds changed voxels worth (re-)evaluating: initially all of
-// them, afterwards only the later neighbours of voxels decided in the previous round -- a blocked voxel
-// is re-examined exactly when one of its blockers has been decided.  Lists live on the device
-// (`in` -> `out`, de-duplicated with a per-voxel round stamp) and rounds are queued back-to-back;
-// the host only polls the list length now and then.
-//   edge&max voxel            -> processed at once (earlier boxes leave it -2, refinement.py:480)
-//   an earlier neighbour is P -> skipped
-//   no earlier neighbour left undecided -> processed
 // One evaluation of edge voxel v against the statuses of its 27-box (refinement.py:428-470 in
 // dependency order): returns 0 when v is not (or no longer) undecided or still has to wait for an
 // earlier neighbour, else the decision (1 processed / 2 skipped) and in `later` the box voxels that

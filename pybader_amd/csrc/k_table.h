@@ -321,9 +321,8 @@ __global__ __launch_bounds__(TPB) void k_box_stamp(GridL g, GradRec *G, int mx, 
 // for maximum m (closed boxes, earlier bricks).  A brick B without a 26-neighbour maximum whose
 // every possible move (any dr) from every voxel lands in B itself or in bricks that are certain
 // for the SAME m keeps U + B closed, and a trajectory cannot stay in B forever (it only ends on
-// a maximum), so it must enter U: B is certain for m as well.  One round tests the uncertain
-// bricks that touch the certain region of the previous round (deterministic: reads `blab` of the
-// previous round only) and stamps the ones that pass.
+// a maximum), so it must enter U: B is certain for m as well.  Mutually dependent bricks are certified
+// together by a greatest-fixpoint (kill) iteration on provisional labels, see k_brick_grow.
 // ---------------------------------------------------------------------------------------------
 #define BRK 8
 // blab: 0 unknown, id > 0 certain for box id, -1 never (holds a maximum)
@@ -353,48 +352,13 @@ __global__ void k_brick_seed(GridL g, int nb0, int nb1, int nb2, int n_boxes, co
 // bmask[K] (built by k_grad_field): bit k (k = (d0+1)*9+(d1+1)*3+(d2+1), d = brick offset) is set
 // when some possible move of some voxel of brick K lands in the neighbour brick K+d; bit 27 is set
 // when the brick holds a 26-neighbour maximum.
-__device__ __forceinline__ int brick_nb(int b0, int b1, int b2, int k, int nb0, int nb1, int nb2) {
-    return (wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2);
-}
-// provisional labels: an unlabelled brick adopts the label of a labelled brick it can move into
-// (smallest label on ties); `plab` double-buffered by the caller.  Any guess is sound -- the kill
-// iterations below decide -- a good guess only makes the certain regions larger.
-__global__ void k_brick_propagate(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
-                                  const int *__restrict__ pin, int *__restrict__ pout, int *changed) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb0 * nb1 * nb2) return;
-    int l = pin[b];
-    if (l == 0 && !(bmask[b] >> 27)) {
-        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-        const int m = bmask[b];
-        int best = 0;
-        for (int k = 0; k < 27; k++)
-            if ((m >> k) & 1) {
-                const int q = pin[brick_nb(b0, b1, b2, k, nb0, nb1, nb2)];
-                if (q > 0 && (best == 0 || q < best)) best = q;
-            }
-        if (best) { l = best; *changed = 1; }
-    }
-    pout[b] = l;
-}
-// kill iterations (greatest fixpoint): a non-seed brick stays alive for its label m only while it
-// holds no maximum and every brick it can move into is alive with the same label.  What survives,
-// together with the seed cubes, is closed under every possible move: a trapping region of m.
-__global__ void k_brick_kill(int nb0, int nb1, int nb2, const int *__restrict__ bmask, const int *__restrict__ seed,
-                             const int *__restrict__ ain, int *__restrict__ aout, int *changed) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb0 * nb1 * nb2) return;
-    int l = ain[b];
-    if (l > 0 && seed[b] == 0) {
-        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-        const int m = bmask[b];
-        bool ok = !(m >> 27);
-        for (int k = 0; k < 27 && ok; k++)
-            if ((m >> k) & 1) ok = (ain[brick_nb(b0, b1, b2, k, nb0, nb1, nb2)] == l);
-        if (!ok) { l = 0; *changed = 1; }
-    }
-    aout[b] = l;
-}
+// The two iterations (k_brick_grow below):
+//  * provisional labels: an unlabelled brick adopts the label of a labelled brick it can move into (smallest
+//    label on ties).  Any guess is sound -- the kill iteration decides -- a good guess only makes the
+//    certain regions larger;
+//  * kill (greatest fixpoint): a non-seed brick stays alive for its label m only while it holds no maximum
+//    and every brick it can move into is alive with the same label.  What survives, together with the seed
+//    cubes, is closed under every possible move: a trapping region of m.
 // Both iterations, several rounds per launch: a workgroup keeps an 8x8x8 chunk of bricks plus a one-brick
 // (periodic) halo in LDS and iterates on it until nothing changes or `inner` rounds are done; the halo is
 // what the previous launch left.  Labels then travel up to `inner` bricks per launch instead of one.
