@@ -116,6 +116,23 @@ static GridL light(const Grid &g) {
     return l;
 }
 
+// the 14-distance form of the grid for the tiled field kernels; false when dist_mat is not symmetric
+static bool sym_grid(const Grid &g, GridS &s) {
+    s.nx = g.nx; s.ny = g.ny; s.nz = g.nz; s.nyz = g.nyz;
+    s.x0 = g.x0; s.x1 = g.x1; s.vx0 = g.vx0; s.vlen = g.vlen; s.wx0 = g.wx0; s.wlen = g.wlen;
+    for (int k = 0; k < 9; k++) s.T[k] = g.T[k];
+    auto at = [&](int idx) {
+        const int ix = idx / 9, iy = (idx / 3) % 3, iz = idx % 3;
+        return g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+    };
+    for (int idx = 0; idx <= 13; idx++) {
+        const double a = at(idx), b = at(26 - idx);
+        if (std::memcmp(&a, &b, sizeof a) != 0) return false;
+        s.dsym[idx] = a;
+    }
+    return true;
+}
+
 struct ScopedTimer {
     xb_ctx *c;
     int which;
@@ -407,8 +424,13 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.wlen + GT_X - 1) / GT_X);
         ScopedTimer tk(c, 5);
-        k_grad_field<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
-                                                 BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
+        GridS gs;
+        if (sym_grid(g, gs))
+            k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
+                                                            BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
+        else
+            k_grad_field<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
+                                                           BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
     }
     HIPCHK(hipGetLastError());
     c->grad_valid = true;
@@ -676,7 +698,11 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
             ScopedTimer t(c, 1);
             const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
             dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
-            k_og_pointer_tiled<<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, c->has_vacuum ? 1 : 0);
+            GridS gs;
+            if (sym_grid(g, gs))
+                k_og_pointer_tiled<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->labels, small, c->has_vacuum ? 1 : 0);
+            else
+                k_og_pointer_tiled<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, c->has_vacuum ? 1 : 0);
         }
         HIPCHK(hipGetLastError());
         for (int it = 0; it < 64; it++) {

@@ -17,6 +17,25 @@ struct Grid {
     double dist[27];  // dist_mat [3][3][3], index 2 == -1 (interface.py:242-259)
 };
 
+// Grid for the tiled field kernels when dist_mat is symmetric (dist(-o) == dist(o), which it is for every
+// lattice: the entries are 1/|o . voxel_lattice|): 14 instead of 27 distances, so that T + dist fit the
+// SGPR file without spilling (the 27-entry version costs ~30 v_readlane per voxel in k_grad_field).
+// dsym[k], k = min(idx, 26 - idx) with idx = ix*9 + iy*3 + iz over offsets ix,iy,iz in 0..2 (== -1..1).
+struct GridS {
+    int nx, ny, nz, nyz;
+    int x0, x1, vx0, vlen;
+    int wx0, wlen;
+    double T[9];
+    double dsym[14];
+};
+__device__ __forceinline__ double dist_at(const Grid &g, int ix, int iy, int iz) {
+    return g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+}
+__device__ __forceinline__ double dist_at(const GridS &g, int ix, int iy, int iz) {
+    const int idx = ix * 9 + iy * 3 + iz;
+    return g.dsym[idx < 26 - idx ? idx : 26 - idx];
+}
+
 // What the trace kernels need of Grid (keeps their SGPR count low: more waves per SIMD).
 struct GridL {
     int nx, ny, nz, nyz;
@@ -60,10 +79,8 @@ __device__ __forceinline__ bool ng_dir_vals(const GT &g, double c, double hx, do
     d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
     d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
     d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
-    double mg = 0.;
-    if (d0 > mg) mg = d0; else if (-d0 > mg) mg = -d0;
-    if (d1 > mg) mg = d1; else if (-d1 > mg) mg = -d1;
-    if (d2 > mg) mg = d2; else if (-d2 > mg) mg = -d2;
+    // refinement.py:131-134: max_grad = the largest |component| (the reference's if/elif chain from 0; no NaNs)
+    const double mg = fmax(fmax(fabs(d0), fabs(d1)), fabs(d2));
     if (mg < 1E-14) return true;
     d0 /= mg; d1 /= mg; d2 /= mg;  // refinement.py:137, true division
     return false;

@@ -25,7 +25,8 @@ __device__ __forceinline__ void move_ranges_raw(int code, int og, double r0, dou
         lo[2] = min(lo[2], i2 - (r2 < 1e-12)); hi[2] = max(hi[2], i2 + (r2 > -1e-12));
     }
 }
-__global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__restrict__ rho,
+template <typename GT>
+__global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restrict__ rho,
                                                     GradRec *__restrict__ G, int *seeds, int *seed_count,
                                                     int seed_cap, int small, int *__restrict__ bmask) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
 #pragma unroll
                 for (int iz = 0; iz < 3; iz++) {
                     double w = tile[tx + ix][ty + iy][tz + iz];
-                    w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+                    w = (w - c) * dist_at(g, ix, iy, iz);
                     w += c;
                     og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
                     max_val = fmax(max_val, w);  // no NaNs in a density: same as the conditional assignment
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(TPB) void k_grad_field(Grid g, const double *__rest
 // The ongrid pointer of every voxel (methods.py:84-117) from the same staged tile: labels[v] = linear
 // index of the best distance-weighted neighbour (v itself for a 26-neighbour maximum); vacuum voxels
 // (label -1) keep their -1 (methods.py:73-74).
-__global__ __launch_bounds__(TPB) void k_og_pointer_tiled(Grid g, const double *__restrict__ rho, int *labels,
+template <typename GT>
+__global__ __launch_bounds__(TPB) void k_og_pointer_tiled(GT g, const double *__restrict__ rho, int *labels,
                                                           int small, int has_vacuum) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
     const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(TPB) void k_og_pointer_tiled(Grid g, const double *
 #pragma unroll
                 for (int iz = 0; iz < 3; iz++) {
                     double w = tile[tx + ix][ty + iy][tz + iz];
-                    w = (w - c) * g.dist[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+                    w = (w - c) * dist_at(g, ix, iy, iz);
                     w += c;
                     og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
                     max_val = fmax(max_val, w);
