@@ -55,6 +55,13 @@ int xb_upload_density(xb_ctx *c, const double *rho_host);           /* H2D, nx*n
 int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, int64_t n_atoms,
                      double background);
 int xb_download_density(xb_ctx *c, double *rho_host);
+/* The density block of a VASP CHGCAR / CHG file (io/vasp.py:90-104, 147-149): `text` holds nx*ny*nz (or more)
+ * whitespace separated decimal numbers in Fortran order (x fastest); they are converted exactly as numpy's
+ * string -> float64 does (correctly rounded), divided by `divisor` (the cell volume) and stored as the
+ * resident density rho[x][y][z].  The text is uploaded as it is and parsed on the device; tokens outside the
+ * exact fast path go through strtod on the host (n_host of them).  SURVEY.md 8(f) rank 4. */
+int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double divisor, int64_t *n_tokens,
+                          int64_t *n_host);
 /* labels: host <-> device with widening/narrowing on the device (utils.dtype_change, utils.py:255-259) */
 int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype);
 int xb_download_labels(xb_ctx *c, void *labels_host, int dtype);

@@ -50,6 +50,8 @@ def lib():
         L.orc_own_trajectory.argtypes = [_f64p, _i64p, _i32p, _f64p, _f64p, _i64p]
         L.orc_trajectory_path.restype = C.c_int64
         L.orc_trajectory_path.argtypes = [_f64p, _i64p, _f64p, _f64p, C.c_int64, _i64p, C.c_int64]
+        L.orc_parse_density_text.restype = C.c_int64
+        L.orc_parse_density_text.argtypes = [C.c_char_p, C.c_int64, _i64p, C.c_double, _f64p]
         L.orc_vacuum_assign.restype = None
         L.orc_vacuum_assign.argtypes = [_f64p, _i32p, C.c_double, _f64p, C.c_double, C.c_int64,
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -191,6 +193,15 @@ def trajectory_path(density, dist_mat, T_grad, start, cap=1 << 16):
     if n < 0:
         raise RuntimeError('trajectory longer than the buffer')
     return out[:n].copy()
+
+
+def parse_density_text(text, shape, divisor):
+    """The density block of a CHGCAR (bytes, Fortran order) -> float64 [x][y][z] / divisor (io/vasp.py:90-104)."""
+    out = np.zeros(tuple(int(s) for s in shape), dtype=np.float64)
+    n = lib().orc_parse_density_text(text, len(text), np.array(shape, dtype=np.int64), float(divisor), out)
+    if n != out.size:
+        raise ValueError(f'density block: {n} numbers converted, {out.size} expected')
+    return out
 
 
 def vacuum_assign(reference, volumes, vac_tol, density, voxel_volume):

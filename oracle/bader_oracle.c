@@ -530,4 +530,31 @@ void orc_synth_density(const int64_t shape[3], const double *lattice, const doub
     }
 }
 
+/* The density block of a CHGCAR (io/vasp.py:90-104, 147-149): whitespace separated decimal numbers in
+ * Fortran order (x fastest), each converted by strtod (correctly rounded, as numpy's string -> float64),
+ * stored as out[x][y][z] = value / divisor.  Returns the number of tokens converted (stops after nx*ny*nz),
+ * or -1 - k when token k is malformed. */
+int64_t orc_parse_density_text(const char *text, int64_t nbytes, const int64_t shape[3], double divisor, double *out) {
+    const int64_t nx = shape[0], ny = shape[1], nz = shape[2], N = nx * ny * nz;
+    int64_t pos = 0, k = 0;
+    char buf[128];
+    while (k < N) {
+        while (pos < nbytes && (text[pos] == ' ' || (text[pos] >= 9 && text[pos] <= 13))) pos++;
+        if (pos >= nbytes) break;
+        int64_t end = pos;
+        while (end < nbytes && !(text[end] == ' ' || (text[end] >= 9 && text[end] <= 13))) end++;
+        if (end - pos >= (int64_t)sizeof buf) return -1 - k;
+        memcpy(buf, text + pos, (size_t)(end - pos));
+        buf[end - pos] = 0;
+        char *stop;
+        const double v = strtod(buf, &stop);
+        if (stop == buf || *stop) return -1 - k;
+        const int64_t x = k % nx, r = k / nx;
+        out[(x * ny + r % ny) * nz + r / ny] = v / divisor;
+        k++;
+        pos = end;
+    }
+    return k;
+}
+
 void orc_free(void *p) { free(p); }

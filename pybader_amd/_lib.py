@@ -25,6 +25,7 @@ SYMBOLS = {
     'xb_set_grid': (_int, [_vp, _pi64, _pdbl, _pdbl, _i64, _i64]),
     'xb_upload_density': (_int, [_vp, _vp]),
     'xb_synth_density': (_int, [_vp, _pdbl, _pdbl, _i64, _dbl]),
+    'xb_parse_density_text': (_int, [_vp, _vp, _i64, _dbl, _pi64, _pi64]),
     'xb_download_density': (_int, [_vp, _vp]),
     'xb_upload_labels': (_int, [_vp, _vp, _int]),
     'xb_download_labels': (_int, [_vp, _vp, _int]),
@@ -224,6 +225,15 @@ class Context:
     def refine_trace_escaped(self):
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_refine_trace_escaped(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def parse_density_text(self, text, divisor):
+        """the density block of a CHGCAR (bytes or a uint8 array, Fortran order) -> resident density / divisor;
+        returns (numbers found, numbers converted by the host fallback)"""
+        buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else text
+        assert buf.dtype == np.uint8 and buf.flags.c_contiguous
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_parse_density_text(self.h, _ptr(buf), buf.size, float(divisor), C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def escaped_paths(self, max_len=1 << 15):

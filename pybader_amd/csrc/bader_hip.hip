@@ -20,6 +20,7 @@
 #include "k_ongrid.h"
 #include "k_edges.h"
 #include "k_sums.h"
+#include "k_text.h"
 
 // =============================================================================================
 // host side
@@ -303,6 +304,103 @@ int xb_download_density(xb_ctx *c, double *rho_host) {
     NEED_GRID("xb_download_density");
     HIPCHK(hipMemcpyAsync(rho_host, c->rho, c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+// ---- density block of a CHGCAR / CHG file: text -> resident rho (k_text.h) ----------------------
+static int read_counter(xb_ctx *c, int idx, int *out);
+__global__ void k_patch_doubles(const long long *__restrict__ at, const double *__restrict__ val, int n, double *out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[at[t]] = val[t];
+}
+// in-place exclusive scan of n ints on the device (levels of 2048)
+static int device_scan(xb_ctx *c, int *data, int n, int *scratch) {
+    const int nb = (n + 2047) / 2048;
+    k_scan_2048<<<nb, TPB, 0, c->stream>>>(data, n, data, scratch);
+    HIPCHK(hipGetLastError());
+    if (nb > 1) {
+        if (int rc = device_scan(c, scratch, nb, scratch + nb)) return rc;
+        k_scan_add<<<nb, TPB, 0, c->stream>>>(data, n, scratch);
+        HIPCHK(hipGetLastError());
+    }
+    return XB_OK;
+}
+int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double divisor, int64_t *n_tokens,
+                          int64_t *n_host) {
+    NEED_GRID("xb_parse_density_text");
+    const Grid &g = c->g;
+    if (!text || nbytes <= 0) return fail(XB_E_ARG, "xb_parse_density_text: empty text");
+    if (nbytes / (TPB * TXT_BYTES) >= (1LL << 31) - 2) return fail(XB_E_LIMIT, "xb_parse_density_text: text too large");
+    if (!(divisor == divisor) || divisor == 0.) return fail(XB_E_ARG, "xb_parse_density_text: bad divisor");
+    c->grad_valid = false;
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const int nblk = (int)((nbytes + TPB * TXT_BYTES - 1) / (TPB * TXT_BYTES));
+    const int todo_cap = 1 << 20;
+    unsigned char *dtext = nullptr;
+    int *counts = nullptr;
+    double *dp10 = nullptr;
+    long long *dtodo = nullptr;
+    int rc = XB_OK;
+    auto cleanup = [&]() { hipFree(dtext); hipFree(counts); hipFree(dp10); hipFree(dtodo); };
+    hipError_t e = hipMalloc(&dtext, (size_t)nbytes + 32);
+    if (e == hipSuccess) e = hipMalloc(&counts, ((size_t)nblk + nblk / 1024 + 4096) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&dp10, sizeof P10);
+    if (e == hipSuccess) e = hipMalloc(&dtodo, (size_t)todo_cap * 2 * sizeof(long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(dtext, text, (size_t)nbytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dp10, P10, sizeof P10, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream);
+    if (e != hipSuccess) { cleanup(); return fail(XB_E_HIP, "xb_parse_density_text: %s", hipGetErrorString(e)); }
+    int last_count = 0, last_off = 0, n_todo = 0;
+    k_text_count<<<nblk, TPB, 0, c->stream>>>(dtext, nbytes, counts);
+    e = hipMemcpyAsync(&last_count, counts + nblk - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) rc = device_scan(c, counts, nblk, counts + nblk);
+    if (e == hipSuccess && rc == XB_OK) e = hipMemcpyAsync(&last_off, counts + nblk - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == XB_OK) e = hipStreamSynchronize(c->stream);
+    const long long tokens = (long long)last_off + last_count;
+    if (e == hipSuccess && rc == XB_OK && tokens < c->N)
+        rc = fail(XB_E_ARG, "xb_parse_density_text: %lld numbers in the text, the grid has %lld voxels", tokens, (long long)c->N);
+    if (e == hipSuccess && rc == XB_OK) {
+        k_text_parse<<<nblk, TPB, 0, c->stream>>>(dtext, nbytes, counts, dp10, divisor, g.nx, g.ny, g.nz, c->rho, dtodo,
+                                                 c->counters + 6, todo_cap);
+        e = hipGetLastError();
+        if (e == hipSuccess) rc = read_counter(c, 6, &n_todo);
+    }
+    if (e == hipSuccess && rc == XB_OK && n_todo > todo_cap)
+        rc = fail(XB_E_LIMIT, "xb_parse_density_text: %d tokens need the host parser (cap %d)", n_todo, todo_cap);
+    if (e == hipSuccess && rc == XB_OK && n_todo) {  // the rare tokens outside the exact fast path: strtod on the host
+        std::vector<long long> todo(2 * (size_t)n_todo), at(n_todo);
+        std::vector<double> val(n_todo);
+        e = hipMemcpyAsync(todo.data(), dtodo, todo.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        for (int k = 0; k < n_todo && e == hipSuccess && rc == XB_OK; k++) {
+            const long long off = todo[2 * k], idx = todo[2 * k + 1];
+            long long end = off;
+            while (end < nbytes && !(text[end] == ' ' || (text[end] >= 9 && text[end] <= 13))) end++;
+            const std::string tok(text + off, text + end);
+            char *stop = nullptr;
+            const double v = std::strtod(tok.c_str(), &stop);
+            if (stop == tok.c_str() || *stop != 0) rc = fail(XB_E_ARG, "xb_parse_density_text: could not convert '%s' to a number", tok.c_str());
+            const long long x = idx % g.nx, r = idx / g.nx;
+            at[k] = (x * g.ny + r % g.ny) * g.nz + r / g.ny;
+            val[k] = v / divisor;
+        }
+        if (e == hipSuccess && rc == XB_OK) {
+            long long *dat = dtodo;                                   // reuse: indices then values
+            double *dval = reinterpret_cast<double *>(dtodo + n_todo);
+            e = hipMemcpyAsync(dat, at.data(), n_todo * sizeof(long long), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dval, val.data(), n_todo * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) k_patch_doubles<<<(n_todo + 255) / 256, 256, 0, c->stream>>>(dat, dval, n_todo, c->rho);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(XB_E_HIP, "xb_parse_density_text: %s", hipGetErrorString(e));
+    if (rc != XB_OK) return rc;
+    if (n_tokens) *n_tokens = tokens;
+    if (n_host) *n_host = n_todo;
     return XB_OK;
 }
 

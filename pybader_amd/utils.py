@@ -36,6 +36,11 @@ def ensure_density(ctx, density):
     return density
 
 
+def remember_density(ctx, density):
+    """Declare `density` (a host array just downloaded from the context) as the resident one."""
+    _fingerprints[id(ctx)] = _fingerprint(np.ascontiguousarray(density, dtype=np.float64))
+
+
 def forget_density(ctx):
     _fingerprints.pop(id(ctx), None)
 
