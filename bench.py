@@ -123,6 +123,7 @@ def main():
         ctx.set_option(4, int(os.environ['XB_OPT_EC_GROUPS']))
 
     def step():
+        ctx.set_option(6, 1)                            # no table carried over from the previous step
         ctx.vacuum_assign(None, voxel_volume)           # Bader.volumes_init: labels := 0 (no vacuum)
         n = runner.assign(args.method)                  # Bader.bader_calc
         log = runner.refine(mode, iters)                # Bader.refine_volumes
@@ -167,7 +168,7 @@ def main():
     # profiles/r1_final_pmc_fetch_write_512_neargrid.txt -- FETCH_SIZE + WRITE_SIZE as reported (KB)
     traffic = None
     if args.size == 512 and args.method == 'neargrid' and world == 1:
-        traffic = {'k_grad_field': (1314837 + 4196359) * 1024.0, 'k_ng_trace': (4143464 + 213697) * 1024.0}[dom]
+        traffic = {'k_grad_field': (1315034 + 4196362) * 1024.0, 'k_ng_trace': (4148687 + 213736) * 1024.0}[dom]
 
     out = {
         'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',

@@ -173,7 +173,8 @@ int xb_enable_timing(xb_ctx *c, int on);
 /* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order;
  * key 1: trapping boxes bit0 / brick growth bit1; key 2: trace threads per block; key 3: debug prints;
  * key 4: workgroups of the edge_check chase; key 5: its LDS queue capacity, lowered in tests to force
- * the overflow hand-over) */
+ * the overflow hand-over; key 6: drop the cached gradient-field table, so that the next refinement
+ * rebuilds it -- bench.py does this every step: a table kept from an earlier step would hide 1.6 ms) */
 int xb_set_option(xb_ctx *c, int key, int value);
 /* statistics of the last assignment: trapping boxes found and voxels they cover */
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);

@@ -1401,6 +1401,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 3) c->opt_dbg = value;
     else if (key == 4 && value >= 1 && value <= 4096) c->opt_ec_groups = value;
     else if (key == 5 && value >= 2 && value <= EC_Q) c->opt_ec_qcap = value;
+    else if (key == 6) c->grad_valid = false;  // drop the cached gradient-field table (a refinement rebuilds it)
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
