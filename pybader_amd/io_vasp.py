@@ -8,8 +8,8 @@ Cartesian.  Only the 1.3e8-number text block (2.4 GB at 512^3) is handled differ
 bit-identical to numpy's string -> float64.  The charge density stays resident for the following
 `bader_calc` (the upload a `Bader` run would start with is skipped).
 
-The reference's writer (`pybader.io.vasp.write`) is untouched; `file_info['write_function']` is None here
-and the caller keeps using the reference's for output.
+The reference's writer (`pybader.io.vasp.write`) is untouched: `file_info['write_function']` is that very
+function when pybader is importable (None otherwise), so `Bader.write_volume` keeps working.
 """
 import mmap
 import os
@@ -18,6 +18,11 @@ import numpy as np
 
 from . import _lib, utils
 from .interface import distance_matrix, gradient_transform
+
+try:                                    # the export path (-e) keeps using the reference's writer
+    from pybader.io.vasp import write as _reference_write
+except Exception:                       # noqa: BLE001  (pybader absent, or its numba stack not importable)
+    _reference_write = None
 
 __extensions__ = ['chgcar', '.vasp']
 __args__ = ['charge_flag', 'spin_flag', 'buffer_size']
@@ -122,7 +127,7 @@ def read(fn, charge_flag=True, spin_flag=False, buffer_size=64, ctx=None):
         'prefix': prefix,
         'file_type': 'VASP',
         'buffer_size': buffer_size,
-        'write_function': None,
+        'write_function': _reference_write,
         'element_nums': atom_nums,
         'charge_flag': charge_flag,
         'spin_flag': spin_flag,
