@@ -193,8 +193,12 @@ def main():
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_note': 'bytes/launch, FETCH_SIZE+WRITE_SIZE as reported by rocprofv3 --pmc (committed under '
-                                     'profiles/, not corrected for the gfx950 2x FETCH under-count of coalesced streams)',
+                     'traffic_note': 'bytes/launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from the committed rocprofv3 --pmc passes '
+                                     '(profiles/r1_final_pmc_fetch_write_512_neargrid.txt).  k_grad_field: WRITE_SIZE equals the '
+                                     '32 B/voxel table exactly; its reads are 8 B/lane row loads (1.78 GB requested, 1.07 GB '
+                                     'unique) and FETCH_SIZE reports 1.32 GB, so the gfx950 x2 rule for 16 B/lane streams does '
+                                     'not apply (it would exceed the bytes requested).  k_ng_trace: scattered 32-B gathers, '
+                                     'uncalibrated',
                      'algorithmic_bytes_per_voxel': BYTES_ASSIGN, 'kernel_ms_avg': k_avg, 'launches': int(k_n),
                      'whole_path': {'bytes_per_voxel': BYTES_PATH,
                                     'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
