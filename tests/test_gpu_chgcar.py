@@ -90,3 +90,26 @@ def test_parser_errors(ctx):
         ctx.parse_density_text(b' 1.0 2.0 3.0\n', 1.0)                       # fewer numbers than voxels
     with pytest.raises(_lib.BaderHipError):
         ctx.parse_density_text(b' '.join([b'1.0'] * 63 + [b'1.0x']), 1.0)    # a malformed number
+
+
+def test_end_to_end_example(tmp_path, capsys):
+    """examples/chgcar_charges.py on a fixture file: the flow CHGCAR -> resident density -> Bader steps runs
+    through the Python mirror and conserves the charge."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('chgcar_charges', os.path.join(root, 'examples', 'chgcar_charges.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(GOLDEN, 'chgcar_f90_16x16x16.npz'))
+    path = tmp_path / 'CHGCAR'
+    path.write_bytes(g['file_bytes'].tobytes())
+    import sys
+    argv, sys.argv = sys.argv, ['chgcar_charges.py', str(path)]
+    try:
+        b = mod.main()
+    finally:
+        sys.argv = argv
+    assert np.array_equal(b.charge, g['charge'])
+    assert b.atoms_charge.shape[0] == g['atoms'].shape[0]
+    total = b.atoms_charge.sum() + b.vacuum_charge
+    assert abs(total - g['charge'].sum() * b.voxel_volume) < 1e-9 * abs(total)
