@@ -151,16 +151,28 @@ class Bader:
         self.atoms_surface_distance = surface_distance(self.reference, self.atoms_volumes, self.lattice, atoms,
                                                        self.threads)
 
+    @property
+    def spin_bool(self):
+        """interface.py:215-221: the spin density is summed as well when it exists and spin_flag is set."""
+        return bool(self.spin_flag) if self.spin is not None else False
+
     def sum_volumes(self, bader=False):
-        """interface.py:492-525 (charge only; the spin branch re-runs charge_sum on the spin array)."""
+        """interface.py:492-525: charge (and, with spin_bool, spin) and volume per Bader volume or per atom;
+        like the reference the volume array is summed again in the spin pass."""
         if bader:
             n = self.bader_maxima.shape[0]
             self.bader_charge, self.bader_volume = np.zeros(n), np.zeros(n)
             charge_sum(self.bader_charge, self.bader_volume, self.voxel_volume, self.density, self.bader_volumes)
+            if self.spin_bool:
+                self.bader_spin, self.bader_volume = np.zeros(n), np.zeros(n)
+                charge_sum(self.bader_spin, self.bader_volume, self.voxel_volume, self.spin, self.bader_volumes)
         else:
             n = self.atoms.shape[0]
             self.atoms_charge, self.atoms_volume = np.zeros(n), np.zeros(n)
             charge_sum(self.atoms_charge, self.atoms_volume, self.voxel_volume, self.density, self.atoms_volumes)
+            if self.spin_bool:
+                self.atoms_spin, self.atoms_volume = np.zeros(n), np.zeros(n)
+                charge_sum(self.atoms_spin, self.atoms_volume, self.voxel_volume, self.spin, self.atoms_volumes)
 
     def __call__(self, **kwargs):
         """The compute part of Bader.__call__ (interface.py:399-416); export and the pickle/dat output stay

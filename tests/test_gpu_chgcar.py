@@ -113,3 +113,23 @@ def test_end_to_end_example(tmp_path, capsys):
     assert b.atoms_charge.shape[0] == g['atoms'].shape[0]
     total = b.atoms_charge.sum() + b.vacuum_charge
     assert abs(total - g['charge'].sum() * b.voxel_volume) < 1e-9 * abs(total)
+
+
+def test_spin_sums_through_the_mirror(ctx, tmp_path):
+    """with spin_flag the per-atom / per-volume sums run a second time over the spin
+    density (interface.py:505-511, 519-525); checked against plain numpy sums over the final maps."""
+    from pybader_amd.interface import Bader
+    g = np.load(os.path.join(GOLDEN, 'chgcar_f90_16x16x16.npz'))
+    path = tmp_path / 'CHGCAR'
+    path.write_bytes(g['file_bytes'].tobytes())
+    density, lattice, atoms, info = io_vasp.read(str(path), spin_flag=True, ctx=ctx)
+    b = Bader(density, lattice, atoms, info, spin_flag=True)
+    b()
+    vv = b.voxel_volume
+    for lab, q, s_, vol in ((b.bader_volumes, b.bader_charge, b.bader_spin, b.bader_volume),
+                            (b.atoms_volumes, b.atoms_charge, b.atoms_spin, b.atoms_volume)):
+        for k in range(q.shape[0]):
+            m = lab == k
+            assert abs(q[k] - density['charge'][m].sum() * vv) <= 1e-9 * max(1.0, abs(q[k]))
+            assert abs(s_[k] - density['spin'][m].sum() * vv) <= 1e-9 * max(1.0, abs(s_[k]))
+            assert abs(vol[k] - m.sum() * vv) <= 1e-9 * max(1.0, vol[k])
