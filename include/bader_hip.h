@@ -124,7 +124,8 @@ int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capa
 int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *charge, double *volume);
 /* utils.volume_assign (utils.py:404-421): labels[v] = swap[labels[v]] for labels >= 0 */
 int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap);
-/* utils.atom_assign (utils.py:185-232): host-side nearest atom over the 27 periodic images */
+/* utils.atom_assign (utils.py:185-232): nearest atom of every maximum over the 27 periodic images (one
+ * device thread per maximum; context free: buffers on the current device) */
 int xb_atom_assign(const double *bader_max_cart, int64_t n_max, const double *atoms_cart, int64_t n_atoms,
                    const double lattice[9], int64_t *atom_out, double *dist_out);
 

@@ -1248,26 +1248,27 @@ int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap) {
 int xb_atom_assign(const double *b_max, int64_t n_max, const double *atoms, int64_t n_atoms, const double lattice[9],
                    int64_t *atom_out, double *dist_out) {
     if (n_atoms <= 0) return fail(XB_E_ARG, "xb_atom_assign: no atoms");
-    double pbc[3] = {0., 0., 0.};  // utils.py:199: persists across maxima (206-208 read it before the loops)
-    for (int64_t i = 0; i < n_max; i++) {
-        const double *b = b_max + 3 * i;
-        double e0 = b[0] - (atoms[0] + pbc[0]), e1 = b[1] - (atoms[1] + pbc[1]), e2 = b[2] - (atoms[2] + pbc[2]);
-        double best = (e0 * e0 + e1 * e1) + e2 * e2;
-        int64_t who = 0;
-        for (int64_t j = 0; j < n_atoms; j++) {
-            const double *a = atoms + 3 * j;
-            for (int x = -1; x < 2; x++)
-                for (int y = -1; y < 2; y++)
-                    for (int z = -1; z < 2; z++) {
-                        for (int k = 0; k < 3; k++) pbc[k] = (lattice[k] * x + lattice[3 + k] * y) + lattice[6 + k] * z;
-                        e0 = b[0] - (a[0] + pbc[0]); e1 = b[1] - (a[1] + pbc[1]); e2 = b[2] - (a[2] + pbc[2]);
-                        const double d = (e0 * e0 + e1 * e1) + e2 * e2;
-                        if (d < best) { best = d; who = j; }
-                    }
-        }
-        atom_out[i] = who;
-        dist_out[i] = std::sqrt(best);
+    if (n_max <= 0) return XB_OK;
+    if (n_max > (1LL << 30) || n_atoms > (1LL << 24)) return fail(XB_E_LIMIT, "xb_atom_assign: too many maxima / atoms");
+    // context free (the reference calls it without a grid): buffers on the current device, default stream
+    double *d = nullptr;
+    const size_t nd = 3 * (size_t)n_max + 3 * (size_t)n_atoms + 9 + (size_t)n_max;   // maxima, atoms, lattice, distances
+    hipError_t e = hipMalloc(&d, nd * sizeof(double) + (size_t)n_max * sizeof(long long));
+    if (e != hipSuccess) return fail(XB_E_HIP, "xb_atom_assign: %s", hipGetErrorString(e));
+    double *dmax = d, *datoms = d + 3 * n_max, *dlat = datoms + 3 * n_atoms, *ddist = dlat + 9;
+    long long *dwho = reinterpret_cast<long long *>(ddist + n_max);
+    e = hipMemcpy(dmax, b_max, 3 * n_max * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(datoms, atoms, 3 * n_atoms * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dlat, lattice, 9 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_atom_assign<<<(unsigned)((n_max + 63) / 64), 64>>>(dmax, (int)n_max, datoms, (int)n_atoms, dlat, dwho, ddist);
+        e = hipGetLastError();
     }
+    static_assert(sizeof(long long) == sizeof(int64_t), "label width");
+    if (e == hipSuccess) e = hipMemcpy(atom_out, dwho, n_max * sizeof(long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(dist_out, ddist, n_max * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(XB_E_HIP, "xb_atom_assign: %s", hipGetErrorString(e));
     return XB_OK;
 }
 

@@ -112,3 +112,33 @@ __global__ void k_narrow(const int *__restrict__ in, T *__restrict__ out, long l
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (T)in[i];
 }
+
+// utils.atom_assign (utils.py:185-232): nearest atom of every Bader maximum over the 27 periodic images,
+// squared distances compared with strict '<' in the reference's loop order (atoms, then x, y, z images), one
+// thread per maximum.  The reference's `pbc` vector persists across maxima (utils.py:199, 206-208): the
+// starting distance of maximum i > 0 uses the image vector the previous maximum's loops ended on, (+1,+1,+1).
+__global__ void k_atom_assign(const double *__restrict__ b_max, int n_max, const double *__restrict__ atoms, int n_atoms,
+                              const double *__restrict__ lattice, long long *atom_out, double *dist_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max) return;
+    double pbc[3] = {0., 0., 0.};
+    if (i > 0)
+        for (int k = 0; k < 3; k++) pbc[k] = (lattice[k] * 1 + lattice[3 + k] * 1) + lattice[6 + k] * 1;
+    const double b0 = b_max[3 * i], b1 = b_max[3 * i + 1], b2 = b_max[3 * i + 2];
+    double e0 = b0 - (atoms[0] + pbc[0]), e1 = b1 - (atoms[1] + pbc[1]), e2 = b2 - (atoms[2] + pbc[2]);
+    double best = (e0 * e0 + e1 * e1) + e2 * e2;
+    long long who = 0;
+    for (int j = 0; j < n_atoms; j++) {
+        const double a0 = atoms[3 * j], a1 = atoms[3 * j + 1], a2 = atoms[3 * j + 2];
+        for (int x = -1; x < 2; x++)
+            for (int y = -1; y < 2; y++)
+                for (int z = -1; z < 2; z++) {
+                    for (int k = 0; k < 3; k++) pbc[k] = (lattice[k] * x + lattice[3 + k] * y) + lattice[6 + k] * z;
+                    e0 = b0 - (a0 + pbc[0]); e1 = b1 - (a1 + pbc[1]); e2 = b2 - (a2 + pbc[2]);
+                    const double d = (e0 * e0 + e1 * e1) + e2 * e2;
+                    if (d < best) { best = d; who = j; }
+                }
+    }
+    atom_out[i] = who;
+    dist_out[i] = sqrt(best);
+}

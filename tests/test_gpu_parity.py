@@ -257,6 +257,19 @@ def test_edge_check_queue_overflow_hand_over(ctx, groups, qcap):
         ctx.set_option(5, 6000)
 
 
+def test_atom_assign_matches_oracle(ctx):
+    """k_atom_assign against the oracle, bit for bit (assigned atom and distance), incl. the reference's
+    carried-over `pbc` vector (utils.py:199)."""
+    import oracle
+    rng = np.random.default_rng(3)
+    lat = np.array([[6.0, 0.0, 0.0], [1.5, 5.5, 0.0], [0.7, 1.1, 6.2]])
+    atoms = rng.random((7, 3)) @ lat
+    bmax = rng.random((400, 3)) @ lat
+    a, d = _lib.atom_assign(bmax, atoms, lat)
+    a2, d2 = oracle.atom_assign(bmax, atoms, lat)
+    assert np.array_equal(a, a2) and np.array_equal(d, d2)
+
+
 def test_edge_check_kernel_level(ctx):
     """edge_check alone on a hand-made `known`: every voxel of a random subset flagged changed."""
     import oracle
