@@ -117,6 +117,17 @@ static GridL light(const Grid &g) {
     return l;
 }
 
+// temporary device memory that is released on every return path
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)); }
+    ~DevBuf() { hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
 // the 14-distance form of the grid for the tiled field kernels; false when dist_mat is not symmetric
 static bool sym_grid(const Grid &g, GridS &s) {
     s.nx = g.nx; s.ny = g.ny; s.nz = g.nz; s.nyz = g.nyz;
@@ -700,20 +711,19 @@ static int read_counter(xb_ctx *c, int idx, int *out) {
 // run the exact slow kernel over ovf_list[0..n) in chunks
 static int run_slow(xb_ctx *c, int n, int refine) {
     const int lmax = 1 << 15, chunk = 2048;
-    int *path = nullptr;
-    HIPCHK(hipMalloc(&path, (size_t)chunk * lmax * sizeof(int)));
+    DevBuf<int> path;
+    HIPCHK(path.alloc((size_t)chunk * lmax));
     HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));  // err
     for (int o = 0; o < n; o += chunk) {
         const int m = std::min(chunk, n - o);
         k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
-                                                         c->ovf_list + o, m, path, lmax, refine, c->first,
+                                                         c->ovf_list + o, m, path.p, lmax, refine, c->first,
                                                          c->max_list, c->counters + 0, c->max_cap,
                                                          c->counters + 2, c->counters + 3, c->counters + 8, nullptr);
     }
     hipError_t e = hipGetLastError();
     int err = 0;
-    int rc = read_counter(c, 8, &err);
-    hipFree(path);
+    int rc = read_counter(c, 8, &err);   // synchronises the stream: the scratch may go afterwards
     if (e != hipSuccess) return fail(XB_E_HIP, "k_trace_slow: %s", hipGetErrorString(e));
     if (rc) return rc;
     if (err) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", lmax);
@@ -979,9 +989,10 @@ int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_vo
     if (n) {
         if (max_len < 2 || max_len > (1 << 15)) return fail(XB_E_ARG, "xb_escaped_paths: max_len out of range");
         const int lmax = (int)max_len, chunk = (int)std::max<int64_t>(256, std::min<int64_t>(8192, (32LL << 20) / max_len));
-        int *path = nullptr, *dlen = nullptr, *packed = nullptr;
-        HIPCHK(hipMalloc(&path, (size_t)chunk * lmax * sizeof(int)));
-        HIPCHK(hipMalloc(&dlen, 3 * chunk * sizeof(int)));   // lengths, first out-of-range indices, offsets
+        DevBuf<int> bpath, blen;
+        HIPCHK(bpath.alloc((size_t)chunk * lmax));
+        HIPCHK(blen.alloc(3 * (size_t)chunk));   // lengths, first out-of-range indices, offsets
+        int *path = bpath.p, *dlen = blen.p, *packed = nullptr;
         std::vector<int> starts(n), len(2 * chunk), off(chunk), buf;
         HIPCHK(hipMemcpyAsync(starts.data(), c->list, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         int rc = XB_OK;
@@ -1020,7 +1031,6 @@ int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_vo
                 c->esc_complete.push_back(len[i] > 0 ? 1 : 0);
             }
         }
-        hipFree(path); hipFree(dlen);
         if (rc != XB_OK) return rc;
     }
     if (n_paths) *n_paths = (int64_t)c->esc_starts.size();
@@ -1044,8 +1054,9 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         if (idx[k] < 0 || idx[k] >= c->N) return fail(XB_E_ARG, "voxel index out of range");
         i32[k] = (int)idx[k];
     }
-    int *d = nullptr;
-    HIPCHK(hipMalloc(&d, (size_t)n * (2 * sizeof(int) + 1)));
+    DevBuf<int> buf;
+    HIPCHK(buf.alloc(2 * (size_t)n + (size_t)n / 4 + 1));   // indices, labels, known bytes
+    int *d = buf.p;
     int *dlab = d + n;
     int8_t *dkn = reinterpret_cast<int8_t *>(d + 2 * n);
     hipError_t e = hipMemcpyAsync(d, i32.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream);
@@ -1061,7 +1072,6 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         if (e == hipSuccess) e = hipMemcpyAsync(kn, dkn, n, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
     if (e != hipSuccess) return fail(XB_E_HIP, "xb_gather/scatter_voxels: %s", hipGetErrorString(e));
     return XB_OK;
 }
@@ -1201,10 +1211,12 @@ int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *char
     if (n_labels <= 0) return XB_OK;
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
-    double *dch = nullptr;
-    unsigned long long *dcn = nullptr;
-    HIPCHK(hipMalloc(&dch, n_labels * sizeof(double)));
-    HIPCHK(hipMalloc(&dcn, n_labels * sizeof(unsigned long long)));
+    DevBuf<double> bch;
+    DevBuf<unsigned long long> bcn;
+    HIPCHK(bch.alloc(n_labels));
+    HIPCHK(bcn.alloc(n_labels));
+    double *dch = bch.p;
+    unsigned long long *dcn = bcn.p;
     HIPCHK(hipMemsetAsync(dch, 0, n_labels * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(dcn, 0, n_labels * sizeof(unsigned long long), c->stream));
     if (n_labels <= CS_BINS) {
@@ -1218,8 +1230,6 @@ int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *char
     if (e == hipSuccess) e = hipMemcpyAsync(charge, dch, n_labels * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(cn.data(), dcn, n_labels * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(dch);
-    hipFree(dcn);
     if (e != hipSuccess) return fail(XB_E_HIP, "xb_charge_sum: %s", hipGetErrorString(e));
     for (int64_t i = 0; i < n_labels; i++) {
         charge[i] *= voxel_volume;  // utils.py:251-252
