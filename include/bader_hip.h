@@ -92,6 +92,9 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local);
 int xb_assign_local_table(xb_ctx *c, int64_t *max_idx, int64_t *first_idx, int64_t capacity);
 int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global);
 
+/* optional, before the first xb_edge_find of a refinement: build what xb_refine_trace needs (the gradient-field
+ * table of the resident density) now, so that edge_find can read "not a maximum" off it (xb_refine does it) */
+int xb_prepare_refine(xb_ctx *c);
 /* refinement.edge_find (refinement.py:326-405) on a fresh `known`: -2 edge, -1 within the 27-box
  * of an edge, 2 other non-vacuum, 0 untouched vacuum.  Returns the edge count of the owned slab. */
 int xb_edge_find(xb_ctx *c, int64_t *edges);

@@ -37,6 +37,7 @@ SYMBOLS = {
     'xb_assign_trace': (_int, [_vp, _int, _pi64]),
     'xb_assign_local_table': (_int, [_vp, _vp, _vp, _i64]),
     'xb_assign_finish': (_int, [_vp, _vp, _i64]),
+    'xb_prepare_refine': (_int, [_vp]),
     'xb_edge_find': (_int, [_vp, _pi64]),
     'xb_refine_trace': (_int, [_vp, _pi64, _pi64]),
     'xb_refine_trace_escaped': (_int, [_vp, _pi64, _pi64]),
@@ -211,6 +212,9 @@ class Context:
         ms = np.ascontiguousarray(max_sorted, dtype=np.int64)
         check(self.lib.xb_assign_finish(self.h, _ptr(ms), ms.shape[0]))
         self.n_maxima = int(ms.shape[0])
+
+    def prepare_refine(self):
+        check(self.lib.xb_prepare_refine(self.h))
 
     def edge_find(self):
         n = C.c_int64()

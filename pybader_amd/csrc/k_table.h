@@ -142,10 +142,16 @@ __global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restri
 // The ongrid pointer of every voxel (methods.py:84-117) from the same staged tile: labels[v] = linear
 // index of the best distance-weighted neighbour (v itself for a 26-neighbour maximum); vacuum voxels
 // (label -1) keep their -1 (methods.py:73-74).
+// With `bmask` (grids of whole 8^3 bricks) the pass also reduces, per brick, which neighbour bricks the ongrid
+// move of any of its voxels enters (bit 27: the brick holds a 26-neighbour maximum) and lists the maxima, so
+// that the trapping regions of the ongrid pointer field can be grown exactly like the neargrid ones.
 template <typename GT>
 __global__ __launch_bounds__(TPB) void k_og_pointer_tiled(GT g, const double *__restrict__ rho, int *labels,
-                                                          int small, int has_vacuum) {
+                                                          int small, int has_vacuum, int *seeds, int *seed_count,
+                                                          int seed_cap, int *__restrict__ bmask) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
+    __shared__ int s_mask[GT_Z / 8];
+    if (threadIdx.x < GT_Z / 8) s_mask[threadIdx.x] = 0;
     const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
     {
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(TPB) void k_og_pointer_tiled(GT g, const double *__
     }
     __syncthreads();
     const int tz = threadIdx.x & (GT_Z - 1), ty = threadIdx.x / GT_Z;
+    int mine = 0;
 #pragma unroll 1
     for (int tx = 0; tx < GT_X; tx++) {
         const int x = x0 + tx, y = y0 + ty, z = z0 + tz;
@@ -198,6 +205,24 @@ __global__ __launch_bounds__(TPB) void k_og_pointer_tiled(GT g, const double *__
                 }
         const int qx = wrapi(x + og / 9 - 1, g.nx), qy = wrapi(y + (og / 3) % 3 - 1, g.ny), qz = wrapi(z + og % 3 - 1, g.nz);
         labels[v] = (qx * g.ny + qy) * g.nz + qz;
+        if (bmask) {
+            if (og == XB_OG_SELF) {
+                const int q = atomicAdd(seed_count, 1);
+                if (q < seed_cap) seeds[q] = v;
+                mine |= 1 << 27;
+            }
+            const int a = tx + og / 9 - 1, b = ty + (og / 3) % 3 - 1, c2 = (tz & 7) + og % 3 - 1;
+            const int k0 = a < 0 ? 0 : (a >= 8 ? 2 : 1), k1 = b < 0 ? 0 : (b >= 8 ? 2 : 1), k2 = c2 < 0 ? 0 : (c2 >= 8 ? 2 : 1);
+            mine |= 1 << (k0 * 9 + k1 * 3 + k2);
+        }
+    }
+    if (bmask) {
+        atomicOr(&s_mask[tz >> 3], mine);
+        __syncthreads();
+        if (threadIdx.x < GT_Z / 8 && z0 + threadIdx.x * 8 < g.nz) {
+            const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+            bmask[((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x] = s_mask[threadIdx.x] & ~(1 << 13);
+        }
     }
 }
 

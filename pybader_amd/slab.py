@@ -442,6 +442,9 @@ class SlabRunner:
         if iters == 0:
             return log
         self.exchange_label_halo()
+        if hasattr(self.be, 'prepare_refine') and not getattr(self, 'windowed', False):
+            with _Phase(self, 'table_build'):
+                self.be.prepare_refine()     # the retraces need the table anyway; edge_find profits from it
         with _Phase(self, 'edge_find'):
             edges = self.be.edge_find()
         if self.comm.size > 1:
