@@ -63,7 +63,7 @@ struct xb_ctx {
     int opt_boxes = 1;
     int opt_bricks = 1;
     int opt_dbg = 0;
-    int opt_ec_groups = 64;     // workgroups of k_ec_chase
+    int opt_ec_groups = 256;    // workgroups of k_ec_chase (at most one per CU)
     int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
     std::vector<int64_t> esc_starts, esc_offsets, esc_vox;  // xb_escaped_paths -> xb_escaped_paths_fetch
     std::vector<int8_t> esc_complete;
@@ -1176,15 +1176,17 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (edges) *edges = 0;
     if (!n) return XB_OK;
     {
-        // greedy resolution (k_edges.h): round 1 over the whole edge list as one launch, then the dependency
-        // chains are chased asynchronously by a small grid of workgroups; queue overflows seed another launch.
-        // Scratch: the class cache in `st`, seed/overflow lists in the staging buffer (2 x N ints).
-        int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
-        const int cap = (int)std::min<long long>(c->N, 1LL << 30);
-        HIPCHK(hipMemsetAsync(c->st, 0, c->N, c->stream));
+        // greedy resolution by dependency counters (k_edges.h): counters + classes for the whole list, round 1
+        // over the whole list, then the dependency chains are chased asynchronously by a small grid of
+        // workgroups; queue overflows seed another launch.  Scratch in the staging buffer (8 N bytes): two
+        // seed / overflow lists of N/2 ints each, then the 16 bits per voxel of the counters.
+        const int cap = (int)std::min<long long>(c->N / 2, 1LL << 30);
+        int *buf[2] = {(int *)c->stage, (int *)c->stage + cap};
+        unsigned int *pend_w = reinterpret_cast<unsigned int *>((int *)c->stage + 2 * (size_t)cap + 4);
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-        k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(
-            g, c->rho, c->labels, c->known, c->list, n, buf[0], c->counters + 6, cap, c->st);
+        k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, reinterpret_cast<uint16_t *>(pend_w));
+        k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
+                                                                                         c->counters + 6, cap);
         HIPCHK(hipGetLastError());
         int n_seeds = 0;
         if (int rc = read_counter(c, 6, &n_seeds)) return rc;
@@ -1192,9 +1194,9 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
             if (n_seeds > cap) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
             if (pass > 256) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
             HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-            const int groups = (int)std::min<long long>(std::max(1, n_seeds / 512), c->opt_ec_groups);
-            k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->rho, c->labels, c->known, buf[pass & 1], n_seeds,
-                                                                   buf[1 - (pass & 1)], c->counters + 6, cap, c->st, c->opt_ec_qcap);
+            const int groups = (int)std::min<long long>(std::max(1, n_seeds / 64), c->opt_ec_groups);
+            k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->known, pend_w, buf[pass & 1], n_seeds, buf[1 - (pass & 1)],
+                                                                   c->counters + 6, cap, c->opt_ec_qcap);
             HIPCHK(hipGetLastError());
             const int before = n_seeds;
             if (int rc = read_counter(c, 6, &n_seeds)) return rc;

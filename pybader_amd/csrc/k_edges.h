@@ -448,121 +448,174 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
 #define EC_PROC (-4)
 #define EC_SKIP (-10)
 // ---------------------------------------------------------------------------------------------
-// One evaluation of edge voxel v against the statuses of its 27-box (refinement.py:428-470 in
-// dependency order): returns 0 when v is not (or no longer) undecided or still has to wait for an
-// earlier neighbour, else the decision (1 processed / 2 skipped) and in `later` the box voxels that
-// come later in C order and are still undecided (bit j = (ix+1)*9+(iy+1)*3+(iz+1)) -- they may be
-// waiting for v.  A decision depends only on statuses that are themselves final, so it is the
-// sequential one whenever it can be taken.
-// COHERENT: the status bytes are read with device-scope (sc1) loads, which resolve at the device
-// coherence point (the workgroups of k_ec_chase sit on different XCDs, one L2 each).
-// EAGER_CLASS (round 1): classify v in any case, so that the chase never has a classification (two more
-// dependent round trips) on its critical path.
-template <bool COHERENT, bool EAGER_CLASS>
-__device__ __forceinline__ int ec_evaluate(const Grid &g, const double *__restrict__ rho,
-                                           const int *__restrict__ labels, const int8_t *known, int v,
-                                           int8_t *cls_cache, unsigned int &later, int rows[9], int &z, bool &z_inner) {
-    int8_t cls = __builtin_nontemporal_load(&cls_cache[v]);  // 0 unknown, 1 edge&max, 2 other (static here)
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz;
-    z = r - y * g.nz;
-    bool blocked = false, has_proc = false;
-    later = 0;
-    int8_t kc = 0;
-    z_inner = z >= 1 && z + 2 < g.nz;  // z-1..z+1 contiguous, and the 4th byte of the load stays inside the row
+// Resolution by dependency counters (a topological order of the greedy choice).  Per listed voxel 16 bits of
+// `pend` (indexed by voxel):
+//     bits 0-7   number of C-order EARLIER listed neighbours that have not decided yet
+//     bits 8-14  number of earlier neighbours that were processed
+//     bit  15    the voxel is an edge&maximum voxel (processed whatever its neighbours do)
+// A voxel is decidable as soon as bit 15 is set (processed), an earlier neighbour was processed (skipped) or
+// the counter reaches zero (processed); the lane that decides it (claim by atomicAnd on the status word: one
+// winner in the grid) tells every LATER listed neighbour with ONE atomicAdd on its 16 bits (-1, or +0x100-1
+// when it was processed itself) and queues exactly the neighbours that became decidable through it (first
+// processed neighbour, or the decrement that reached zero with none processed).  Every voxel is evaluated once,
+// from its 16 bits alone (when the counter reaches zero every earlier neighbour has already contributed), so a
+// chain step costs a couple of device-scope round trips instead of re-reading 27 statuses for every wake-up;
+// the result is the sequential one because each rule is the reference's (refinement.py:428-470) applied to
+// final inputs.  `known` of a listed voxel is -2 / -4 / -10 at any time, which is how the later listed
+// neighbours are found (membership does not change).
+// The code below is written branch-free on purpose: with a branch per neighbour the compiler waits for every
+// load / atomic before it issues the next one (measured: ~20 serial round trips, 10 us per chain step).
+// ---------------------------------------------------------------------------------------------
+#define EC_CNT 0x00FFu
+#define EC_NPROC 0x7F00u
+#define EC_CLS1 0x8000u
+__device__ __forceinline__ bool ec_listed(int8_t k) { return k == -2 || k == EC_PROC || k == EC_SKIP; }
+// status bytes of the 27-box of (x,y,z) as 9 words: byte (iz+1) of word (ix+1)*3+(iy+1); all loads in flight
+__device__ __forceinline__ void ec_box(const Grid &g, const int8_t *__restrict__ known, int x, int y, int z, int rows[9],
+                                       unsigned int w[9]) {
+    const bool z_inner = z >= 1 && z + 2 < g.nz;
+    const int zm = wrapi(z - 1, g.nz), zp = wrapi(z + 1, g.nz);
 #pragma unroll
     for (int ix = -1; ix < 2; ix++) {
         const int tx = wrapi(x + ix, g.nx);
 #pragma unroll
         for (int iy = -1; iy < 2; iy++) {
-            const int ty = wrapi(y + iy, g.ny);
-            const int row = (tx * g.ny + ty) * g.nz;
+            const int row = (tx * g.ny + wrapi(y + iy, g.ny)) * g.nz;
             rows[(ix + 1) * 3 + iy + 1] = row;
-            unsigned int w = 0;
-            if (z_inner) {  // one (unaligned) 32-bit load instead of three byte loads: the rounds are TA-bound
-                const unsigned int *wp = reinterpret_cast<const unsigned int *>(known + row + z - 1);
-                w = COHERENT ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __builtin_nontemporal_load(wp);
-            }
-#pragma unroll
-            for (int iz = -1; iz < 2; iz++) {
-                const int tz = z_inner ? z + iz : wrapi(z + iz, g.nz);
-                const int l = row + tz;
-                int8_t k;
-                if (z_inner) k = (int8_t)((w >> (8 * (iz + 1))) & 0xff);
-                else k = COHERENT ? __hip_atomic_load(&known[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                  : __builtin_nontemporal_load(&known[l]);
-                if (l < v) {
-                    blocked |= (k == -2);
-                    has_proc |= (k == EC_PROC);
-                } else if (l > v) {
-                    if (k == -2) later |= 1u << ((ix + 1) * 9 + (iy + 1) * 3 + iz + 1);
-                } else kc = k;
-            }
         }
     }
-    if (kc != -2) return 0;
-    if (!EAGER_CLASS && !blocked && !has_proc) return 1;
-    if (!cls) {
+    if (z_inner) {  // z-1..z+1 contiguous: one (unaligned) 32-bit load per row
+#pragma unroll
+        for (int k = 0; k < 9; k++) w[k] = *reinterpret_cast<const unsigned int *>(known + rows[k] + z - 1);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            w[k] = (unsigned int)(uint8_t)known[rows[k] + zm] | ((unsigned int)(uint8_t)known[rows[k] + z] << 8) |
+                   ((unsigned int)(uint8_t)known[rows[k] + zp] << 16);
+    }
+}
+__device__ __forceinline__ int ec_box_voxel(const Grid &g, const int rows[9], int z, int j) {
+    return rows[j / 3] + wrapi(z + (j % 3) - 1, g.nz);
+}
+// pend[v] := (listed earlier neighbours) | (edge&max ? bit 15); every listed voxel once, nothing decided yet
+__global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
+                                                 const int8_t *__restrict__ known, const int *__restrict__ list, int n,
+                                                 uint16_t *pend) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    int rows[9];
+    unsigned int w[9];
+    ec_box(g, known, x, y, z, rows, w);
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 27; j++) {
+        const int8_t k = (int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff);
+        cnt += (ec_box_voxel(g, rows, z, j) < v) & (k == -2);
+    }
+    // class: edge & maximum.  A denser non-vacuum FACE neighbour already rules the maximum out (13 loads
+    // instead of the 54 of the full classification)
+    const double c0 = rho[v];
+    bool denser = false;
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+        const int d = (f & 1) ? 1 : -1;
+        const int l = f < 2 ? lin3(g, wrapi(x + d, g.nx), y, z) : (f < 4 ? lin3(g, x, wrapi(y + d, g.ny), z) : lin3(g, x, y, wrapi(z + d, g.nz)));
+        denser |= (labels[l] != -1) & (rho[l] > c0);
+    }
+    bool cls1 = false;
+    if (!denser) {
         bool is_edge, is_max;
         classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
-        cls = (is_edge && is_max) ? 1 : 2;
-        cls_cache[v] = cls;  // racing writers store the same value
+        cls1 = is_edge && is_max;
     }
-    if (cls == 1 || (!blocked && !has_proc)) return 1;
-    return has_proc ? 2 : 0;
+    pend[v] = (uint16_t)(cnt | (cls1 ? EC_CLS1 : 0u));
 }
-__device__ __forceinline__ int ec_later_voxel(const Grid &g, const int rows[9], int z, bool z_inner, int j) {
-    return rows[j / 3] + (z_inner ? z + (j % 3) - 1 : wrapi(z + (j % 3) - 1, g.nz));
-}
-// Round 1: every listed edge voxel once (one launch over the whole list; the kernel boundary publishes
-// the statuses).  The undecided later neighbours of the decided voxels are the seeds of k_ec_chase
-// (with duplicates: a voxel is listed once per decided earlier neighbour).
-__global__ __launch_bounds__(TPB) void k_ec_first(Grid g, const double *__restrict__ rho,
-                                                  const int *__restrict__ labels, int8_t *known,
-                                                  const int *__restrict__ in, int n, int *out, int *n_out, int out_cap,
-                                                  int8_t *cls_cache) {
-    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        const int v = in[e];
-        unsigned int later;
-        int rows[9], z;
-        bool z_inner;
-        const int d = ec_evaluate<false, false>(g, rho, labels, known, v, cls_cache, later, rows, z, z_inner);
-        if (!d) continue;
-        known[v] = d == 1 ? (int8_t)EC_PROC : (int8_t)EC_SKIP;
-        if (!later) continue;
-        int at = atomicAdd(n_out, __popc(later));
+// Decide v if its 16 bits allow it and tell the later listed neighbours; push(u) receives every voxel that became
+// decidable through this decision.  A voxel from the blanket scan of round 1 may not be decidable yet; one from
+// a queue always is.
+template <typename Push>
+__device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigned int *pend_w, int v, Push push) {
+    const unsigned int b = (__hip_atomic_load(pend_w + (v >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> ((v & 1) * 16)) & 0xffffu;
+    int d;
+    if (b & EC_CLS1) d = 1;
+    else if (b & EC_NPROC) d = 2;
+    else if ((b & EC_CNT) == 0) d = 1;
+    else return;  // still waiting for an earlier neighbour (blanket scan only)
+    {   // claim + publish: one atomicAnd clears the decision's bit of 0xFE; the returned word names the winner
+        const int sh = (v & 3) * 8;
+        const unsigned int old = atomicAnd(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh));
+        if (((old >> sh) & 0xffu) != 0xFEu) return;
+    }
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    int rows[9];
+    unsigned int w[9];
+    ec_box(g, known, x, y, z, rows, w);
+    // the later listed neighbours as a bit set over the box positions
+    unsigned int later = 0;
 #pragma unroll
-        for (int j = 0; j < 27; j++)
-            if ((later >> j) & 1u) {
-                if (at < out_cap) out[at] = ec_later_voxel(g, rows, z, z_inner, j);
-                at++;
-            }
+    for (int j = 0; j < 27; j++) {
+        const int u = ec_box_voxel(g, rows, z, j);
+        if ((u > v) & ec_listed((int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff))) later |= 1u << j;
+    }
+    // One atomicAdd per neighbour, issued together (13 slots: the number of later positions away from the
+    // periodic seam; an empty slot adds 0 to v's own word, harmless and on the same cache line).  The atomics
+    // of a workgroup share one CU's address unit, so 13 instead of one per box position matters.
+    const unsigned int delta = d == 1 ? 0xFFu : 0xFFFFFFFFu;  // +0x100 - 1  |  -1   (shifted into the voxel's half)
+    unsigned int o[10];
+    int uu[10];
+#pragma unroll
+    for (int s = 0; s < 10; s++) {
+        const bool hit = later != 0;
+        const int j = hit ? __ffs(later) - 1 : 13;
+        later &= later - 1;
+        const int u = hit ? ec_box_voxel(g, rows, z, j) : v;
+        uu[s] = hit ? u : -1;
+        o[s] = atomicAdd(pend_w + (u >> 1), hit ? delta << ((u & 1) * 16) : 0u) >> ((u & 1) * 16);
+    }
+#pragma unroll
+    for (int s = 0; s < 10; s++) {
+        const unsigned int ob = o[s] & 0xffffu;
+        const bool wake = (uu[s] >= 0) & !(ob & (EC_NPROC | EC_CLS1)) & ((d == 1) | ((ob & EC_CNT) == 1));
+        if (wake) push(uu[s]);   // first processed earlier neighbour (u gets skipped) / the last one u waited for
+    }
+    while (later) {  // more than 13 later neighbours: only next to the periodic seam
+        const int u = ec_box_voxel(g, rows, z, __ffs(later) - 1);
+        later &= later - 1;
+        const unsigned int ob = (atomicAdd(pend_w + (u >> 1), delta << ((u & 1) * 16)) >> ((u & 1) * 16)) & 0xffffu;
+        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1)) push(u);
     }
 }
-// The rest of the resolution.  The dependency chains are ~1000 voxels long while only a few thousand
-// voxels are decidable at any time, so global rounds (a launch or a grid barrier each) cost 20-40 us
-// per chain step.  Here every workgroup chases its own share asynchronously -- no barrier, no waiting
-// on another workgroup: a round evaluates the workgroup's queue (LDS); a lane that decides a voxel
-// claims it with an atomicAnd on the aligned word holding its status byte (one winner in the whole
-// grid, so nothing is woken twice) and queues the voxel's still undecided later neighbours for the
-// workgroup's next round.  A candidate that is still blocked is dropped: whoever decides its last
-// blocker queues it again.  No wake-up is lost: of two lanes deciding the two last blockers of w, the one
-// whose atomic lands second evaluates w only after that atomic has returned, and its (sc1) loads then see the
-// first one's.  No __threadfence(): on the 8-XCD gfx950 an agent-scope fence writes back and invalidates
-// the XCD's L2 (~2 us each).  A chain step costs one workgroup round = two memory round trips.
+// Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
+// decided, the voxels that become decidable through these decisions seed the chase.
+__global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, unsigned int *pend_w, const int *__restrict__ in,
+                                                  int n, int *out, int *n_out, int out_cap) {
+    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
+        ec_resolve(g, known, pend_w, in[e], [&](int u) {
+            const int at = atomicAdd(n_out, 1);
+            if (at < out_cap) out[at] = u;
+        });
+}
+// The rest: the dependency chains are ~1000 voxels long while only a few thousand voxels are decidable at any
+// time, so global rounds (a launch or a grid barrier each) would cost 20-40 us per chain step.  Every workgroup
+// chases its own share asynchronously instead -- no barrier across workgroups, nothing waits on another
+// workgroup: a round resolves the workgroup's queue (LDS) and queues what became decidable for its next
+// round.  All cross-workgroup traffic is device-scope atomics on the status and counter words (they resolve at
+// the device coherence point; the workgroups sit on different XCDs, one L2 each) -- no __threadfence(): on the
+// 8-XCD gfx950 an agent-scope fence writes back and invalidates the XCD's L2 (~2 us each).
 // Queue overflows go to `ovf` and seed the next launch.
 #define EC_CHASE_THREADS 1024
 #define EC_Q 6000   // queue entries per buffer (2 buffers, 47 KB of LDS)
-#define EC_SEEN 4096  // direct-mapped filter of the voxels already queued for the next round (16 KB)
-__global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const double *__restrict__ rho,
-                                                               const int *__restrict__ labels, int8_t *known,
-                                                               const int *__restrict__ seeds, int n_seeds,
-                                                               int *ovf, int *n_ovf, int ovf_cap, int8_t *cls_cache,
-                                                               int qcap) {
+__global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *known, unsigned int *pend_w,
+                                                               const int *__restrict__ seeds, int n_seeds, int *ovf,
+                                                               int *n_ovf, int ovf_cap, int qcap) {
     __shared__ int q[2][EC_Q];
     __shared__ int s_n[2];
-    __shared__ int seen[EC_SEEN];
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
     const int seed_end = min(seed_cur + per, n_seeds);
@@ -574,46 +627,20 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, const dou
         if (n + take == 0) break;
         __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
         if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
-        for (int i = threadIdx.x; i < EC_SEEN; i += EC_CHASE_THREADS) seen[i] = -1;
-        __syncthreads();
+        int *nq = q[cur ^ 1], *n_next = &s_n[cur ^ 1];
         for (int e = threadIdx.x; e < n + take; e += EC_CHASE_THREADS) {
             const int v = e < n ? q[cur][e] : seeds[seed_cur + e - n];
-            unsigned int later;
-            int rows[9], z;
-            bool z_inner;
-            const int d = ec_evaluate<true, false>(g, rho, labels, known, v, cls_cache, later, rows, z, z_inner);
-            if (!d) continue;
-            // claim + publish: one atomicAnd clears the decision's bit in the status byte; the lane that finds
-            // the byte still 0xFE in the returned word is the (only) winner
-            unsigned int *wp = reinterpret_cast<unsigned int *>(known + (v & ~3));
-            const int sh = (v & 3) * 8;
-            const unsigned int old = atomicAnd(wp, ~((d == 1 ? 0x02u : 0x08u) << sh));
-            const bool won = ((old >> sh) & 0xffu) == 0xFEu;
-            if (!won || !later) continue;
-            // a voxel woken by several of its earlier neighbours in the same round is queued once (the filter
-            // may miss duplicates on a slot collision: they are only evaluated twice, see above)
-#pragma unroll
-            for (int j = 0; j < 27; j++)
-                if ((later >> j) & 1u) {
-                    const int l = ec_later_voxel(g, rows, z, z_inner, j);
-                    if (atomicExch(&seen[(unsigned)(l * 0x9E3779B1u) >> 20], l) == l) later &= ~(1u << j);
+            ec_resolve(g, known, pend_w, v, [&](int u) {
+                const int at = atomicAdd(n_next, 1);
+                if (at < qcap) nq[at] = u;
+                else {  // queue full: hand over to the next launch
+                    const int o = atomicAdd(n_ovf, 1);
+                    if (o < ovf_cap) ovf[o] = u;
                 }
-            if (!later) continue;
-            int at = atomicAdd(&s_n[cur ^ 1], __popc(later));
-#pragma unroll
-            for (int j = 0; j < 27; j++)
-                if ((later >> j) & 1u) {
-                    const int l = ec_later_voxel(g, rows, z, z_inner, j);
-                    if (at < qcap) q[cur ^ 1][at] = l;
-                    else {
-                        const int o = atomicAdd(n_ovf, 1);
-                        if (o < ovf_cap) ovf[o] = l;
-                    }
-                    at++;
-                }
+            });
         }
         seed_cur += take;
-        __syncthreads();  // the next round's queue is complete (every claim has returned: its result was used)
+        __syncthreads();  // the next round's queue is complete (every atomic's result was used: they have returned)
     }
 }
 // the voxels the resolution left undecided (must be none) are counted for a loud failure

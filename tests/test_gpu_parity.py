@@ -253,7 +253,7 @@ def test_edge_check_queue_overflow_hand_over(ctx, groups, qcap):
         assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['ng_changed_inf_log'])
         assert np.array_equal(ctx.download_labels(g['ng_changed_inf'].dtype), g['ng_changed_inf'])
     finally:
-        ctx.set_option(4, 64)
+        ctx.set_option(4, 256)
         ctx.set_option(5, 6000)
 
 
