@@ -35,9 +35,13 @@ __device__ __forceinline__ void classify27(const Grid &g, const double *__restri
     }
     if (!is_edge) return;  // is_max only matters for edges (refinement.py:376-383)
     const double max_val = rho[v];
+    // unconditional loads (a vacuum neighbour reads rho[v] instead): with a branch per neighbour the compiler
+    // waits for each load before it issues the next, 27 serial round trips
+    double nr[27];
 #pragma unroll
-    for (k = 0; k < 27; k++)
-        if (nb[k] >= 0 && rho[nb[k]] > max_val) is_max = false;
+    for (k = 0; k < 27; k++) nr[k] = rho[nb[k] >= 0 ? nb[k] : v];
+#pragma unroll
+    for (k = 0; k < 27; k++) is_max &= !(nr[k] > max_val);
 }
 
 // buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
