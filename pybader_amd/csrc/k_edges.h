@@ -102,19 +102,17 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
+    // all 27 loads first (with a load-test-store per neighbour the compiler serialises 27 round trips)
+    int idx[27];
+    int8_t k[27];
 #pragma unroll
-    for (int ix = -1; ix < 2; ix++) {
-        const int tx = wrapi(x + ix, g.nx);
-#pragma unroll
-        for (int iy = -1; iy < 2; iy++) {
-            const int ty = wrapi(y + iy, g.ny);
-#pragma unroll
-            for (int iz = -1; iz < 2; iz++) {
-                const int l = (tx * g.ny + ty) * g.nz + wrapi(z + iz, g.nz);
-                if (known[l] >= 0) known[l] = -1;
-            }
-        }
+    for (int j = 0; j < 27; j++) {
+        idx[j] = (wrapi(x + j / 9 - 1, g.nx) * g.ny + wrapi(y + (j / 3) % 3 - 1, g.ny)) * g.nz + wrapi(z + j % 3 - 1, g.nz);
+        k[j] = known[idx[j]];
     }
+#pragma unroll
+    for (int j = 0; j < 27; j++)
+        if (k[j] >= 0) known[idx[j]] = -1;
 }
 
 // LDS-tiled edge_find pass 1: a block stages the labels of a 4x8x64 tile plus a one-voxel periodic
