@@ -1211,9 +1211,17 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
         if (undecided) return fail(XB_E_STATE, "xb_edge_check: %d edge voxels left undecided", undecided);
     }
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
-    k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1);
+    const int new_cap = (int)std::min<long long>(c->N - n, 1LL << 30);   // the rest of `list` behind the compacted edges
+    HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
+    k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1,
+                                                  c->list + n, c->counters + 7, new_cap);
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
-    k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
+    {   // -1 ring around the new edges (-3): from their list, or by a full-grid sweep if the list did not fit
+        int n_new = 0;
+        if (int rc = read_counter(c, 7, &n_new)) return rc;
+        if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
+        else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new);
+    }
     k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64);
     HIPCHK(hipGetLastError());
     unsigned long long r[2];

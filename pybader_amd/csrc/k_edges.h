@@ -659,14 +659,14 @@ __global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__rest
 __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
                                                   const int *__restrict__ labels, int8_t *known,
                                                   const int *__restrict__ list, int n, const int8_t *st,
-                                                  unsigned long long *checked) {
+                                                  unsigned long long *checked, int *new_edges, int *n_new, int new_cap) {
     const int t = blockIdx.x * TPB + threadIdx.x;
     const bool act = t < n && st[t] == 1;
     const int v = act ? list[t] : 0;
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
-    unsigned int nchk = 0;
+    unsigned int nchk = 0, m3 = 0;  // m3: box positions this thread turned into new edges (-3)
     for (int ex = -1; ex < 2 && act; ex++) {
         const int tx = wrapi(x + ex, g.nx);
         for (int ey = -1; ey < 2; ey++) {
@@ -678,8 +678,30 @@ __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restri
                 bool is_edge, is_max;
                 classify27(g, rho, labels, tx, ty, tz, l, is_edge, is_max);
                 if (!is_edge) { known[l] = -1; nchk++; }
-                else if (!is_max) known[l] = -3;
+                else if (!is_max) { known[l] = -3; m3 |= 1u << ((ex + 1) * 9 + (ey + 1) * 3 + ez + 1); }
             }
+        }
+    }
+    // the new edges go to a list (with duplicates: boxes overlap) for the -1 ring around them: one atomic per wave
+    {
+        const int lane = threadIdx.x % XB_WAVE;
+        const int cnt = __popc(m3);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < XB_WAVE; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        const int total = __shfl(incl, XB_WAVE - 1);
+        int base = 0;
+        if (lane == XB_WAVE - 1 && total) base = atomicAdd(n_new, total);
+        base = __shfl(base, XB_WAVE - 1);
+        int at = base + incl - cnt;
+        for (unsigned int m = m3; m; m &= m - 1) {
+            const int j = __ffs(m) - 1;
+            if (at < new_cap)
+                new_edges[at] = lin3(g, wrapi(x + j / 9 - 1, g.nx), wrapi(y + (j / 3) % 3 - 1, g.ny), wrapi(z + j % 3 - 1, g.nz));
+            at++;
         }
     }
     for (int o = 32; o > 0; o >>= 1) nchk += __shfl_down(nchk, o);  // one atomic per wave (lanes that returned early hold 0)
