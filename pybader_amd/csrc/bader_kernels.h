@@ -230,18 +230,16 @@ __device__ __noinline__ GradRec make_rec_rho(const GridL &g, const double *__res
     const double c = rho[v];
     double max_val = c;
     int og = XB_OG_SELF;
-    for (int ix = 0; ix < 3; ix++) {
-        const int tx = wrapi(x + ix - 1, g.nx);
-        for (int iy = 0; iy < 3; iy++) {
-            const int ty = wrapi(y + iy - 1, g.ny);
-            for (int iz = 0; iz < 3; iz++) {
-                const int tz = wrapi(z + iz - 1, g.nz);
-                double w = rho[(tx * g.ny + ty) * g.nz + tz];
-                w = (w - c) * gc[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
-                w += c;
-                if (w > max_val) { max_val = w; og = ix * 9 + iy * 3 + iz; }
-            }
-        }
+    double nb[27];  // all 27 loads in flight before the scan
+#pragma unroll
+    for (int j = 0; j < 27; j++)
+        nb[j] = rho[(wrapi(x + j / 9 - 1, g.nx) * g.ny + wrapi(y + (j / 3) % 3 - 1, g.ny)) * g.nz + wrapi(z + j % 3 - 1, g.nz)];
+#pragma unroll
+    for (int j = 0; j < 27; j++) {
+        const int ix = j / 9, iy = (j / 3) % 3, iz = j % 3;
+        double w = (nb[j] - c) * gc[((ix + 2) % 3) * 9 + ((iy + 2) % 3) * 3 + ((iz + 2) % 3)];
+        w += c;
+        if (w > max_val) { max_val = w; og = j; }
     }
     TGradView t;
     for (int k = 0; k < 9; k++) t.T[k] = gc[27 + k];
