@@ -1170,6 +1170,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     c->list_valid = false;
     c->buni_valid = false;
     if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: 'changed' mode is single-slab only; slabs use mode 'all'");
+    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
     int n = 0;
     if (int rc = compact(c, -2, &n)) return rc;
     if (checked) *checked = 0;

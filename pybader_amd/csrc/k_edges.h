@@ -539,25 +539,35 @@ __global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restric
 // Decide v if its 16 bits allow it and tell the later listed neighbours; push(u) receives every voxel that became
 // decidable through this decision.  A voxel from the blanket scan of round 1 may not be decidable yet; one from
 // a queue always is.
+// `entry`: the voxel, with bit 31 set when the notifier already knows the decision is "skipped" and bit 30 when it
+// knows "processed" (queue entries carry it: the notifier has the neighbour's 16 bits from its atomic, which
+// saves the consumer a dependent load); neither bit: read the 16 bits (blanket scan of round 1).
+#define EC_E_SKIP 0x80000000u
+#define EC_E_PROC 0x40000000u
 template <typename Push>
-__device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigned int *pend_w, int v, Push push) {
-    const unsigned int b = (__hip_atomic_load(pend_w + (v >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> ((v & 1) * 16)) & 0xffffu;
+__device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigned int *pend_w, unsigned int entry, Push push) {
+    const int v = (int)(entry & 0x3FFFFFFFu);
     int d;
-    if (b & EC_CLS1) d = 1;
-    else if (b & EC_NPROC) d = 2;
-    else if ((b & EC_CNT) == 0) d = 1;
-    else return;  // still waiting for an earlier neighbour (blanket scan only)
-    {   // claim + publish: one atomicAnd clears the decision's bit of 0xFE; the returned word names the winner
-        const int sh = (v & 3) * 8;
-        const unsigned int old = atomicAnd(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh));
-        if (((old >> sh) & 0xffu) != 0xFEu) return;
+    if (entry & EC_E_SKIP) d = 2;
+    else if (entry & EC_E_PROC) d = 1;
+    else {
+        const unsigned int b = (__hip_atomic_load(pend_w + (v >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> ((v & 1) * 16)) & 0xffffu;
+        if (b & EC_CLS1) d = 1;
+        else if (b & EC_NPROC) d = 2;
+        else if ((b & EC_CNT) == 0) d = 1;
+        else return;  // still waiting for an earlier neighbour (blanket scan only)
     }
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
     int rows[9];
     unsigned int w[9];
-    ec_box(g, known, x, y, z, rows, w);
+    ec_box(g, known, x, y, z, rows, w);  // issued before the claim below: the loads and the atomic travel together
+    {   // claim + publish: one atomicAnd clears the decision's bit of 0xFE; the returned word names the winner
+        const int sh = (v & 3) * 8;
+        const unsigned int old = atomicAnd(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh));
+        if (((old >> sh) & 0xffu) != 0xFEu) return;
+    }
     // the later listed neighbours as a bit set over the box positions
     unsigned int later = 0;
 #pragma unroll
@@ -565,9 +575,9 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigne
         const int u = ec_box_voxel(g, rows, z, j);
         if ((u > v) & ec_listed((int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff))) later |= 1u << j;
     }
-    // One atomicAdd per neighbour, issued together (13 slots: the number of later positions away from the
-    // periodic seam; an empty slot adds 0 to v's own word, harmless and on the same cache line).  The atomics
-    // of a workgroup share one CU's address unit, so 13 instead of one per box position matters.
+    // One atomicAdd per neighbour, issued together in 10 slots (a voxel rarely has more later listed neighbours;
+    // the rest is handled one by one below; an empty slot adds 0 to v's own word, harmless and on the same cache
+    // line).  The atomics of a workgroup share one CU's address unit, so 10 instead of one per box position matters.
     const unsigned int delta = d == 1 ? 0xFFu : 0xFFFFFFFFu;  // +0x100 - 1  |  -1   (shifted into the voxel's half)
     unsigned int o[10];
     int uu[10];
@@ -584,13 +594,14 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigne
     for (int s = 0; s < 10; s++) {
         const unsigned int ob = o[s] & 0xffffu;
         const bool wake = (uu[s] >= 0) & !(ob & (EC_NPROC | EC_CLS1)) & ((d == 1) | ((ob & EC_CNT) == 1));
-        if (wake) push(uu[s]);   // first processed earlier neighbour (u gets skipped) / the last one u waited for
+        // first processed earlier neighbour: u gets skipped / the last one u waited for, none processed: processed
+        if (wake) push((unsigned int)uu[s] | (d == 1 ? EC_E_SKIP : EC_E_PROC));
     }
-    while (later) {  // more than 13 later neighbours: only next to the periodic seam
+    while (later) {  // the later neighbours beyond the slots
         const int u = ec_box_voxel(g, rows, z, __ffs(later) - 1);
         later &= later - 1;
         const unsigned int ob = (atomicAdd(pend_w + (u >> 1), delta << ((u & 1) * 16)) >> ((u & 1) * 16)) & 0xffffu;
-        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1)) push(u);
+        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1)) push((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC));
     }
 }
 // Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
@@ -598,9 +609,9 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigne
 __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, unsigned int *pend_w, const int *__restrict__ in,
                                                   int n, int *out, int *n_out, int out_cap) {
     for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
-        ec_resolve(g, known, pend_w, in[e], [&](int u) {
+        ec_resolve(g, known, pend_w, (unsigned int)in[e], [&](unsigned int u) {
             const int at = atomicAdd(n_out, 1);
-            if (at < out_cap) out[at] = u;
+            if (at < out_cap) out[at] = (int)u;
         });
 }
 // The rest: the dependency chains are ~1000 voxels long while only a few thousand voxels are decidable at any
@@ -631,13 +642,13 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
         if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
         int *nq = q[cur ^ 1], *n_next = &s_n[cur ^ 1];
         for (int e = threadIdx.x; e < n + take; e += EC_CHASE_THREADS) {
-            const int v = e < n ? q[cur][e] : seeds[seed_cur + e - n];
-            ec_resolve(g, known, pend_w, v, [&](int u) {
+            const unsigned int v = (unsigned int)(e < n ? q[cur][e] : seeds[seed_cur + e - n]);
+            ec_resolve(g, known, pend_w, v, [&](unsigned int u) {
                 const int at = atomicAdd(n_next, 1);
-                if (at < qcap) nq[at] = u;
+                if (at < qcap) nq[at] = (int)u;
                 else {  // queue full: hand over to the next launch
                     const int o = atomicAdd(n_ovf, 1);
-                    if (o < ovf_cap) ovf[o] = u;
+                    if (o < ovf_cap) ovf[o] = (int)u;
                 }
             });
         }
