@@ -168,7 +168,7 @@ def main():
     # profiles/r1_final_pmc_fetch_write_512_neargrid.txt -- FETCH_SIZE + WRITE_SIZE as reported (KB)
     traffic = None
     if args.size == 512 and args.method == 'neargrid' and world == 1:
-        traffic = {'k_grad_field': (1315034 + 4196362) * 1024.0, 'k_ng_trace': (4148687 + 213736) * 1024.0}[dom]
+        traffic = {'k_grad_field': (1314801 + 4196362) * 1024.0, 'k_ng_trace': (4146778 + 213734) * 1024.0}[dom]
 
     out = {
         'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',
