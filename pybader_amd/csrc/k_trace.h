@@ -164,17 +164,20 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     GradRec rec = {0., 0., 0., 0.};
     PathWindow<K> w;
     w.init(0, 0.);
-    if (valid && labels[v] != -1) {
-        px = sx; py = sy; pz = sz;
-        lp = v;
-        // trapping regions: brick labels (grids made of whole 8^3 bricks) or box ids in the keys
-        int b = blab ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
-        if (b <= 0) {
-            rec = fetch_rec(G, v);
-            b = key_box(rec.key);
+    if (valid) {
+        // the three start loads travel together (label for the vacuum test, brick label, own record); a start
+        // voxel from the work list lies in an uncertain brick by construction
+        const int lab0 = labels[v];
+        int b = (blab && !walk) ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
+        rec = fetch_rec(G, v);
+        if (lab0 != -1) {
+            px = sx; py = sy; pz = sz;
+            lp = v;
+            // trapping regions: brick labels (grids made of whole 8^3 bricks) or box ids in the keys
+            if (b <= 0) b = key_box(rec.key);
+            if (b > 0) result = box_max[b - 1];  // starts inside a trapping region: ends at its maximum
+            else { w.init(v, rec.key); moving = true; }
         }
-        if (b > 0) result = box_max[b - 1];  // starts inside a trapping region: ends at its maximum
-        else { w.init(v, rec.key); moving = true; }
     }
     while (__any(moving)) {
         if (moving) {
