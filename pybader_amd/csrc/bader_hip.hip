@@ -66,6 +66,7 @@ struct xb_ctx {
     int opt_ec_groups = 256;    // workgroups of k_ec_chase (at most one per CU)
     int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
     std::vector<int64_t> esc_starts, esc_offsets, esc_vox;  // xb_escaped_paths -> xb_escaped_paths_fetch
+    unsigned int *ec_pend = nullptr;  // edge_check's 16 bits per voxel (2 N bytes, allocated on first use)
     std::vector<int8_t> esc_complete;
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
@@ -198,7 +199,7 @@ int xb_create(int device, xb_ctx **out) {
 
 static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
-    hipFree(c->st); hipFree(c->stage); hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
@@ -1179,11 +1180,12 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     {
         // greedy resolution by dependency counters (k_edges.h): counters + classes for the whole list, round 1
         // over the whole list, then the dependency chains are chased asynchronously by a small grid of
-        // workgroups; queue overflows seed another launch.  Scratch in the staging buffer (8 N bytes): two
-        // seed / overflow lists of N/2 ints each, then the 16 bits per voxel of the counters.
-        const int cap = (int)std::min<long long>(c->N / 2, 1LL << 30);
-        int *buf[2] = {(int *)c->stage, (int *)c->stage + cap};
-        unsigned int *pend_w = reinterpret_cast<unsigned int *>((int *)c->stage + 2 * (size_t)cap + 4);
+        // workgroups; queue overflows seed another launch.  Scratch: two seed / overflow lists of N ints in the
+        // staging buffer, 16 bits per voxel for the counters (only 'changed' refinement needs them).
+        const int cap = (int)std::min<long long>(c->N, 1LL << 30);
+        int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
+        if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 2 * (size_t)c->N + 16));
+        unsigned int *pend_w = c->ec_pend;
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
         k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, reinterpret_cast<uint16_t *>(pend_w));
         k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
