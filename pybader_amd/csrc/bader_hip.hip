@@ -1018,7 +1018,8 @@ static int compact(xb_ctx *c, int value, int *n_out) {
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
-    k_compact_known16<<<nblocks((own + 15) / 16), TPB, 0, c->stream>>>(light(g), c->known, value, c->list, c->counters + 5);
+    k_compact_known16<<<nblocks((own + 16 * CK_CHUNKS - 1) / (16 * CK_CHUNKS)), TPB, 0, c->stream>>>(light(g), c->known, value, c->list,
+                                                                                               c->counters + 5);
     HIPCHK(hipGetLastError());
     return read_counter(c, 5, n_out);
 }

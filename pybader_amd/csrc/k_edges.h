@@ -290,20 +290,27 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
 }
 
 // compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block
+#define CK_CHUNKS 4   // 16-voxel chunks per thread: all loads of a thread in flight, one scan + one atomic per 16 K voxels
 __global__ __launch_bounds__(TPB) void k_compact_known16(GridL g, const int8_t *__restrict__ known, int value,
                                                          int *__restrict__ list, int *count) {
     const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
-    const long long base = vbeg + ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
-    int8_t b[16];
-    if (base + 16 <= vend && ((vbeg & 15) == 0)) {
-        *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(known + base);
-    } else {
+    long long base[CK_CHUNKS];
+    int8_t b[CK_CHUNKS][16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) b[k] = (base + k < vend) ? known[base + k] : (int8_t)(value + 1);
+    for (int c = 0; c < CK_CHUNKS; c++) {
+        base[c] = vbeg + (((long long)blockIdx.x * CK_CHUNKS + c) * TPB + threadIdx.x) * 16;
+        if (base[c] + 16 <= vend && ((vbeg & 15) == 0)) {
+            *reinterpret_cast<uint4 *>(b[c]) = *reinterpret_cast<const uint4 *>(known + base[c]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) b[c][k] = (base[c] + k < vend) ? known[base[c] + k] : (int8_t)(value + 1);
+        }
     }
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) cnt += (b[k] == value);
+    for (int c = 0; c < CK_CHUNKS; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) cnt += (b[c][k] == value);
     int total;
     const int off = block_scan_excl(cnt, total);
     __shared__ int base_s;
@@ -311,8 +318,10 @@ __global__ __launch_bounds__(TPB) void k_compact_known16(GridL g, const int8_t *
     __syncthreads();
     int w = base_s + off;
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (b[k] == value) list[w++] = (int)(base + k);
+    for (int c = 0; c < CK_CHUNKS; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (b[c][k] == value) list[w++] = (int)(base[c] + k);
 }
 
 // known >= 0 with a `flag` voxel in the 27-box -> -1.  Used by edge_find (flag=-2) and edge_check
