@@ -993,6 +993,9 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
             buni = reinterpret_cast<int *>(c->st);             // N bytes >= N/512 ints; edge_check reuses st later
             if (!c->buni_valid)
                 k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
+            const int nbr = (int)(c->N / 512);
+            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
+            buni += nbr;   // the sweep reads the 27-brick version
         }
         dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
         k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,

@@ -73,6 +73,21 @@ __global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const
     const int l = blab[b];
     if (l > 0) buni[b] = rank[box_max[l - 1]];
 }
+// buni3[K] = the label when brick K AND its 26 neighbour bricks all carry that one label, else XB_MIXED: a tile
+// of the edge sweep then needs a handful of lookups instead of one per brick of its surroundings
+__global__ void k_buni3(int nb0, int nb1, int nb2, const int *__restrict__ buni, int *__restrict__ buni3) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb0 * nb1 * nb2) return;
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    const int l = buni[b];
+    bool ok = l != XB_MIXED;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const int q = buni[(wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2)];
+        ok &= (q == l);
+    }
+    buni3[b] = ok ? l : XB_MIXED;
+}
 __global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *__restrict__ labels, int nb1, int nb2,
                                                             const int *__restrict__ walk, int n_walk,
                                                             int *__restrict__ buni) {
@@ -132,19 +147,20 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
     __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
     const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
     if (buni) {
-        // every brick that meets the tile or its one-voxel halo carries the same single label: no
-        // voxel of the tile has a foreign neighbour (2 x 3 x 10 bricks, one lookup per thread)
+        // `buni` here is buni3 (k_buni3): a brick entry says that the brick and all its 26 neighbours carry one
+        // label, so the bricks the tile itself lies in (1-2 in x, one in y, ET_Z/8 in z) settle the tile plus
+        // its one-voxel halo: no voxel of it has a foreign neighbour
         __shared__ int s_lab, s_mixed;
         if (threadIdx.x == 0) { s_lab = XB_MIXED; s_mixed = 0; }
         __syncthreads();
-        const int nb0 = g.nx >> 3, nb1 = g.ny >> 3, nb2 = g.nz >> 3;
-        const int bx_lo = (xa + tx0 - 1) >> 3, bx_n = ((xa + tx0 + ET_X) >> 3) - bx_lo + 1;  // arithmetic shift: -1 >> 3 == -1
-        const int by_lo = (y0 - 1) >> 3, by_n = ((y0 + ET_Y) >> 3) - by_lo + 1;
-        const int bz_lo = (z0 - 1) >> 3, bz_n = ((z0 + ET_Z) >> 3) - bz_lo + 1;
-        for (int t = threadIdx.x; t < bx_n * by_n * bz_n; t += TPB) {
-            const int q0 = wrap_any(bx_lo + t / (by_n * bz_n), nb0), q1 = wrap_any(by_lo + (t / bz_n) % by_n, nb1),
-                      q2 = wrap_any(bz_lo + t % bz_n, nb2);
-            const int l = buni[(q0 * nb1 + q1) * nb2 + q2];
+        const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        int X0 = xa + tx0, X1 = xa + min(tx0 + ET_X, nplanes) - 1;
+        if (X0 >= g.nx) X0 -= g.nx;
+        if (X1 >= g.nx) X1 -= g.nx;
+        const int bxa = X0 >> 3, bxb = X1 >> 3, nbz = min(ET_Z / 8, nb2 - (z0 >> 3));
+        if ((int)threadIdx.x < 2 * nbz) {
+            const int bx = (threadIdx.x & 1) ? bxb : bxa;
+            const int l = buni[(bx * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + (threadIdx.x >> 1)];
             if (l == XB_MIXED) s_mixed = 1;
             else {
                 const int old = atomicCAS(&s_lab, XB_MIXED, l);
