@@ -48,6 +48,8 @@ def lib():
         L.orc_refine_neargrid.argtypes = [_i8p, _i8p, _f64p, _i64p, _i32p, _f64p, _f64p]
         L.orc_own_trajectory.restype = None
         L.orc_own_trajectory.argtypes = [_f64p, _i64p, _i32p, _f64p, _f64p, _i64p]
+        L.orc_own_trajectory_main.restype = None
+        L.orc_own_trajectory_main.argtypes = [_f64p, _i64p, _i32p, _f64p, _f64p, _i64p]
         L.orc_trajectory_path.restype = C.c_int64
         L.orc_trajectory_path.argtypes = [_f64p, _i64p, _f64p, _f64p, C.c_int64, _i64p, C.c_int64]
         L.orc_parse_density_text.restype = C.c_int64
@@ -177,10 +179,11 @@ def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads=1, l
         iter_num += 1
 
 
-def own_trajectory_map(density, volumes, dist_mat, T_grad):
-    """Map F of SURVEY.md 7.3: linear index of the maximum each voxel's own trajectory reaches."""
+def own_trajectory_map(density, volumes, dist_mat, T_grad, main_ties=False):
+    """Map F of SURVEY.md 7.3: linear index of the maximum each voxel's own trajectory reaches (refinement.py's
+    strict tie test; main_ties=True: the tie test of methods.py:324)."""
     out = np.empty(density.shape, dtype=np.int64)
-    lib().orc_own_trajectory(_c(density, np.float64), _shape(density), _c(volumes, np.int32),
+    (lib().orc_own_trajectory_main if main_ties else lib().orc_own_trajectory)(_c(density, np.float64), _shape(density), _c(volumes, np.int32),
                              _c(dist_mat, np.float64), _c(T_grad, np.float64), out)
     return out
 

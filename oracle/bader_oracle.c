@@ -385,8 +385,8 @@ int64_t orc_refine_neargrid(int8_t *known, const int8_t *rknown, const double *r
 /* The "own-trajectory" map F of SURVEY.md section 7.3: every non-vacuum voxel follows its own
  * dr=0 neargrid trajectory (refinement.py:17-322 stepping rules, no early stop: rknown == 0) to
  * the maximum it reaches.  out[v] = linear index of that maximum (or -1 for vacuum voxels). */
-void orc_own_trajectory(const double *rho, const int64_t shape[3], const lab_t *vol, const double *dist,
-                        const double *T, int64_t *out) {
+static void own_trajectory(const double *rho, const int64_t shape[3], const lab_t *vol, const double *dist,
+                           const double *T, int64_t *out, int strict) {
     grid_t g; grid_init(&g, rho, shape, dist, T);
     const int64_t N = shape[0] * shape[1] * shape[2];
     int8_t *mark = (int8_t *)calloc((size_t)N, 1);
@@ -400,7 +400,7 @@ void orc_own_trajectory(const double *rho, const int64_t shape[3], const lab_t *
         mark[li] = 1;
         path.len = 0; ivec_push(&path, li);
         for (;;) {
-            ng_step(&g, 1, p, dr, pd);
+            ng_step(&g, strict, p, dr, pd);
             int64_t lpk = lin(&g, pd);
             if (mark[lpk]) {
                 dr[0] = dr[1] = dr[2] = 0.;
@@ -415,6 +415,16 @@ void orc_own_trajectory(const double *rho, const int64_t shape[3], const lab_t *
         for (int64_t j = 0; j < path.len; j++) mark[path.v[j]] = 0;
     }
     free(mark); free(path.v);
+}
+void orc_own_trajectory(const double *rho, const int64_t shape[3], const lab_t *vol, const double *dist,
+                        const double *T, int64_t *out) {
+    own_trajectory(rho, shape, vol, dist, T, out, 1);
+}
+/* the same with the main pass's tie test (methods.py:324, `<= >=`): the trajectories methods.neargrid follows
+ * when no known == 2 voxel cuts them short */
+void orc_own_trajectory_main(const double *rho, const int64_t shape[3], const lab_t *vol, const double *dist,
+                             const double *T, int64_t *out) {
+    own_trajectory(rho, shape, vol, dist, T, out, 0);
 }
 
 /* The voxels of one own (dr=0) trajectory, start voxel first, maximum last -- the same stepping as

@@ -74,3 +74,37 @@ def synth_density(shape, lattice=CUBIC6, atoms=ATOMS8, background=BACKGROUND, x_
 
 def sha256(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def hash_noise(shape, seed):
+    """Uniform [0, 1) float64 noise per voxel from integer arithmetic only (splitmix64 of the C-order voxel
+    index + seed; top 53 bits scaled by 2**-53): bit-reproducible on any numpy, no RNG implementation involved."""
+    n = int(np.prod(shape))
+    with np.errstate(over='ignore'):
+        z = np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(11)).astype(np.float64) * np.float64(2.0 ** -53)).reshape(tuple(int(s) for s in shape))
+
+
+def round_sig(rho, digits):
+    """Round to `digits` significant decimal digits the way a '%.{digits-1}E' text file does (CHG files carry 5)."""
+    flat = np.ascontiguousarray(rho, dtype=np.float64).reshape(-1)
+    out = np.array([float(('%.' + str(int(digits) - 1) + 'E') % v) for v in flat], dtype=np.float64)
+    return out.reshape(rho.shape)
+
+
+def rough_density(shape, lattice=CUBIC6, atoms=ATOMS8, noise=0.0, seed=7, sig_digits=0, quantum=0.0):
+    """The non-smooth test densities: the synthetic atoms + `noise` * hash_noise, optionally rounded to `sig_digits`
+    significant digits (exact ties in every low-density region, like a CHG file) or to multiples of `quantum`
+    (plateaus of exactly equal density)."""
+    rho = synth_density(shape, lattice, atoms)
+    if noise:
+        rho = rho + np.float64(noise) * hash_noise(shape, seed)
+    if sig_digits:
+        rho = round_sig(rho, sig_digits)
+    if quantum:
+        rho = np.round(rho / np.float64(quantum)) * np.float64(quantum)
+    return np.ascontiguousarray(rho)

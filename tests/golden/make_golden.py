@@ -225,6 +225,104 @@ def tables():
     print('tables done', flush=True)
 
 
+def run_rough_case(name, shape, lattice, vacuum_tol=None, modes=(('changed', 2), ('changed', -1), ('all', -1)),
+                   **rough):
+    """Non-smooth densities: noise (thousands of maxima), 5-significant-digit rounding (what a
+    CHG file holds: exact ties in the low-density regions), exact plateaus, vacuum where refinement changes
+    voxels.  Stored: the reference's sequential main map, its final map + log per refine mode, its own-trajectory
+    map (refinement.py stepping, strict ties), maxima lists, the ongrid map and its ('changed',2) refinement."""
+    t0 = time.time()
+    lattice = np.asarray(lattice, np.float64)
+    rho = synth.rough_density(shape, lattice, synth.ATOMS8, **rough)
+    atoms_cart = synth.atoms_cartesian(synth.ATOMS8, lattice)
+    out = {'shape': np.array(shape, np.int64), 'lattice': lattice, 'rho_sha256': np.array(sha(rho)),
+           'vacuum_tol': np.float64(np.nan if vacuum_tol is None else vacuum_tol),
+           'rough_json': np.array(json.dumps(rough, sort_keys=True))}
+    with nostdout():
+        b = make_bader(rho, lattice, atoms_cart, vacuum_tol=vacuum_tol)
+        out['dist_mat'] = b.distance_matrix
+        out['T_grad'] = b.T_grad
+        out['voxel_volume'] = np.float64(b.voxel_volume)
+        b.volumes_init()
+        out['ng_init'] = b.bader_volumes.astype(np.int8)
+        b.bader_calc()
+        main = b.bader_volumes.copy()
+        out['ng_main'] = main
+        out['ng_bader_max'] = np.rint(b.bader_maxima_fractional * np.array(shape)).astype(np.int64)
+        out['ng_F'] = own_trajectory(b, main)
+        for mode in modes:
+            tag = f"ng_{mode[0]}_{'inf' if mode[1] < 0 else mode[1]}"
+            v = main.copy()
+            log, known0, known_last = ref_refine_logged(b, v, mode)
+            v2 = main.copy()
+            thread_handlers.refine('neargrid', mode, b.reference, v2, b.distance_matrix, b.T_grad, 1)
+            assert np.array_equal(v, v2)
+            out[tag] = v
+            out[tag + '_log'] = np.array(log, np.int64).reshape(-1, 2)
+        b = make_bader(rho, lattice, atoms_cart, vacuum_tol=vacuum_tol, method='ongrid')
+        b.volumes_init()
+        b.bader_calc()
+        out['og_main'] = b.bader_volumes.copy()
+        out['og_bader_max'] = np.rint(b.bader_maxima_fractional * np.array(shape)).astype(np.int64)
+        v = out['og_main'].copy()
+        log, _, _ = ref_refine_logged(b, v, ('changed', 2))
+        out['og_ngrefine_changed_2'] = v
+        out['og_ngrefine_changed_2_log'] = np.array(log, np.int64).reshape(-1, 2)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB; ng maxima "
+          f"{out['ng_bader_max'].shape[0]}, og maxima {out['og_bader_max'].shape[0]}, logs "
+          + json.dumps({k: out[k].tolist() for k in out if k.endswith('_log')}), flush=True)
+
+
+def trajectory_vectors(name='traj_vectors', shape=(20, 18, 22), n_starts=400, n_steps=6):
+    """G5: step-level vectors from the reference's own refinement kernel (strict tie test,
+    refinement.py:111): refinement.neargrid with ONE voxel flagged -2, labels == linear index and rknown == 2
+    everywhere except on the voxels already known to be on the path: the trace stops on the first voxel outside
+    that set and hands its label (== its index) to the start voxel.  Growing the set one voxel at a time yields
+    the first n_steps voxels of the trajectory, carried remainder included.
+    (The non-strict variant of methods.py:324 cannot be isolated that way -- methods.neargrid has no rknown input
+    and a lone path among vacuum voxels ends on a vacuum maximum and is labelled -1; it is pinned by the full
+    main-pass maps of the rough cases below, where exact ties abound.)
+    Densities: quantised + noisy (ties, plateaus, hundreds of maxima)."""
+    t0 = time.time()
+    lattice = synth.TRICLINIC
+    out = {'shape': np.array(shape, np.int64), 'lattice': lattice}
+    dens = {'q': dict(noise=0.3, seed=3, quantum=0.0625), 's': dict(noise=0.05, seed=5, sig_digits=3)}
+    b0 = make_bader(np.ones(shape), lattice, np.zeros((1, 3)))
+    dm, tg = b0.distance_matrix, b0.T_grad
+    out['dist_mat'], out['T_grad'] = dm, tg
+    N = int(np.prod(shape))
+    idx0, ic = np.zeros(3, np.int64), np.zeros(1, np.int64)
+    for key, kw in dens.items():
+        rho = synth.rough_density(shape, lattice, synth.ATOMS8, **kw)
+        out[key + '_rough_json'] = np.array(json.dumps(kw, sort_keys=True))
+        out[key + '_rho_sha256'] = np.array(sha(rho))
+        starts = (np.arange(n_starts, dtype=np.int64) * 7919 + 13) % N
+        out[key + '_starts'] = starts
+        lab0 = np.arange(N, dtype=np.int64).reshape(shape)
+        strict = np.full((n_starts, n_steps), -1, np.int64)
+        for t, s in enumerate(starts):
+            on_path = [int(s)]
+            for k in range(n_steps):
+                known = np.zeros(shape, np.int8)
+                rknown = np.full(shape, 2, np.int8)
+                known.reshape(-1)[s] = -2
+                rknown.reshape(-1)[on_path] = 0
+                vol = lab0.copy()
+                refinement.neargrid(known, rknown, rho, vol, idx0, dm, tg, ic)
+                q = int(vol.reshape(-1)[s])
+                if q == int(s) or q in on_path:      # ended on a maximum that is on the path already
+                    strict[t, k] = q
+                    break
+                strict[t, k] = q
+                on_path.append(q)
+        out[key + '_strict_steps'] = strict
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 CASES = {
     # G6: tiny hand-checkable
     'c12_cubic': dict(shape=(12, 12, 12), lattice=synth.CUBIC6),
@@ -240,11 +338,29 @@ CASES = {
                        modes=(('changed', 2),)),
 }
 
+ROUGH = {
+    # noise: hundreds to thousands of maxima, no ties
+    'r40_noise005': dict(shape=(40, 40, 40), lattice=synth.TRICLINIC, noise=0.05),
+    'r40_noise04': dict(shape=(40, 40, 40), lattice=synth.TRICLINIC, noise=0.4),
+    'r64_noise04': dict(shape=(64, 64, 64), lattice=synth.CUBIC6, noise=0.4, modes=(('changed', 2), ('all', -1))),
+    # what a CHG file holds (%13.5E): exact ties wherever the density is low
+    'r48_sig5': dict(shape=(48, 48, 48), lattice=synth.CUBIC6, sig_digits=5),
+    'r48_sig5_noise': dict(shape=(48, 48, 48), lattice=synth.TRICLINIC, noise=0.02, sig_digits=5),
+    # exact plateaus
+    'r32_quant8': dict(shape=(32, 24, 24), lattice=synth.TRICLINIC, quantum=0.125),
+    # vacuum where refinement changes voxels ('changed' mode carries the reference's vacuum bug)
+    'r40_vac_noise': dict(shape=(40, 40, 40), lattice=synth.CUBIC6, noise=0.05, vacuum_tol=0.06),
+}
+
 if __name__ == '__main__':
     # warm the JIT on a tiny grid first
-    which = sys.argv[1:] or ['tables'] + list(CASES)
+    which = sys.argv[1:] or ['tables', 'traj_vectors'] + list(CASES) + list(ROUGH)
     for name in which:
         if name == 'tables':
             tables()
+        elif name == 'traj_vectors':
+            trajectory_vectors()
+        elif name in ROUGH:
+            run_rough_case(name, **ROUGH[name])
         else:
             run_case(name, **CASES[name])
