@@ -6,13 +6,18 @@ on a synthetic 512^3 grid (BASELINE config 3), data resident in HBM, on N GPUs o
                     [--refine changed:2] [--cpu-size 320] [--no-cpu]
 
 A "step" is one full pass of the hot path over the grid: volumes_init (label reset) -> bader_calc
--> refine, exactly the call sequence of Bader.__call__ (interface.py:406-409).  N > 1 is launched
-by torch.distributed.run (one rank per GPU); the grid is cut into axis-0 slabs (strong scaling:
-the 512^3 grid is fixed, north_star: ">= 6x at 8 GPUs").  Rank 0 prints ONE JSON line.
+-> refine, exactly the call sequence of Bader.__call__ (interface.py:406-409).  N > 1: one rank per
+GPU, either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or -- `python bench.py --gpus N` as typed -- by this script itself, which then spawns N fresh
+rank processes BEFORE anything touches the GPU, relays rank 0's JSON line and exits non-zero if any rank
+failed.  The grid is cut into axis-0 slabs (strong scaling: the 512^3 grid is fixed, north_star: ">= 6x at
+8 GPUs").  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,6 +54,40 @@ def cpu_baseline(size, method, mode, iters, lattice, atoms, background):
             'assign_mvox_s': n / (t1 - t0) / 1e6}, (rho, dm, tg, main, bmax)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N rank processes of this script (fresh interpreters
+    that have not touched the GPU; this parent never does), wait, relay rank 0's output.  Returns the exit code."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(n))
+    while alive:                         # a rank that dies leaves its peers hanging in a collective: end them
+        time.sleep(0.2)
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0:
+                print(f'bench.py: rank {r} exited with code {code}', file=sys.stderr)
+                rc = rc or (code if code > 0 else 1)
+                for q in alive:
+                    procs[q].kill()
+    out0 = procs[0].stdout.read().decode()   # one JSON line: far below the pipe buffer
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc == 0 and not any(line.startswith('{') for line in out0.splitlines()):
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -72,8 +111,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+        if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
+            raise SystemExit(spawn_ranks(args.gpus))   # nothing has touched the GPU in this process
         args.gpus = world
 
     from pybader_amd import _lib, slab, synth

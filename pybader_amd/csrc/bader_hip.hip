@@ -81,6 +81,8 @@ struct xb_ctx {
     int nbk[3] = {0, 0, 0};
     int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
     bool grad_valid = false;
+    int grad_rule = 0;         // which tie rule the resident table obeys: 0 refinement.py:111, 1 methods.py:324, 2 both
+                               // (the density has no voxel where they differ)
     int *labels = nullptr;
     int8_t *known = nullptr;
     int *first = nullptr;      // n^3: min voxel per maximum, then rank per maximum
@@ -115,6 +117,7 @@ static GridL light(const Grid &g) {
     l.x0 = g.x0; l.x1 = g.x1; l.vx0 = g.vx0; l.vlen = g.vlen;
     l.wx0 = g.wx0; l.wlen = g.wlen;
     l.use24 = ((long long)g.nx * g.ny < (1 << 24)) && g.nz < (1 << 24);
+    l.main_ties = g.main_ties;
     return l;
 }
 
@@ -133,6 +136,7 @@ struct DevBuf {
 static bool sym_grid(const Grid &g, GridS &s) {
     s.nx = g.nx; s.ny = g.ny; s.nz = g.nz; s.nyz = g.nyz;
     s.x0 = g.x0; s.x1 = g.x1; s.vx0 = g.vx0; s.vlen = g.vlen; s.wx0 = g.wx0; s.wlen = g.wlen;
+    s.main_ties = g.main_ties;
     for (int k = 0; k < 9; k++) s.T[k] = g.T[k];
     auto at = [&](int idx) {
         const int ix = idx / 9, iy = (idx / 3) % 3, iz = idx % 3;
@@ -519,11 +523,14 @@ enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 4352, BB_BOXM
 static bool table_windowed(const xb_ctx *c) { return c->g.wlen < c->g.nx; }
 static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks, bool ranges_from_rho = false);
 
-static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
-    if (c->grad_valid && !force) return XB_OK;
+// main_rule: records under the assignment's tie test (methods.py:324) instead of the refinement's
+// (refinement.py:111); a table built for one rule serves the other when no voxel of the density has such a tie.
+static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
+    c->g.main_ties = main_rule ? 1 : 0;   // the trace / slow kernels of this phase follow the same rule
+    if (c->grad_valid && !force && (c->grad_rule == 2 || c->grad_rule == (main_rule ? 1 : 0))) return XB_OK;
     const Grid &g = c->g;
     ScopedTimer t(c, 4);
-    HIPCHK(hipMemsetAsync(c->counters + 9, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters + 9, 0, 2 * sizeof(int), c->stream));
     // brick growth needs a grid made of whole 8^3 bricks; its scratch is carved from `list`
     const bool bricks = boxes && c->opt_boxes && c->opt_bricks && g.nx % BRK == 0 && g.ny % BRK == 0 &&
                         g.nz % BRK == 0 && 5LL * (c->N / (BRK * BRK * BRK)) <= c->N;
@@ -537,20 +544,28 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes) {
         GridS gs;
         if (sym_grid(g, gs))
             k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
-                                                            BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
+                                                            BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr,
+                                                            c->counters + 10);
         else
             k_grad_field<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, c->boxbuf + BB_SEEDS, c->counters + 9,
-                                                           BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr);
+                                                           BB_SEED_CAP, small, bricks ? c->list + nbr_all : nullptr,
+                                                           c->counters + 10);
     }
     HIPCHK(hipGetLastError());
     c->grad_valid = true;
+    c->grad_rule = main_rule ? 1 : 0;   // until the tie counter says the rules agree on this density
     c->n_boxes = 0;
     c->box_voxels = 0;
     c->blab = nullptr;
     c->table_stage = 1;
     if (!boxes || !c->opt_boxes) return XB_OK;
     int ns = 0;
-    if (int rc = read_counter(c, 9, &ns)) return rc;
+    {
+        HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 9, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ns = c->host_ints[0];
+        if (c->host_ints[1] == 0) c->grad_rule = 2;
+    }
     if (ns > BB_SEED_CAP) ns = XB_BOX_SEEDS_MAX + 1;  // list overflowed: far too many maxima for boxes anyway
     std::vector<int> seeds(std::max(ns, 0));
     if (ns > 0 && ns <= XB_BOX_SEEDS_MAX) {
@@ -749,8 +764,9 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         if (c->table_prebuilt) c->table_prebuilt = false;   // built by xb_table_build/xb_table_finish just now
         else {
             if (table_windowed(c)) return fail(XB_E_STATE, "windowed table: call xb_table_build / xb_table_finish first");
-            if (int rc = ensure_grad(c, true, true)) return rc;
+            if (int rc = ensure_grad(c, true, true, true)) return rc;
         }
+        c->g.main_ties = 1;   // methods.neargrid's stepping rule for everything the assignment traces
         {
             ScopedTimer t(c, 0);
             const int opt = c->opt_trace;
@@ -802,6 +818,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         c->stat_ovf_assign += novf;
         if (novf > 0)
             if (int rc = run_slow(c, novf, 0)) return rc;
+        c->g.main_ties = 0;
     } else if (method == XB_METHOD_ONGRID) {
         const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
         // trapping regions of the pointer field (whole 8^3 bricks, one slab, no vacuum), else plain pointer jumping
@@ -1034,6 +1051,7 @@ static int compact(xb_ctx *c, int value, int *n_out) {
 int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_voxels) {
     NEED_GRID("xb_escaped_paths");
     c->esc_starts.clear(); c->esc_offsets.assign(1, 0); c->esc_vox.clear(); c->esc_complete.clear();
+    c->g.main_ties = 0;   // retraces follow refinement.py's rule
     int n = 0;
     if (int rc = compact(c, -6, &n)) return rc;
     c->list_valid = false;
@@ -1139,6 +1157,7 @@ int xb_refine_trace_escaped(xb_ctx *c, int64_t *changed, int64_t *escaped) { ret
 static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *escaped) {
     NEED_GRID("xb_refine_trace");
     const Grid &g = c->g;
+    c->g.main_ties = 0;
     int n = 0;
     if (c->list_valid && flag == -2) n = c->list_n;
     else if (int rc = compact(c, flag, &n)) return rc;
@@ -1147,7 +1166,7 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
-        if (int rc = ensure_grad(c, false, false)) return rc;
+        if (int rc = ensure_grad(c, false, false, false)) return rc;
         {
             ScopedTimer t(c, 3);
             (table_windowed(c) ? k_refine_trace<2, true> : k_refine_trace<2, false>)<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n,
@@ -1244,7 +1263,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
 // per edge voxel (2.0 -> 0.9 ms at 512^3 after an ongrid assignment).
 int xb_prepare_refine(xb_ctx *c) {
     NEED_GRID("xb_prepare_refine");
-    return ensure_grad(c, false, false);
+    return ensure_grad(c, false, false, false);
 }
 
 int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
@@ -1423,7 +1442,7 @@ int xb_set_table_window(xb_ctx *c, int64_t margin) {
 }
 int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
     NEED_GRID("xb_table_build");
-    if (int rc = ensure_grad(c, true, true)) return rc;
+    if (int rc = ensure_grad(c, true, true, true)) return rc;
     if (n_local_seeds) *n_local_seeds = table_windowed(c) ? (int64_t)c->window_seeds.size() : 0;
     return XB_OK;
 }

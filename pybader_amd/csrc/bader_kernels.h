@@ -13,6 +13,7 @@ struct Grid {
     int x0, x1;       // owned slab: planes [x0, x1)
     int vx0, vlen;    // planes whose labels/known are valid: [vx0, vx0+vlen) modulo nx
     int wx0, wlen;    // planes whose gradient-field table records exist: [wx0, wx0+wlen) modulo nx
+    int main_ties;    // 1: the axis tie test of methods.py:324 (`<= >=`, the assignment), 0: refinement.py:111 (`< >`)
     double T[9];      // T_grad, row-major (interface.py:285-290)
     double dist[27];  // dist_mat [3][3][3], index 2 == -1 (interface.py:242-259)
 };
@@ -25,6 +26,7 @@ struct GridS {
     int nx, ny, nz, nyz;
     int x0, x1, vx0, vlen;
     int wx0, wlen;
+    int main_ties;
     double T[9];
     double dsym[14];
 };
@@ -42,6 +44,7 @@ struct GridL {
     int x0, x1, vx0, vlen;
     int wx0, wlen;    // table window (see Grid)
     int use24;        // nx*ny < 2^24 and nz < 2^24: linear indices via 24-bit multiplies
+    int main_ties;    // see Grid
 };
 
 #define XB_INT_MAX 0x7fffffff
@@ -68,13 +71,23 @@ __device__ __forceinline__ int rha(double x) { return x > 0 ? (int)(x + .5) : (i
 // 111): the normalised gradient direction grad_dir / max_grad at voxel p.  It depends on rho only
 // (not on the carried remainder dr), so it is precomputed once per voxel by k_grad_field.
 // Returns true when max_grad < 1E-14 (refinement.py:132-134: the trajectory does not move).
+// The two callers of the reference differ in ONE comparison: methods.neargrid (the assignment) zeroes an axis
+// when `hi <= c >= lo` (methods.py:324), refinement.neargrid when `hi < c > lo` (refinement.py:111); they
+// only disagree on exact ties (hi == c or lo == c with c >= both), which real CHG files (5 significant
+// digits) are full of.  `tie` reports that this voxel has such an axis (its two records differ).
+__device__ __forceinline__ bool axis_flat(int main_ties, double hi, double c, double lo) {
+    return main_ties ? (hi <= c && c >= lo) : (hi < c && c > lo);
+}
+__device__ __forceinline__ bool axis_tie(double hi, double c, double lo) {
+    return (hi <= c && c >= lo) && !(hi < c && c > lo);
+}
 template <typename GT>
 __device__ __forceinline__ bool ng_dir_vals(const GT &g, double c, double hx, double lx, double hy, double ly,
                                             double hz, double lz, double &d0, double &d1, double &d2) {
-    // refinement.py:111-114: zero when p is a strict maximum along the axis, else central difference
-    const double g0 = (hx < c && c > lx) ? 0. : (hx - lx) / 2.;
-    const double g1 = (hy < c && c > ly) ? 0. : (hy - ly) / 2.;
-    const double g2 = (hz < c && c > lz) ? 0. : (hz - lz) / 2.;
+    // methods.py:324-327 / refinement.py:111-114: zero when p is a maximum along the axis, else central difference
+    const double g0 = axis_flat(g.main_ties, hx, c, lx) ? 0. : (hx - lx) / 2.;
+    const double g1 = axis_flat(g.main_ties, hy, c, ly) ? 0. : (hy - ly) / 2.;
+    const double g2 = axis_flat(g.main_ties, hz, c, lz) ? 0. : (hz - lz) / 2.;
     // refinement.py:123-130: grad_dir = T_grad . grad with (a+b)+c association
     d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
     d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
@@ -223,7 +236,7 @@ struct PathWindow {
 // for operation -- for the few trajectories that leave the table window of a slab (multi-GPU): they carry
 // on with ~33 loads per step instead of one gather, and never need the exact slow kernel for that.
 // gc: dist_mat (27 doubles) followed by T_grad (9 doubles) in device memory.
-struct TGradView { double T[9]; };
+struct TGradView { double T[9]; int main_ties; };
 __device__ __noinline__ GradRec make_rec_rho(const GridL &g, const double *__restrict__ rho,
                                              const double *__restrict__ gc, int x, int y, int z) {
     const int v = (x * g.ny + y) * g.nz + z;
@@ -243,6 +256,7 @@ __device__ __noinline__ GradRec make_rec_rho(const GridL &g, const double *__res
     }
     TGradView t;
     for (int k = 0; k < 9; k++) t.T[k] = gc[27 + k];
+    t.main_ties = g.main_ties;
     const int xp = wrapi(x + 1, g.nx), xm = wrapi(x - 1, g.nx);
     const int yp = wrapi(y + 1, g.ny), ym = wrapi(y - 1, g.ny);
     const int zp = wrapi(z + 1, g.nz), zm = wrapi(z - 1, g.nz);

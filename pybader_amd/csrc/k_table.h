@@ -28,7 +28,7 @@ __device__ __forceinline__ void move_ranges_raw(int code, int og, double r0, dou
 template <typename GT>
 __global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restrict__ rho,
                                                     GradRec *__restrict__ G, int *seeds, int *seed_count,
-                                                    int seed_cap, int small, int *__restrict__ bmask) {
+                                                    int seed_cap, int small, int *__restrict__ bmask, int *tie_count) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
     __shared__ int s_mask[GT_Z / 8];
     // plane tiles are counted from the start of the table window (brick aligned; the whole grid on one GPU)
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restri
     __syncthreads();
     const int tz = threadIdx.x & (GT_Z - 1), ty = threadIdx.x / GT_Z;   // 32 x 8 threads, 8 voxels (x) each
     int mine = 0;  // move mask of this thread's voxels (all in brick tz >> 3 of the tile)
+    bool any_tie = false;  // a voxel whose record depends on the tie rule (methods.py:324 vs refinement.py:111)
 #pragma unroll 1
     for (int k = 0; k < GT_X; k++) {
         const int tx = k;
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restri
         GradRec o;
         double d0, d1, d2;
         int code;
+        any_tie |= ((int)axis_tie(tile[tx + 2][ty + 1][tz + 1], c, tile[tx][ty + 1][tz + 1]) |
+                    (int)axis_tie(tile[tx + 1][ty + 2][tz + 1], c, tile[tx + 1][ty][tz + 1]) |
+                    (int)axis_tie(tile[tx + 1][ty + 1][tz + 2], c, tile[tx + 1][ty + 1][tz])) != 0;
         if (ng_dir_vals(g, c, tile[tx + 2][ty + 1][tz + 1], tile[tx][ty + 1][tz + 1], tile[tx + 1][ty + 2][tz + 1],
                         tile[tx + 1][ty][tz + 1], tile[tx + 1][ty + 1][tz + 2], tile[tx + 1][ty + 1][tz], d0, d1, d2)) {
             // max_grad < 1E-14: a trajectory stays on p, p is on its path, so the reference resets dr
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restri
             mine |= yz * (512 | (pa & 1) | ((pa & 4) << 16));
         }
     }
+    if (__any(any_tie) && threadIdx.x % XB_WAVE == 0) atomicAdd(tie_count, 1);  // only != 0 matters
     if (bmask) {
         atomicOr(&s_mask[tz >> 3], mine);
         __syncthreads();

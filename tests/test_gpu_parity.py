@@ -203,7 +203,7 @@ def test_against_oracle_seeded(ctx, seed, shape, tol):
     ctx.vacuum_assign(tol, 1.0)
     assert np.array_equal(ctx.download_labels(np.int32), vol0)
     # neargrid: own-trajectory map
-    F = oracle.own_trajectory_map(rho, vol0, dm, tg)
+    F = oracle.own_trajectory_map(rho, vol0, dm, tg, main_ties=True)
     want, maxima = rank_labels(F)
     n = ctx.assign('neargrid')
     got = ctx.download_labels(np.int64)
@@ -398,7 +398,7 @@ def test_rough_densities_against_oracle(ctx, kind, shape):
     vol0, _, _ = oracle.vacuum_assign(rho, vol0, float('nan') if tol is None else tol, rho, 1.0)
     ctx.vacuum_assign(tol, 1.0)
     assert np.array_equal(ctx.download_labels(np.int32), vol0)
-    F = oracle.own_trajectory_map(rho, vol0, dm, tg)
+    F = oracle.own_trajectory_map(rho, vol0, dm, tg, main_ties=True)   # xb_assign follows methods.py:324's tie test
     # a trajectory that ends on a vacuum maximum hands -1 to its start voxel (refinement.py:286)
     flat = F.reshape(-1).copy()
     ends_in_vac = (flat >= 0) & (vol0.reshape(-1)[np.maximum(flat, 0)] == -1)
