@@ -16,6 +16,7 @@
 // =============================================================================================
 #include "k_common.h"
 #include "k_table.h"
+#include "k_fused.h"
 #include "k_trace.h"
 #include "k_ongrid.h"
 #include "k_edges.h"
@@ -72,6 +73,7 @@ struct xb_ctx {
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
     int n_walk = 0;                // bricks on the walk list of the last assignment
+    int *walk = nullptr;           // ... and where that list lives (inside `list`)
     int table_margin = -1;         // planes of table each side of the slab (slabs); -1: whole grid
     bool table_prebuilt = false;   // xb_table_finish done: the next xb_assign_trace must not rebuild
     int table_stage = 0;           // windowed build: 1 = records + masks done, 2 = trapping regions done
@@ -96,6 +98,14 @@ struct xb_ctx {
     int *ovf_list = nullptr;
     int ovf_cap = 0;
     int *counters = nullptr;   // small device scratch: ints
+    int *fs = nullptr;         // state block of the device-side control flow (k_fused.h), inside `counters`
+    int *blab_buf = nullptr;   // brick labels of the trapping regions (fused path), nbr ints
+    long long blab_alloc = 0;
+    bool labels_zero_pending = false;   // volumes_init without vacuum: labels := 0 is owed (see xb_vacuum_assign)
+    int opt_fused = 1;         // 0: the host-driven round-1 orchestration (kept for slabs and odd grids)
+    int opt_trace_grid = 8192; // one-wave workgroups of the persistent trace
+    int opt_trace_chunk = 1;   // items (4x4x4 eighths of a brick) per pull: 1 keeps the waves of an XCD on ~128 neighbouring bricks (2 MB of table, L2 resident); 32 per pull ran 1.8x slower
+    int opt_trace_xcd = 1;     // 1: ranges by the real XCC id, 0: by blockIdx % 8
     unsigned long long *counters64 = nullptr;
     double *dsum = nullptr;
     int *host_ints = nullptr;  // pinned
@@ -191,12 +201,13 @@ int xb_create(int device, xb_ctx **out) {
     xb_ctx *c = new xb_ctx();
     c->device = device;
     HIPCHK(hipStreamCreate(&c->stream));
-    HIPCHK(hipMalloc(&c->counters, 64 * sizeof(int)));
+    HIPCHK(hipMalloc(&c->counters, 1024 * sizeof(int)));
+    c->fs = c->counters + 128;
     HIPCHK(hipMalloc(&c->counters64, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->dsum, 16 * sizeof(double)));
     HIPCHK(hipMalloc(&c->dist_dev, 36 * sizeof(double)));  // dist_mat (27) then T_grad (9): make_rec_rho
     HIPCHK(hipMalloc(&c->boxbuf, (size_t)(1 << 20) * sizeof(int)));
-    HIPCHK(hipHostMalloc(&c->host_ints, 64 * sizeof(long long)));
+    HIPCHK(hipHostMalloc(&c->host_ints, 4096 * sizeof(int)));
     *out = c;
     return XB_OK;
 }
@@ -204,6 +215,7 @@ int xb_create(int device, xb_ctx **out) {
 static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
     hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->labels_zero_pending = false;
     c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
@@ -305,9 +317,22 @@ int xb_set_halo(xb_ctx *c, int64_t halo) {
     return XB_OK;
 }
 
-#define NEED_GRID(name) \
+// volumes_init without vacuum owes `labels := 0` (xb_vacuum_assign defers the 4 B/voxel memset because the
+// neargrid / ongrid assignment that normally follows overwrites every label without reading any); every other
+// entry point pays the debt first, so the deferral is not observable.
+static int settle_labels(xb_ctx *c) {
+    if (c->labels_zero_pending) {
+        c->labels_zero_pending = false;
+        HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+    }
+    return XB_OK;
+}
+#define NEED_GRID_RAW(name) \
     if (!c || !c->has_grid) return fail(XB_E_STATE, name ": call xb_set_grid first"); \
     HIPCHK(hipSetDevice(c->device))
+#define NEED_GRID(name) \
+    NEED_GRID_RAW(name); \
+    if (int rc_ = settle_labels(c)) return rc_
 
 int xb_upload_density(xb_ctx *c, const double *rho_host) {
     NEED_GRID("xb_upload_density");
@@ -436,7 +461,8 @@ int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, i
 static size_t dtype_size(int dtype) { return (dtype == XB_I8 || dtype == XB_I16 || dtype == XB_I32 || dtype == XB_I64) ? (size_t)dtype : 0; }
 
 int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
-    NEED_GRID("xb_upload_labels");
+    NEED_GRID_RAW("xb_upload_labels");
+    c->labels_zero_pending = false;   // every label is overwritten
     c->list_valid = false;
     c->has_vacuum = true;
     c->buni_valid = false;
@@ -485,12 +511,16 @@ int xb_download_known(xb_ctx *c, int8_t *known_host) {
 }
 
 int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume) {
-    NEED_GRID("xb_vacuum_assign");
+    NEED_GRID_RAW("xb_vacuum_assign");
     c->buni_valid = false;
+    c->labels_zero_pending = false;
     if (vac_tol != vac_tol) {
         // vacuum_tol=None reaches the reference's sweep as NaN (interface.py:459): `rho <= NaN` is never
-        // true, so the result is all-zero labels and zero vacuum charge/volume -- no need to read rho
-        HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+        // true, so the result is all-zero labels and zero vacuum charge/volume -- no need to read rho.
+        // On one slab the 4 B/voxel memset is deferred (settle_labels): the assignment that follows
+        // overwrites every label without reading any.
+        if (c->g.x1 - c->g.x0 == c->g.nx) c->labels_zero_pending = true;
+        else HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
         c->has_vacuum = false;
         if (vac_charge) *vac_charge = 0.;
         if (vac_volume) *vac_volume = 0.;
@@ -725,7 +755,10 @@ static int read_counter(xb_ctx *c, int idx, int *out) {
 }
 
 // run the exact slow kernel over ovf_list[0..n) in chunks
-static int run_slow(xb_ctx *c, int n, int refine) {
+static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr) {
+    if (!max_count) max_count = c->counters + 0;
+    if (!changed) changed = c->counters + 2;
+    if (!escaped) escaped = c->counters + 3;
     const int lmax = 1 << 15, chunk = 2048;
     DevBuf<int> path;
     HIPCHK(path.alloc((size_t)chunk * lmax));
@@ -734,8 +767,8 @@ static int run_slow(xb_ctx *c, int n, int refine) {
         const int m = std::min(chunk, n - o);
         k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
                                                          c->ovf_list + o, m, path.p, lmax, refine, c->first,
-                                                         c->max_list, c->counters + 0, c->max_cap,
-                                                         c->counters + 2, c->counters + 3, c->counters + 8, nullptr);
+                                                         c->max_list, max_count, c->max_cap,
+                                                         changed, escaped, c->counters + 8, nullptr);
     }
     hipError_t e = hipGetLastError();
     int err = 0;
@@ -776,6 +809,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 // trapping regions known per brick: fill them in one sweep, trace only the rest
                 const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
                 int *walk = c->blab + nbr;  // next scratch slice of `list` (see ensure_grad)
+                c->walk = walk;
                 HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
                 k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
                                                                          (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, c->counters + 13);
@@ -856,6 +890,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         if (c->blab) {
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *walk = c->blab + nbr;
+            c->walk = walk;
             HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
             k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, c->counters + 13);
             k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(light(g), c->nbk[0], c->nbk[1], c->nbk[2], 0, nbr, c->blab,
@@ -929,21 +964,21 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     if (c->regions_pending && c->blab) {
         if (g.nz % 4 == 0)
             k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
-                                                                    c->nbk[2], c->boxbuf + BB_BOXMAX);
+                                                                    c->nbk[2], c->boxbuf + BB_BOXMAX, nullptr);
         else
             k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
-                                                                   c->boxbuf + BB_BOXMAX);
+                                                                   c->boxbuf + BB_BOXMAX, nullptr);
         if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, c->boxbuf + BB_BOXMAX, c->first, buni);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, c->boxbuf + BB_BOXMAX, c->first, buni, nullptr);
             if (c->n_walk)
-                k_label_uniform_list<<<c->n_walk, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
-                                                                      c->blab + nbr, c->n_walk, buni);
+                k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
+                                                                                c->walk, c->n_walk, nullptr, nullptr, buni);
             c->buni_valid = true;
         }
     } else
-        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first);
+        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, nullptr);
     c->regions_pending = false;
     HIPCHK(hipGetLastError());
     if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
@@ -955,9 +990,179 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     return XB_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The single-GPU neargrid assignment with the control flow on the device (k_fused.h): one host wait at the end.
+// Preconditions (checked by the caller): one slab, grid of whole 8^3 bricks, trapping regions enabled.
+// ---------------------------------------------------------------------------------------------------------------
+static bool fused_ok(const xb_ctx *c) {
+    const Grid &g = c->g;
+    return c->opt_fused && c->opt_boxes && c->opt_bricks && g.x0 == 0 && g.x1 == g.nx && !table_windowed(c) &&
+           g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 && 6LL * (c->N / (BRK * BRK * BRK)) <= c->N &&
+           g.nx >= 16 && g.ny >= 16 && g.nz >= 16;
+}
+static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
+
+static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
+    Grid &g = c->g;
+    const GridL gl0 = light(g);
+    const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+    if (c->blab_alloc < nbr) {
+        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0;
+        HIPCHK(hipMalloc(&c->blab_buf, (size_t)nbr * sizeof(int)));
+        c->blab_alloc = nbr;
+    }
+    int *fs = c->fs;
+    // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
+    int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
+    int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP, *box_max = c->boxbuf + BB_BOXMAX,
+        *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * 64, *bad = c->boxbuf + BB_BAD;
+    const int stride = XB_BOX_K + 4;
+    HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(bad, 0, (size_t)64 * stride * sizeof(int), c->stream));
+    if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
+        k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
+        HIPCHK(hipGetLastError());
+    }
+    c->first_clean = false;
+    c->regions_pending = false;
+    c->buni_valid = false;
+    c->list_valid = false;
+    g.main_ties = 1;   // methods.neargrid's tie test (methods.py:324)
+    const GridL gl = light(g);
+    (void)gl0;
+    {   // table + brick masks + seeds
+        ScopedTimer t4(c, 4);
+        {
+            ScopedTimer t5(c, 5);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+            GridS gs;
+            if (sym_grid(g, gs))
+                k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
+                                                                bmask, fs + FS_TIES);
+            else
+                k_grad_field<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
+                                                               bmask, fs + FS_TIES);
+        }
+        c->grad_valid = true;
+        c->grad_rule = 1;
+        // closed seed cubes around the maxima, then brick growth -- all decided on the device
+        k_box_setup<<<1, 64, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
+        const long long wmax = 2LL * XB_BOX_K + 1;
+        k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
+        k_box_pick<<<1, 64, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
+        k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
+        const int launches = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
+        const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
+        for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
+            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf);
+        HIPCHK(hipGetLastError());
+    }
+    c->blab = c->blab_buf;
+    c->walk = walk;
+    c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
+    const long long own = c->N;
+    {   // region fill / notes, then the walkers of the uncertain bricks
+        ScopedTimer t0(c, 0);
+        k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK);
+        if (c->has_vacuum)
+            k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
+                                                                fs + FS_N_MAX, c->max_cap);
+        else {
+            k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, 0, nbr, c->blab, box_max, c->first,
+                                                                          c->max_list, fs + FS_N_MAX, c->max_cap);
+            c->regions_pending = true;
+        }
+        {
+            ScopedTimer t6(c, 6);
+            const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+            k_ng_trace_p<2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels,
+                                                                          c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap,
+                                                                          maxsteps, c->has_vacuum ? 1 : 0, c->opt_trace_chunk, c->opt_trace_xcd);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host)
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
+    int *buni = reinterpret_cast<int *>(c->st);
+    if (c->regions_pending) {
+        if (g.nz % 4 == 0)
+            k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
+        else
+            k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
+        k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+        k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+    } else
+        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
+    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    HIPCHK(hipGetLastError());
+    // the ONE host wait of the assignment: state block + the sorted maxima
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints + FS_COUNT, c->max_aux, XB_SORT_MAX * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int *h = c->host_ints;
+    g.main_ties = 0;
+    if (h[FS_TIES] == 0) c->grad_rule = 2;
+    c->n_boxes = h[FS_N_BOXES];
+    c->box_voxels = (long long)h[FS_N_CERTAIN] * BRK * BRK * BRK;
+    c->n_walk = h[FS_N_WALK];
+    const int novf = h[FS_N_OVF];
+    int nmax = h[FS_N_MAX];
+    if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
+    if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    c->stat_ovf_assign += novf;
+    if (h[FS_SORT_OK] && novf == 0) {
+        c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+        c->regions_pending = false;
+        c->buni_valid = !c->has_vacuum;   // k_buni_from_regions + k_label_uniform_list ran
+        c->first_clean = true;
+        if (n_maxima) *n_maxima = nmax;
+        return XB_OK;
+    }
+    // rare: trajectories for the exact slow kernel and/or more maxima than the device sort takes
+    if (novf > 0) {
+        g.main_ties = 1;
+        const int rc = run_slow(c, novf, 0, fs + FS_N_MAX);
+        g.main_ties = 0;
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_MAX, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        nmax = c->host_ints[0];
+        if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    }
+    return finish_numbering_on_host(c, nmax, n_maxima);
+}
+
+// maxima table -> host, sort by first voxel, rank + relabel (the tail of the host-driven path)
+static int sort_and_finish(xb_ctx *c, int64_t n, int64_t *n_maxima);
+static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima) {
+    c->local_max.resize(nmax);
+    c->local_first.resize(nmax);
+    if (nmax) {
+        k_gather_first<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, c->max_aux);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->local_max.data(), c->max_list, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->local_first.data(), c->max_aux, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return sort_and_finish(c, nmax, n_maxima);
+}
+
 int xb_assign(xb_ctx *c, int method, int64_t *n_maxima) {
+    NEED_GRID_RAW("xb_assign");
+    if (method == XB_METHOD_NEARGRID && fused_ok(c)) {
+        if (c->has_vacuum) { if (int rc = settle_labels(c)) return rc; }
+        else c->labels_zero_pending = false;   // every label is overwritten, none is read
+        return assign_neargrid_fused(c, n_maxima);
+    }
+    if (method == XB_METHOD_ONGRID && !c->has_vacuum) c->labels_zero_pending = false;   // the pointer pass writes every label
     int64_t n = 0;
     if (int rc = xb_assign_trace(c, method, &n)) return rc;
+    return sort_and_finish(c, n, n_maxima);
+}
+static int sort_and_finish(xb_ctx *c, int64_t n, int64_t *n_maxima) {
     // numbering: rank of the smallest voxel index reaching each maximum (thread_handlers.py:59-65
     // numbers maxima in the order the C-order scan discovers them)
     std::vector<int> order(n);
@@ -1025,7 +1230,7 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
     if (int rc = read_counter(c, 5, &n)) return rc;
     if (whole && n) {  // one slab: the list holds every edge, dilate from it
         ScopedTimer t(c, 2);
-        k_edge_dilate_list<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->known, c->list, n);
+        k_edge_dilate_list<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->known, c->list, n, nullptr);
         HIPCHK(hipGetLastError());
     }
     c->list_n = n;           // the edge list stays valid until `known` changes
@@ -1169,7 +1374,7 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
         if (int rc = ensure_grad(c, false, false, false)) return rc;
         {
             ScopedTimer t(c, 3);
-            (table_windowed(c) ? k_refine_trace<2, true> : k_refine_trace<2, false>)<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n,
+            (table_windowed(c) ? k_refine_trace<2, true> : k_refine_trace<2, false>)<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
                                                                 c->counters + 2, c->counters + 3, c->ovf_list,
                                                                 c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev);
         }
@@ -1246,7 +1451,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
         int n_new = 0;
         if (int rc = read_counter(c, 7, &n_new)) return rc;
         if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
-        else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new);
+        else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new, nullptr);
     }
     k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64);
     HIPCHK(hipGetLastError());
@@ -1266,24 +1471,94 @@ int xb_prepare_refine(xb_ctx *c) {
     return ensure_grad(c, false, false, false);
 }
 
+// edge_find + retrace of one refinement iteration on one slab with ONE host wait: the edge count stays on the
+// device (the list kernels stride over it), the counters come back together at the end.
+static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
+    const Grid &g = c->g;
+    int *fs = c->fs;
+    c->g.main_ties = 0;
+    const GridL gl = light(g);
+    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 4 * sizeof(int), c->stream));   // edges, changed, escaped, overflows
+    {
+        ScopedTimer t(c, 2);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        int *buni = nullptr;
+        if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {
+            buni = reinterpret_cast<int *>(c->st);
+            if (!c->buni_valid)
+                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
+            const int nbr = (int)(c->N / 512);
+            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
+            buni += nbr;
+        }
+        dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (g.nx + ET_X - 1) / ET_X);
+        k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, 0, g.nx, c->list, fs + FS_N_EDGES, small, buni,
+                                                       c->grad_valid ? c->grad : nullptr);
+        k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
+    }
+    c->list_valid = false;
+    c->buni_valid = false;
+    {
+        ScopedTimer t(c, 3);
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        k_refine_trace<2, false><<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, fs + FS_N_EDGES,
+                                                              fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
+                                                              c->ovf_cap, maxsteps, c->rho, c->dist_dev);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *edges = c->host_ints[0];
+    *changed = c->host_ints[1];
+    const int novf = c->host_ints[3];
+    if (c->host_ints[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", c->host_ints[2]);
+    if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
+    c->stat_ovf_refine += novf;
+    if (novf > 0) {
+        if (int rc = run_slow(c, novf, 1, nullptr, fs + FS_CHANGED, fs + FS_ESCAPED)) return rc;
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_CHANGED, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *changed = c->host_ints[0];
+    }
+    return XB_OK;
+}
+
 int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
     NEED_GRID("xb_refine");
     if (n_iters) *n_iters = 0;
     if (iters == 0) return XB_OK;  // thread_handlers.py:146-147
     if (int rc = xb_prepare_refine(c)) return rc;
     int64_t edges = 0, changed = 0, esc = 0, checked = 0;
-    if (int rc = xb_edge_find(c, &edges)) return rc;
-    if (edges == 0) return XB_OK;  // thread_handlers.py:151-153
+    const bool fused = c->opt_fused && c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
     int64_t k = 0;
     auto put = [&](int64_t e, int64_t ch) {
         if (log && 2 * k + 1 < log_capacity) { log[2 * k] = e; log[2 * k + 1] = ch; }
         k++;
         if (n_iters) *n_iters = k;
     };
-    if (int rc = xb_refine_trace(c, &changed, &esc)) return rc;
-    if (esc) return fail(XB_E_STATE, "xb_refine: %lld traces left the valid slab", (long long)esc);
+    if (fused) {
+        if (int rc = refine_iteration_fused(c, &edges, &changed)) return rc;
+        if (edges == 0) return XB_OK;  // thread_handlers.py:151-153 (no edge: the retrace had nothing to do)
+    } else {
+        if (int rc = xb_edge_find(c, &edges)) return rc;
+        if (edges == 0) return XB_OK;  // thread_handlers.py:151-153
+        if (int rc = xb_refine_trace(c, &changed, &esc)) return rc;
+        if (esc) return fail(XB_E_STATE, "xb_refine: %lld traces left the valid slab", (long long)esc);
+    }
     put(edges, changed);
     for (int64_t it = 2; iters < 0 || it <= iters; it++) {  // thread_handlers.py:194-236
+        if (fused && mode != XB_REFINE_ALL && changed == 0) {
+            // edge_check re-classifies the boxes of the voxels still flagged -2, i.e. the CHANGED ones
+            // (refinement.py:425-427): none is left, so it reports 0 edges and the retrace has no work
+            put(0, 0);
+            break;
+        }
+        if (fused && mode == XB_REFINE_ALL) {
+            if (int rc = refine_iteration_fused(c, &edges, &changed)) return rc;
+            put(edges, changed);
+            if (changed == 0) break;
+            continue;
+        }
         if (mode == XB_REFINE_ALL) {
             if (int rc = xb_edge_find(c, &edges)) return rc;
         } else {
@@ -1478,7 +1753,11 @@ int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds) {
     return rc;
 }
 
-void *xb_labels_ptr(xb_ctx *c) { return c ? (void *)c->labels : nullptr; }
+void *xb_labels_ptr(xb_ctx *c) {
+    if (!c) return nullptr;
+    settle_labels(c);
+    return (void *)c->labels;
+}
 void *xb_known_ptr(xb_ctx *c) { return c ? (void *)c->known : nullptr; }
 void *xb_density_ptr(xb_ctx *c) { return c ? (void *)c->rho : nullptr; }
 int64_t xb_plane_elems(xb_ctx *c) { return c ? c->g.nyz : 0; }
@@ -1505,6 +1784,10 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 5 && value >= 2 && value <= EC_Q) c->opt_ec_qcap = value;
     else if (key == 6) c->grad_valid = false;  // drop the cached gradient-field table (a refinement rebuilds it)
     else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
+    else if (key == 7) c->opt_fused = value != 0;  // 0: the host-driven orchestration on one GPU too (tests compare the two)
+    else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
+    else if (key == 9 && value >= 1 && value <= 4096) c->opt_trace_chunk = value;
+    else if (key == 10) c->opt_trace_xcd = value != 0;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
 }

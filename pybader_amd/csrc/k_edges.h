@@ -67,9 +67,9 @@ __global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__res
 // After an assignment without vacuum every certain brick is uniform by construction (all its voxels
 // carry the rank of the region's maximum): only the bricks of the walk list need the label scan.
 __global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
-                                    const int *__restrict__ rank, int *__restrict__ buni) {
+                                    const int *__restrict__ rank, int *__restrict__ buni, const int *gate) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbr) return;
+    if (b >= nbr || (gate && !*gate)) return;
     const int l = blab[b];
     if (l > 0) buni[b] = rank[box_max[l - 1]];
 }
@@ -88,31 +88,35 @@ __global__ void k_buni3(int nb0, int nb1, int nb2, const int *__restrict__ buni,
     }
     buni3[b] = ok ? l : XB_MIXED;
 }
+// one WAVE per listed brick (8 labels per lane), bricks strided over the grid; the list length may live on the
+// device (n_dev) and `gate` (when given) must be non-zero for the kernel to do anything
 __global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *__restrict__ labels, int nb1, int nb2,
-                                                            const int *__restrict__ walk, int n_walk,
-                                                            int *__restrict__ buni) {
-    __shared__ int s_min, s_max;
-    if ((int)blockIdx.x >= n_walk) return;
-    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
-    __syncthreads();
-    const int b = walk[blockIdx.x];
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int lo = 2147483647, hi = XB_MIXED;
-    for (int t = threadIdx.x; t < 512; t += TPB) {
-        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
-        lo = min(lo, l); hi = max(hi, l);
+                                                            const int *__restrict__ walk, int n_walk, const int *n_dev,
+                                                            const int *gate, int *__restrict__ buni) {
+    if (gate && !*gate) return;
+    const int n = n_dev ? *n_dev : n_walk;
+    const int lane = threadIdx.x % XB_WAVE;
+    for (int e = blockIdx.x * (TPB / XB_WAVE) + threadIdx.x / XB_WAVE; e < n; e += gridDim.x * (TPB / XB_WAVE)) {
+        const int b = walk[e];
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        int lo = 2147483647, hi = XB_MIXED;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = lane + k * XB_WAVE;
+            const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
+            lo = min(lo, l); hi = max(hi, l);
+        }
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) buni[b] = (lo == hi) ? lo : XB_MIXED;
     }
-    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
-    __syncthreads();
-    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
 }
 
 // refinement.py:385-404 as written there: every listed edge voxel turns the known >= 0 voxels of
 // its 27-box into -1 (all -2 flags are final before this kernel starts).
-__global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known, const int *__restrict__ list, int n) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n) return;
+__global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known, const int *__restrict__ list, int n_host,
+                                                          const int *n_dev) {
+    const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
+  for (int t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) {
     const int v = list[t];
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known
 #pragma unroll
     for (int j = 0; j < 27; j++)
         if (k[j] >= 0) known[idx[j]] = -1;
+  }
 }
 
 // LDS-tiled edge_find pass 1: a block stages the labels of a 4x8x64 tile plus a one-voxel periodic
@@ -377,11 +382,14 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int 
 // ---------------------------------------------------------------------------------------------
 template <int K, bool WIN>
 __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
-                                                      int8_t *known, const int *__restrict__ list, int n,
-                                                      int *changed, int *escaped, int *ovf_list, int *ovf_count,
-                                                      int ovf_cap, int maxsteps, const double *__restrict__ rho,
-                                                      const double *__restrict__ gc) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
+                                                      int8_t *known, const int *__restrict__ list, int n_host,
+                                                      const int *n_dev, int *changed, int *escaped, int *ovf_list,
+                                                      int *ovf_count, int ovf_cap, int maxsteps,
+                                                      const double *__restrict__ rho, const double *__restrict__ gc) {
+    const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
+    int n_ch = 0, n_es = 0;
+  for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
+    const int t = base + threadIdx.x;
     const bool valid = t < n;
     const int v = valid ? list[t] : 0;
     bool moving = false;
@@ -451,10 +459,12 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
             if (k < ovf_cap) ovf_list[k] = v;
         } else if (result == -4) { known[v] = -6; es = 1; }  // left the valid slab: parked for the fallback
     }
-    const unsigned long long bc = __ballot(ch), be = __ballot(es);
+    n_ch += ch; n_es += es;
+  }
+    for (int o = 32; o > 0; o >>= 1) { n_ch += __shfl_down(n_ch, o); n_es += __shfl_down(n_es, o); }
     if (threadIdx.x % XB_WAVE == 0) {
-        if (bc) atomicAdd(changed, __popcll(bc));
-        if (be) atomicAdd(escaped, __popcll(be));
+        if (n_ch) atomicAdd(changed, n_ch);
+        if (n_es) atomicAdd(escaped, n_es);
     }
 }
 

@@ -1,0 +1,272 @@
+// k_fused.h -- device kernels of libbader_hip.so: the control flow of the single-GPU step kept ON the device.
+// Included by bader_hip.hip (one translation unit).
+//
+// Round 1 drove the step from the host: ~25 times per step a counter was copied back and waited for (seed count,
+// box radii, brick-growth convergence flags, list lengths, maxima table) -- ~30 us each, ~0.8 ms of a 5.6 ms step.
+// Here every such decision is taken by a small kernel that leaves its result in the state block `fs` (device
+// ints), the data-dependent launches are either fixed-size grids that stride over a device-side count or
+// persistent grids pulling from a device-side cursor, and the host waits ONCE at the end of xb_assign and ONCE per
+// refinement iteration.
+#pragma once
+
+// state block (ints, device).  Zeroed by one memset at the start of an assignment.
+enum {
+    FS_N_SEEDS = 0,      // 26-neighbour maxima appended by the table pass (raw count, may exceed the capacity)
+    FS_TIES,             // != 0: some voxel's record depends on the tie rule
+    FS_N_SEEDS_EFF,      // seeds used for boxes (0 when there are none or too many)
+    FS_N_BOXES,          // closed seed cubes found
+    FS_GROW_PHASE,       // 0 propagate, 1 kill, 2 done
+    FS_GROW_CHANGED,     // a block of the current launch changed a label
+    FS_GROW_TICKET,      // blocks of the current launch that have finished
+    FS_GROW_CUR,         // which of the two label buffers holds the current labels
+    FS_GROW_CONVERGED,   // the kill iteration reached its fixpoint
+    FS_N_CERTAIN,        // bricks inside trapping regions
+    FS_N_WALK,           // bricks on the walk list
+    FS_N_MAX,            // maxima noted by the trace
+    FS_N_OVF,            // trajectories handed to the exact slow kernel
+    FS_SORT_OK,          // the numbering was done on the device
+    FS_ERR,              // loud failures (bit 0: ongrid chase did not terminate)
+    FS_N_EDGES,          // refinement: edge list length
+    FS_CHANGED, FS_ESCAPED, FS_R_OVF,
+    FS_COUNT = 64,
+    // 8 per-XCD work cursors of the persistent trace, one per 128-byte line: device-scope atomics on ONE line
+    // serialise at ~88 per microsecond whatever the word (measured: 8 cursors in one line = one cursor)
+    FS_CURSOR0 = 64, FS_CURSOR_STRIDE = 32,
+    FS_TOTAL = FS_CURSOR0 + 8 * FS_CURSOR_STRIDE
+};
+
+#define XB_BOX_K 32   // seed cubes are searched up to this radius (brick growth takes over from there)
+
+// seeds (unsorted, appended atomically by the table pass) -> sorted seeds, their coordinates and the largest
+// radius each cube may take (stay clear of the nearest other maximum; a cube must not wrap onto itself)
+__global__ __launch_bounds__(64) void k_box_setup(GridL g, int *fs, int *seeds, int seed_cap, int max_seeds, int *mxyz, int *rcap) {
+    __shared__ int s[64];
+    const int t = threadIdx.x;
+    int ns = fs[FS_N_SEEDS];
+    if (ns < 1 || ns > max_seeds || ns > seed_cap || ns > 64) ns = 0;
+    const int mine = t < ns ? seeds[t] : XB_INT_MAX;
+    int rank = 0;
+    if (t < ns) s[t] = mine;
+    __syncthreads();
+    for (int o = 0; o < ns; o++) rank += (s[o] < mine);   // seeds are distinct voxels
+    __syncthreads();
+    if (t < ns) s[rank] = mine;
+    __syncthreads();
+    if (t < ns) {
+        const int v = s[t];
+        seeds[t] = v;
+        const int x = v / g.nyz, y = (v % g.nyz) / g.nz, z = v % g.nz;
+        mxyz[3 * t] = x; mxyz[3 * t + 1] = y; mxyz[3 * t + 2] = z;
+        int cap = min(min(g.nx, g.ny), g.nz) / 2 - 2;
+        for (int o = 0; o < ns; o++)
+            if (o != t) {
+                const int w = s[o];
+                const int d = max(max(min_image_abs(x - w / g.nyz, g.nx), min_image_abs(y - (w % g.nyz) / g.nz, g.ny)),
+                                  min_image_abs(z - w % g.nz, g.nz));
+                cap = min(cap, d - 1);
+            }
+        rcap[t] = max(cap, 0);
+    }
+    if (t == 0) fs[FS_N_SEEDS_EFF] = ns;
+}
+// shells 0..XB_BOX_K of every seed cube (see k_box_shells); blockIdx.y strides over the seeds found on the device
+template <bool FROM_RHO>
+__global__ __launch_bounds__(TPB) void k_box_shells_dev(Grid g, const double *__restrict__ rho, const GradRec *__restrict__ G,
+                                                        const int *__restrict__ fs, const int *__restrict__ mxyz,
+                                                        const int *__restrict__ rcap, int *bad, int stride) {
+    const int ns = fs[FS_N_SEEDS_EFF];
+    for (int m = blockIdx.y; m < ns; m += gridDim.y) {
+        const int rhi = min(XB_BOX_K, rcap[m]);
+        const int w = 2 * rhi + 1;
+        const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
+        if (t >= (long long)w * w * w) continue;
+        const int o[3] = {(int)(t / ((long long)w * w)) - rhi, (int)((t / w) % w) - rhi, (int)(t % w) - rhi};
+        const int d = max(max(abs(o[0]), abs(o[1])), abs(o[2]));
+        const int x = wrap_any(mxyz[3 * m] + o[0], g.nx), y = wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
+                  z = wrap_any(mxyz[3 * m + 2] + o[2], g.nz);
+        int lo[3], hi[3];
+        if (FROM_RHO) move_ranges_rho(rho, g, x, y, z, lo, hi);
+        else move_ranges(fetch_rec(G, (x * g.ny + y) * g.nz + z), lo, hi);
+        int D = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));
+        for (int R = d; R < D; R++) bad[m * stride + R] = 1;
+    }
+}
+// the largest closed radius per seed; seeds with one become boxes (ids in seed order)
+__global__ __launch_bounds__(64) void k_box_pick(int *fs, const int *__restrict__ seeds, const int *__restrict__ mxyz,
+                                                 const int *__restrict__ rcap, const int *__restrict__ bad, int stride,
+                                                 int *box_max, int *bx, int *br) {
+    __shared__ int best[64];
+    const int ns = fs[FS_N_SEEDS_EFF];
+    const int t = threadIdx.x;
+    if (t < ns) {
+        int b = 0;
+        for (int R = 1; R <= min(XB_BOX_K, rcap[t]); R++)
+            if (!bad[t * stride + R]) b = R;
+        best[t] = b;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int n = 0;
+        for (int m = 0; m < ns; m++)
+            if (best[m] >= 1) {
+                box_max[n] = seeds[m];
+                bx[3 * n] = mxyz[3 * m]; bx[3 * n + 1] = mxyz[3 * m + 1]; bx[3 * n + 2] = mxyz[3 * m + 2];
+                br[n] = best[m];
+                n++;
+            }
+        fs[FS_N_BOXES] = n;
+        fs[FS_GROW_PHASE] = n ? 0 : 2;   // nothing to grow without a box
+        fs[FS_GROW_CONVERGED] = 0;
+    }
+}
+
+// k_brick_grow with the convergence logic on the device: every launch of the fixed schedule reads the phase
+// (0 propagate, 1 kill, 2 done: return at once); the block that finishes last advances the phase when the launch
+// changed nothing and flips the current buffer otherwise.  See k_brick_grow for the iteration itself.
+__global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
+                                                                 const int *__restrict__ seed, int *buf0, int *buf1, int *fs,
+                                                                 int inner) {
+    __shared__ int lab[2][BG + 2][BG + 2][BG + 2];
+    __shared__ int s_any;
+    const int phase = fs[FS_GROW_PHASE];
+    if (phase >= 2) return;
+    const int curbuf = fs[FS_GROW_CUR];
+    const int *in = curbuf ? buf1 : buf0;
+    int *out = curbuf ? buf0 : buf1;
+    if (threadIdx.x == 0) s_any = 0;
+    const int c0 = blockIdx.z * BG, c1 = blockIdx.y * BG, c2 = blockIdx.x * BG;
+    for (int i = threadIdx.x; i < (BG + 2) * (BG + 2) * (BG + 2); i += BG * BG * BG) {
+        const int e2 = i % (BG + 2), e1 = (i / (BG + 2)) % (BG + 2), e0 = i / ((BG + 2) * (BG + 2));
+        const int l = in[(wrap_any(c0 + e0 - 1, nb0) * nb1 + wrap_any(c1 + e1 - 1, nb1)) * nb2 + wrap_any(c2 + e2 - 1, nb2)];
+        lab[0][e0][e1][e2] = l;
+        lab[1][e0][e1][e2] = l;
+    }
+    const int t2 = threadIdx.x % BG, t1 = (threadIdx.x / BG) % BG, t0 = threadIdx.x / (BG * BG);
+    const int b0 = c0 + t0, b1 = c1 + t1, b2 = c2 + t2;
+    const bool active = b0 < nb0 && b1 < nb1 && b2 < nb2;
+    const int b = active ? (b0 * nb1 + b1) * nb2 + b2 : 0;
+    const int m = active ? bmask[b] : 0;
+    const bool fixed = !active || (phase == 0 && (m >> 27)) || (phase == 1 && seed[b] != 0);
+    __syncthreads();
+    const int first = lab[0][t0 + 1][t1 + 1][t2 + 1];
+    int l = first, cur = 0;
+    for (int it = 0; it < inner; it++) {
+        int nl = l;
+        if (!fixed) {
+            if (phase == 0) {
+                if (l == 0) {
+                    int best = 0;
+                    for (int k = 0; k < 27; k++)
+                        if ((m >> k) & 1) {
+                            const int q = lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3];
+                            if (q > 0 && (best == 0 || q < best)) best = q;
+                        }
+                    nl = best;
+                }
+            } else if (l > 0) {
+                bool ok = !(m >> 27);
+                for (int k = 0; k < 27 && ok; k++)
+                    if ((m >> k) & 1) ok = (lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3] == l);
+                if (!ok) nl = 0;
+            }
+        }
+        lab[cur ^ 1][t0 + 1][t1 + 1][t2 + 1] = nl;
+        const int any = __syncthreads_or(nl != l);
+        l = nl;
+        cur ^= 1;
+        if (!any) break;
+    }
+    if (active) out[b] = l;
+    if (active && l != first) s_any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // ONE atomic carries this block's ticket (low 16 bits) and its change flag (bit 16 up): the block whose add
+        // comes last sees every other block's flag in the returned word -- no fence needed, the labels themselves
+        // only have to be visible to the NEXT launch
+        const int nblk = gridDim.x * gridDim.y * gridDim.z;
+        const int old = atomicAdd(&fs[FS_GROW_TICKET], 1 + (s_any ? 0x10000 : 0));
+        if ((old & 0xffff) == nblk - 1) {   // last block of this launch
+            const bool ch = (old >> 16) != 0 || s_any;
+            fs[FS_GROW_TICKET] = 0;
+            fs[FS_GROW_CUR] = curbuf ^ 1;       // `out` holds the labels now (identical to `in` if nothing changed)
+            if (!ch) {
+                fs[FS_GROW_PHASE] = phase + 1;
+                if (phase == 1) fs[FS_GROW_CONVERGED] = 1;
+            }
+        }
+    }
+}
+// blab := the surviving labels (a FIXPOINT of the kill iteration is closed under every move; without one fall
+// back to the seed cubes, which are trapping regions on their own); counts the certain bricks
+__global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restrict__ seed, const int *__restrict__ buf0,
+                                                     const int *__restrict__ buf1, int *fs, int *__restrict__ blab) {
+    const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
+    const int nbx = fs[FS_N_BOXES];
+    int cnt = 0;
+    for (int b = blockIdx.x * TPB + threadIdx.x; b < nbr; b += gridDim.x * TPB) {
+        const int l = nbx ? src[b] : 0;
+        blab[b] = l;
+        cnt += (l > 0);
+    }
+    int total;
+    block_scan_excl(cnt, total);
+    if (threadIdx.x == 0 && total) atomicAdd(&fs[FS_N_CERTAIN], total);
+}
+__global__ void k_brick_seed_dev(GridL g, int nb0, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ mxyz,
+                                 const int *__restrict__ radius, int *blab, int *blab2) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb0 * nb1 * nb2) return;
+    const int n_boxes = fs[FS_N_BOXES];
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int lab = 0;
+    for (int m = 0; m < n_boxes; m++) {
+        const int R = radius[m];
+        bool in = true;
+        const int n3[3] = {g.nx, g.ny, g.nz}, bb[3] = {b0, b1, b2};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            int lo = bb[j] * BRK - mxyz[3 * m + j];
+            lo = ((lo % n3[j]) + n3[j]) % n3[j];
+            if (lo > n3[j] / 2) lo -= n3[j];
+            in &= (lo >= -R) && (lo + BRK - 1 <= R);
+        }
+        if (in) lab = m + 1;
+    }
+    blab[b] = lab;
+    blab2[b] = lab;   // first label buffer of the growth
+}
+
+// numbering on the device: maxima sorted by the smallest voxel index that reaches them (thread_handlers.py:59-65
+// numbers maxima in scan order); first[m] := rank.  One block, bitonic sort in LDS; more than XB_SORT_MAX maxima
+// (noisy data) leave FS_SORT_OK = 0 and the host sorts instead.
+#define XB_SORT_MAX 2048
+__global__ __launch_bounds__(1024) void k_number_maxima(int *fs, int *first, const int *__restrict__ max_list, int max_cap,
+                                                        int *sorted) {
+    __shared__ unsigned long long key[XB_SORT_MAX];
+    const int n = fs[FS_N_MAX];
+    // trajectories waiting for the exact slow kernel may still discover maxima: number on the host afterwards
+    if (n > XB_SORT_MAX || n > max_cap || fs[FS_N_OVF] > 0) { if (threadIdx.x == 0) fs[FS_SORT_OK] = 0; return; }
+    for (int i = threadIdx.x; i < XB_SORT_MAX; i += 1024)
+        key[i] = i < n ? ((unsigned long long)(unsigned)first[max_list[i]] << 32) | (unsigned)max_list[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= XB_SORT_MAX; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < XB_SORT_MAX; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = key[i], b = key[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int m = (int)(key[i] & 0xffffffffu);
+        sorted[i] = m;
+        first[m] = i;
+    }
+    if (threadIdx.x == 0) fs[FS_SORT_OK] = 1;
+}

@@ -80,11 +80,17 @@ __global__ void k_reset_first(int *first, const int *max_list, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) first[max_list[i]] = XB_INT_MAX;
 }
+// the same for a device-side count (and only when `gate` is set: the device-side numbering succeeded)
+__global__ void k_reset_first_dev(int *first, const int *max_list, const int *n_dev, const int *gate) {
+    if (!*gate) return;
+    const int n = *n_dev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) first[max_list[i]] = XB_INT_MAX;
+}
 // labels[v] (maximum index) -> rank stored in first[maximum]
-__global__ __launch_bounds__(TPB) void k_relabel(Grid g, int *labels, const int *__restrict__ rank) {
+__global__ __launch_bounds__(TPB) void k_relabel(Grid g, int *labels, const int *__restrict__ rank, const int *gate) {
     const long long vbeg = (long long)g.x0 * g.nyz, vend = (long long)g.x1 * g.nyz;
     const long long v = vbeg + (long long)blockIdx.x * TPB + threadIdx.x;
-    if (v >= vend) return;
+    if (v >= vend || (gate && !*gate)) return;
     const int m = labels[v];
     if (m >= 0) labels[v] = rank[m];
 }

@@ -51,9 +51,9 @@ __global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_
 // from the maximum index the trace left in `labels`
 __global__ __launch_bounds__(TPB) void k_relabel_regions(GridL g, int *labels, const int *__restrict__ rank,
                                                          const int *__restrict__ blab, int nb1, int nb2,
-                                                         const int *__restrict__ box_max) {
+                                                         const int *__restrict__ box_max, const int *gate) {
     const int v = g.x0 * g.nyz + blockIdx.x * TPB + threadIdx.x;
-    if (v >= g.x1 * g.nyz) return;
+    if (v >= g.x1 * g.nyz || (gate && !*gate)) return;
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
@@ -67,9 +67,9 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions(GridL g, int *labels, c
 // the same, four z-consecutive voxels per thread (nz % 4 == 0: they share a brick): one 16-byte store
 __global__ __launch_bounds__(TPB) void k_relabel_regions4(GridL g, int *labels, const int *__restrict__ rank,
                                                           const int *__restrict__ blab, int nb1, int nb2,
-                                                          const int *__restrict__ box_max) {
+                                                          const int *__restrict__ box_max, const int *gate) {
     const long long v = (long long)g.x0 * g.nyz + 4LL * ((long long)blockIdx.x * TPB + threadIdx.x);
-    if (v >= (long long)g.x1 * g.nyz) return;
+    if (v >= (long long)g.x1 * g.nyz || (gate && !*gate)) return;
     const int x = (int)(v / g.nyz);
     const int r = (int)(v - (long long)x * g.nyz);
     const int y = r / g.nz, z = r - y * g.nz;
@@ -112,49 +112,16 @@ __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
     ox = og / 9 - 1; oy = (og / 3) % 3 - 1; oz = og % 3 - 1;
 }
 
-// WIN: the table covers only a window of the grid (slabs); records outside it are derived from rho on the
-// spot.  The single-GPU instantiation leaves that (register hungry) path out.
+// The walkers of one wave: lane -> start voxel (sx,sy,sz); `in_walk`: the start lies in a brick of the walk list
+// (uncertain by construction).  WIN: the table covers only a window of the grid (slabs); records outside it are
+// derived from rho on the spot.  The single-GPU instantiation leaves that (register hungry) path out.
 template <int K, bool WIN>
-__global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
-                                                  const int *__restrict__ box_max, const int *__restrict__ blab,
-                                                  int nb1, int nb2, const int *__restrict__ walk, int n_walk,
-                                                  int *labels, int *first,
-                                                  int *max_list, int *max_count, int max_cap, int *ovf_list,
-                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt,
-                                                  const double *__restrict__ rho, const double *__restrict__ gc) {
-    // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
-    // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
-    // whose trajectories read the same table lines -- share one L2.
-    int blk = blockIdx.x;
-    if (opt & 2) {
-        const int per = gridDim.x >> 3;
-        if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
-    }
-    const int wpb = blockDim.x / XB_WAVE;  // waves per block (launch-time choice)
-    const int wave = blk * wpb + threadIdx.x / XB_WAVE;
-    const int lane = threadIdx.x % XB_WAVE;
-    int sx, sy, sz;
-    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (4x4x4 each) per brick
-        if ((wave >> 3) >= n_walk) return;
-        const int b = walk[wave >> 3], sub = wave & 7;
-        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-        sx = b0 * 8 + ((sub >> 2) << 2) + (lane >> 4);
-        sy = b1 * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
-        sz = b2 * 8 + ((sub & 1) << 2) + (lane & 3);
-        if (sx < g.x0 || sx >= g.x1) return;  // whole wave: 4 planes of one brick half, slab edges are brick aligned or not owned
-    } else if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
-        const int bz_n = (g.nz + 3) >> 2, by_n = (g.ny + 3) >> 2;
-        const int bx = wave / (by_n * bz_n);
-        const int brem = wave - bx * (by_n * bz_n);
-        const int by = brem / bz_n, bz = brem - by * bz_n;
-        sx = g.x0 + bx * 4 + (lane >> 4); sy = by * 4 + ((lane >> 2) & 3); sz = bz * 4 + (lane & 3);
-    } else {        // one wave = a run of 64 voxels along z
-        const int rz_n = (g.nz + 63) >> 6;
-        const int row = wave / rz_n;
-        sz = (wave - row * rz_n) * 64 + lane;
-        sx = g.x0 + row / g.ny;
-        sy = row - (row / g.ny) * g.ny;
-    }
+__device__ __forceinline__ void ng_walk_wave(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+                                             const int *__restrict__ blab, int nb1, int nb2, bool in_walk, int sx, int sy, int sz,
+                                             int *labels, int *first, int *max_list, int *max_count, int max_cap,
+                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps,
+                                             const double *__restrict__ rho, const double *__restrict__ gc,
+                                             bool has_vacuum = true) {
     const bool valid = sx < g.x1 && sy < g.ny && sz < g.nz;
     const int v = valid ? (sx * g.ny + sy) * g.nz + sz : 0;
     bool moving = false;
@@ -167,8 +134,8 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     if (valid) {
         // the three start loads travel together (label for the vacuum test, brick label, own record); a start
         // voxel from the work list lies in an uncertain brick by construction
-        const int lab0 = labels[v];
-        int b = (blab && !walk) ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
+        const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
+        int b = (blab && !in_walk) ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
         rec = fetch_rec(G, v);
         if (lab0 != -1) {
             px = sx; py = sy; pz = sz;
@@ -184,14 +151,14 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
             const int bits = key_bits(rec.key);
             const int code = bits & 63;
             int qx, qy, qz, lq = 0;
-            // refinement.py:132-154: the gradient move (if the voxel has one)
+            // methods.py:345-363 / refinement.py:132-154: the gradient move (if the voxel has one)
             bool og_move = (code == XB_STAY_CODE);
             if (!og_move) {
                 ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
                 lq = lin3f(g, qx, qy, qz);
-                og_move = w.contains(lq);  // refinement.py:200: already been here on this path
+                og_move = w.contains(lq);  // methods.py:411 / refinement.py:200: already been here on this path
             }
-            if (og_move) {  // refinement.py:201-235: dr = 0 and one ongrid step from p (tabulated)
+            if (og_move) {  // methods.py:412-447 / refinement.py:201-235: dr = 0 and one ongrid step from p (tabulated)
                 const int og = (bits >> 6) & 31;
                 if (og == XB_OG_SELF) { result = lp; moving = false; }  // break_flag: p is the maximum
                 else {
@@ -221,13 +188,98 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
             }
         }
     }
-    // a maximum that is itself vacuum hands its -1 to the start voxel (refinement.py:286)
-    if (valid && result >= 0 && result != v && labels[result] == -1) result = -1;
+    // a maximum that is itself vacuum hands its -1 to the start voxel (methods.py:449-452 / refinement.py:286)
+    if (has_vacuum && valid && result >= 0 && result != v && labels[result] == -1) result = -1;
     if (valid) labels[v] = result;
     note_maximum_wave(valid && result >= 0, result, v, first, max_list, max_count, max_cap);
     if (valid && result == -2) {
         const int k = atomicAdd(ovf_count, 1);
         if (k < ovf_cap) ovf_list[k] = v;
+    }
+}
+// lane -> voxel of the 4x4x4 eighth `sub` of brick b (z fastest: 4 lanes per 128-B table line)
+__device__ __forceinline__ void brick_sub_voxel(int b, int sub, int lane, int nb1, int nb2, int &sx, int &sy, int &sz) {
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    sx = b0 * 8 + ((sub >> 2) << 2) + (lane >> 4);
+    sy = b1 * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
+    sz = b2 * 8 + ((sub & 1) << 2) + (lane & 3);
+}
+template <int K, bool WIN>
+__global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
+                                                  const int *__restrict__ box_max, const int *__restrict__ blab,
+                                                  int nb1, int nb2, const int *__restrict__ walk, int n_walk,
+                                                  int *labels, int *first,
+                                                  int *max_list, int *max_count, int max_cap, int *ovf_list,
+                                                  int *ovf_count, int ovf_cap, int maxsteps, int opt,
+                                                  const double *__restrict__ rho, const double *__restrict__ gc) {
+    // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
+    // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
+    // whose trajectories read the same table lines -- share one L2.
+    int blk = blockIdx.x;
+    if (opt & 2) {
+        const int per = gridDim.x >> 3;
+        if (blk < (per << 3)) blk = (blk & 7) * per + (blk >> 3);
+    }
+    const int wpb = blockDim.x / XB_WAVE;  // waves per block (launch-time choice)
+    const int wave = blk * wpb + threadIdx.x / XB_WAVE;
+    const int lane = threadIdx.x % XB_WAVE;
+    int sx, sy, sz;
+    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (4x4x4 each) per brick
+        if ((wave >> 3) >= n_walk) return;
+        brick_sub_voxel(walk[wave >> 3], wave & 7, lane, nb1, nb2, sx, sy, sz);
+        if (sx < g.x0 || sx >= g.x1) return;  // whole wave: 4 planes of one brick half, slab edges are brick aligned or not owned
+    } else if (opt & 1) {  // one wave = one 4x4x4 brick of start voxels (z fastest: 4 lanes per 128-B table line)
+        const int bz_n = (g.nz + 3) >> 2, by_n = (g.ny + 3) >> 2;
+        const int bx = wave / (by_n * bz_n);
+        const int brem = wave - bx * (by_n * bz_n);
+        const int by = brem / bz_n, bz = brem - by * bz_n;
+        sx = g.x0 + bx * 4 + (lane >> 4); sy = by * 4 + ((lane >> 2) & 3); sz = bz * 4 + (lane & 3);
+    } else {        // one wave = a run of 64 voxels along z
+        const int rz_n = (g.nz + 63) >> 6;
+        const int row = wave / rz_n;
+        sz = (wave - row * rz_n) * 64 + lane;
+        sx = g.x0 + row / g.ny;
+        sy = row - (row / g.ny) * g.ny;
+    }
+    ng_walk_wave<K, WIN>(g, G, box_max, blab, nb1, nb2, walk != nullptr, sx, sy, sz, labels, first, max_list, max_count,
+                         max_cap, ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc);
+}
+// Persistent form (single GPU, device-side control flow, k_fused.h): a fixed grid of one-wave workgroups pulls
+// 4x4x4 eighths of the walk-list bricks until none is left; the list length stays on the device.  One cursor per
+// XCD (each XCD takes the k-th contiguous eighth of the list first -- spatial neighbours read the same table
+// lines, one L2 each -- and helps the others afterwards).
+__device__ __forceinline__ int xcc_id() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7;
+}
+template <int K>
+__global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+                                                        const int *__restrict__ blab, int nb1, int nb2,
+                                                        const int *__restrict__ walk, int *fs, int *labels, int *first,
+                                                        int *max_list, int max_cap, int *ovf_list, int ovf_cap, int maxsteps,
+                                                        int has_vacuum, int CH, int xcd_split) {
+    const int n_items = fs[FS_N_WALK] * 8;
+    const int per = (n_items + 7) >> 3;
+    const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
+    const int lane = threadIdx.x;
+    // CH items per pull (16 = two bricks: one device-scope atomic per 1024 start voxels)
+    for (int r = 0; r < 8; r++) {
+        const int q = (home + r) & 7;
+        const int beg = q * per, end = min(beg + per, n_items);
+        for (;;) {
+            int base = 0;
+            if (lane == 0) base = beg + atomicAdd(&fs[FS_CURSOR0 + q * FS_CURSOR_STRIDE], CH);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= end) break;
+            const int stop = min(base + CH, end);
+            for (int item = base; item < stop; item++) {
+                int sx, sy, sz;
+                brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
+                ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                                       max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
+            }
+        }
     }
 }
 

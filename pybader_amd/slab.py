@@ -323,6 +323,11 @@ class SlabRunner:
 
     def assign(self, method):
         """thread_handlers.bader_calc: per-slab trajectories, then one tiny table merge for numbering."""
+        if self.comm.size == 1 and hasattr(self.be, 'assign'):
+            # one GPU: the library's own xb_assign (control flow on the device, one host wait)
+            self.n_maxima = int(self.be.assign(method))
+            self.maxima = np.ravel_multi_index(tuple(self.be.maxima().T), self.shape) if self.n_maxima else np.zeros(0, np.int64)
+            return self.n_maxima
         if getattr(self, 'windowed', False) and method == 'neargrid':
             # windowed table: the trapping regions need every rank's maxima and brick masks
             with _Phase(self, 'table_build'):
@@ -441,6 +446,8 @@ class SlabRunner:
         log = []
         if iters == 0:
             return log
+        if self.comm.size == 1 and hasattr(self.be, 'refine') and hasattr(self.be, 'ctx'):
+            return self.be.refine(mode, iters)      # one GPU: xb_refine (one host wait per iteration)
         self.exchange_label_halo()
         if hasattr(self.be, 'prepare_refine') and not getattr(self, 'windowed', False):
             with _Phase(self, 'table_build'):
