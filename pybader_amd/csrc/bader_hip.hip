@@ -106,6 +106,7 @@ struct xb_ctx {
     int opt_trace_grid = 8192; // one-wave workgroups of the persistent trace
     int opt_trace_chunk = 1;   // items (4x4x4 eighths of a brick) per pull: 1 keeps the waves of an XCD on ~128 neighbouring bricks (2 MB of table, L2 resident); 32 per pull ran 1.8x slower
     int opt_trace_xcd = 1;     // 1: ranges by the real XCC id, 0: by blockIdx % 8
+    int opt_morton = 1;        // walk list in Morton order of the bricks
     unsigned long long *counters64 = nullptr;
     double *dsum = nullptr;
     int *host_ints = nullptr;  // pinned
@@ -1016,7 +1017,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
     int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
     int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP, *box_max = c->boxbuf + BB_BOXMAX,
-        *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * 64, *bad = c->boxbuf + BB_BAD;
+        *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * 64, *box_first = c->boxbuf + BB_EXT + 4 * 64, *bad = c->boxbuf + BB_BAD;
     const int stride = XB_BOX_K + 4;
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(bad, 0, (size_t)64 * stride * sizeof(int), c->stream));
@@ -1057,7 +1058,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf);
+        k_fill<int><<<1, 64, 0, c->stream>>>(box_first, XB_INT_MAX, 64);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first);
         HIPCHK(hipGetLastError());
     }
     c->blab = c->blab_buf;
@@ -1066,13 +1068,19 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     const long long own = c->N;
     {   // region fill / notes, then the walkers of the uncertain bricks
         ScopedTimer t0(c, 0);
-        k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK);
+        if (c->opt_morton) {
+            int bits = 0;
+            while ((1 << bits) < std::max(std::max(nb0, nb1), nb2)) bits++;
+            const unsigned n_codes = 1u << (3 * bits);
+            k_brick_walk_list_morton<<<(n_codes + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nb0, nb1, nb2, n_codes, c->blab, walk,
+                                                                                                  fs + FS_N_WALK);
+        } else
+            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK);
         if (c->has_vacuum)
             k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
                                                                 fs + FS_N_MAX, c->max_cap);
         else {
-            k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, 0, nbr, c->blab, box_max, c->first,
-                                                                          c->max_list, fs + FS_N_MAX, c->max_cap);
+            k_note_regions<<<1, 64, 0, c->stream>>>(gl, nb1, nb2, fs, box_first, box_max, c->first, c->max_list, fs + FS_N_MAX, c->max_cap);
             c->regions_pending = true;
         }
         {
@@ -1089,7 +1097,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     int *buni = reinterpret_cast<int *>(c->st);
     if (c->regions_pending) {
         if (g.nz % 4 == 0)
-            k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
+            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                        box_max, fs, fs + FS_SORT_OK);
         else
             k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
         k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
@@ -1788,6 +1797,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
     else if (key == 9 && value >= 1 && value <= 4096) c->opt_trace_chunk = value;
     else if (key == 10) c->opt_trace_xcd = value != 0;
+    else if (key == 11) c->opt_morton = value != 0;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
 }

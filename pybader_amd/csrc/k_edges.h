@@ -175,6 +175,19 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
         __syncthreads();
         if (!s_mixed) {
             const int8_t o = (s_lab == -1) ? 0 : 2;  // vacuum stays 0 (refinement.py:342-343), else "known"
+            if ((g.nz & 15) == 0 && z0 + ET_Z <= g.nz) {   // 16-byte stores: 32 rows of 64 flags, 4 threads per row
+                if (threadIdx.x < 128) {
+                    const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
+                    const int xr = tx0 + (row >> 3), y = y0 + (row & 7);
+                    if (xr < nplanes && y < g.ny) {
+                        int x = xa + xr;
+                        if (x >= g.nx) x -= g.nx;
+                        const unsigned w = o ? 0x02020202u : 0u;
+                        *reinterpret_cast<uint4 *>(known + ((size_t)(x * g.ny + y) * g.nz + z0 + seg * 16)) = make_uint4(w, w, w, w);
+                    }
+                }
+                return;
+            }
             const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
 #pragma unroll
             for (int k = 0; k < 8; k++) {

@@ -158,17 +158,19 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
             if (phase == 0) {
                 if (l == 0) {
                     int best = 0;
-                    for (int k = 0; k < 27; k++)
-                        if ((m >> k) & 1) {
-                            const int q = lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3];
-                            if (q > 0 && (best == 0 || q < best)) best = q;
-                        }
+                    for (unsigned mm = (unsigned)m & 0x7ffffffu; mm; mm &= mm - 1) {   // the bricks it can move into
+                        const int k = __ffs(mm) - 1;
+                        const int q = lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3];
+                        if (q > 0 && (best == 0 || q < best)) best = q;
+                    }
                     nl = best;
                 }
             } else if (l > 0) {
                 bool ok = !(m >> 27);
-                for (int k = 0; k < 27 && ok; k++)
-                    if ((m >> k) & 1) ok = (lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3] == l);
+                for (unsigned mm = (unsigned)m & 0x7ffffffu; mm && ok; mm &= mm - 1) {
+                    const int k = __ffs(mm) - 1;
+                    ok = (lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3] == l);
+                }
                 if (!ok) nl = 0;
             }
         }
@@ -200,19 +202,39 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
 }
 // blab := the surviving labels (a FIXPOINT of the kill iteration is closed under every move; without one fall
 // back to the seed cubes, which are trapping regions on their own); counts the certain bricks
+// box_first[id] (preset to INT_MAX): the smallest certain brick index of box id + 1 -- without vacuum every voxel of
+// a certain brick belongs to the region's maximum and the smallest voxel index of a brick is its corner, so the
+// numbering needs one note per region, not one per brick.
 __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restrict__ seed, const int *__restrict__ buf0,
-                                                     const int *__restrict__ buf1, int *fs, int *__restrict__ blab) {
+                                                     const int *__restrict__ buf1, int *fs, int *__restrict__ blab,
+                                                     int *box_first) {
+    __shared__ int s_first[64];
     const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
     const int nbx = fs[FS_N_BOXES];
+    if (threadIdx.x < 64) s_first[threadIdx.x] = XB_INT_MAX;
+    __syncthreads();
     int cnt = 0;
     for (int b = blockIdx.x * TPB + threadIdx.x; b < nbr; b += gridDim.x * TPB) {
         const int l = nbx ? src[b] : 0;
         blab[b] = l;
         cnt += (l > 0);
+        if (l > 0 && l <= 64 && s_first[l - 1] > b) atomicMin(&s_first[l - 1], b);
     }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_first[threadIdx.x] != XB_INT_MAX) atomicMin(&box_first[threadIdx.x], s_first[threadIdx.x]);
     int total;
     block_scan_excl(cnt, total);
     if (threadIdx.x == 0 && total) atomicAdd(&fs[FS_N_CERTAIN], total);
+}
+// one note per region (replaces a note per certain brick)
+__global__ __launch_bounds__(64) void k_note_regions(GridL g, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ box_first,
+                                                     const int *__restrict__ box_max, int *first, int *max_list, int *max_count,
+                                                     int max_cap) {
+    const int t = threadIdx.x;
+    if (t >= fs[FS_N_BOXES] || box_first[t] == XB_INT_MAX) return;
+    const int b = box_first[t];
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    note_maximum(box_max[t], ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list, max_count, max_cap);
 }
 __global__ void k_brick_seed_dev(GridL g, int nb0, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ mxyz,
                                  const int *__restrict__ radius, int *blab, int *blab2) {
@@ -248,12 +270,14 @@ __global__ __launch_bounds__(1024) void k_number_maxima(int *fs, int *first, con
     const int n = fs[FS_N_MAX];
     // trajectories waiting for the exact slow kernel may still discover maxima: number on the host afterwards
     if (n > XB_SORT_MAX || n > max_cap || fs[FS_N_OVF] > 0) { if (threadIdx.x == 0) fs[FS_SORT_OK] = 0; return; }
-    for (int i = threadIdx.x; i < XB_SORT_MAX; i += 1024)
+    int len = 64;   // sort the next power of two >= n (a handful of maxima is the common case)
+    while (len < n) len <<= 1;
+    for (int i = threadIdx.x; i < len; i += 1024)
         key[i] = i < n ? ((unsigned long long)(unsigned)first[max_list[i]] << 32) | (unsigned)max_list[i] : ~0ull;
     __syncthreads();
-    for (int k = 2; k <= XB_SORT_MAX; k <<= 1)
+    for (int k = 2; k <= len; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < XB_SORT_MAX; i += 1024) {
+            for (int i = threadIdx.x; i < len; i += 1024) {
                 const int p = i ^ j;
                 if (p > i) {
                     const unsigned long long a = key[i], b = key[p];

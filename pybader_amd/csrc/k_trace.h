@@ -87,6 +87,62 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions4(GridL g, int *labels, 
         *p = m;
     }
 }
+// The same with a 3-D launch (x = blockIdx.z, 4 y-rows per block, threads along z/4): no divisions, 32-bit index math
+__global__ __launch_bounds__(TPB) void k_relabel_regions4_3d(GridL g, int *labels, const int *__restrict__ rank,
+                                                             const int *__restrict__ blab, int nb1, int nb2,
+                                                             const int *__restrict__ box_max, const int *gate) {
+    if (gate && !*gate) return;
+    const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), x = blockIdx.z;
+    if (z >= g.nz || y >= g.ny) return;
+    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
+    int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + y) * g.nz + z));
+    if (b > 0) {
+        const int l = rank[box_max[b - 1]];
+        *p = make_int4(l, l, l, l);
+    } else {
+        int4 m = *p;
+        if (m.x >= 0) m.x = rank[m.x];
+        if (m.y >= 0) m.y = rank[m.y];
+        if (m.z >= 0) m.z = rank[m.z];
+        if (m.w >= 0) m.w = rank[m.w];
+        *p = m;
+    }
+}
+// Brick-shaped version: a thread owns the 8 y-rows of one brick at one (x, z/4): ONE brick-label lookup (through a
+// per-block LDS table of the <= 64 region ranks) for 8 16-byte stores; a block covers 4 x-planes x 256 voxels of z.
+__global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *labels, const int *__restrict__ rank,
+                                                               const int *__restrict__ blab, int nb1, int nb2,
+                                                               const int *__restrict__ box_max, const int *__restrict__ fs,
+                                                               const int *gate) {
+    __shared__ int s_rank[64];
+    if (gate && !*gate) return;
+    if (threadIdx.x < 64) s_rank[threadIdx.x] = threadIdx.x < fs[FS_N_BOXES] ? rank[box_max[threadIdx.x]] : 0;
+    __syncthreads();
+    const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = blockIdx.z * 4 + (threadIdx.x >> 6);
+    if (z >= g.nz || x >= g.nx) return;
+    const int b = blab[((x >> 3) * nb1 + by) * nb2 + (z >> 3)];
+    int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + by * 8) * g.nz + z));
+    const int stride = g.nz >> 2;   // int4 per row
+    if (b > 0) {
+        const int l = s_rank[b - 1];
+        const int4 v = make_int4(l, l, l, l);
+#pragma unroll
+        for (int r = 0; r < 8; r++) p[r * stride] = v;
+    } else {
+        int4 m[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) m[r] = p[r * stride];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (m[r].x >= 0) m[r].x = rank[m[r].x];
+            if (m[r].y >= 0) m[r].y = rank[m[r].y];
+            if (m[r].z >= 0) m[r].z = rank[m[r].z];
+            if (m[r].w >= 0) m[r].w = rank[m[r].w];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) p[r * stride] = m[r];
+    }
+}
 // 16 bricks per thread, one atomic per block; the list keeps brick order inside a block's range
 __global__ __launch_bounds__(TPB) void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab,
                                                          int *walk, int *n_walk) {
@@ -106,6 +162,41 @@ __global__ __launch_bounds__(TPB) void k_brick_walk_list(int nbr, int b_lo, int 
 #pragma unroll
     for (int k = 0; k < 16; k++)
         if ((hits >> k) & 1u) walk[w++] = base + k;
+}
+
+// The same list in MORTON order of the brick coordinates (single GPU): the waves of the persistent trace work on
+// consecutive list entries at the same time, and a Z-order run of bricks is a compact 3-D neighbourhood -- its
+// trajectories share table lines in the XCD's L2 -- where a run in linear order is a thin row of bricks.
+__device__ __forceinline__ int compact3(unsigned x) {   // every third bit of x, packed
+    x &= 0x09249249u;
+    x = (x ^ (x >> 2)) & 0x030c30c3u;
+    x = (x ^ (x >> 4)) & 0x0300f00fu;
+    x = (x ^ (x >> 8)) & 0xff0000ffu;
+    x = (x ^ (x >> 16)) & 0x000003ffu;
+    return (int)x;
+}
+__global__ __launch_bounds__(TPB) void k_brick_walk_list_morton(int nb0, int nb1, int nb2, unsigned n_codes,
+                                                                const int *__restrict__ blab, int *walk, int *n_walk) {
+    const unsigned base = (blockIdx.x * TPB + threadIdx.x) * 16u;   // 16 consecutive Morton codes per thread
+    unsigned int hits = 0;
+    int bidx[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const unsigned code = base + k;
+        const int b2 = compact3(code), b1 = compact3(code >> 1), b0 = compact3(code >> 2);
+        const bool in = code < n_codes && b0 < nb0 && b1 < nb1 && b2 < nb2;
+        bidx[k] = in ? (b0 * nb1 + b1) * nb2 + b2 : 0;
+        if (in && blab[bidx[k]] <= 0) hits |= 1u << k;
+    }
+    int total;
+    const int off = block_scan_excl(__popc(hits), total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(n_walk, total) : 0;
+    __syncthreads();
+    int w = base_s + off;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if ((hits >> k) & 1u) walk[w++] = bidx[k];
 }
 
 __device__ __forceinline__ void og_offsets(int og, int &ox, int &oy, int &oz) {
