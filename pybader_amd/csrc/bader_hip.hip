@@ -284,10 +284,12 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     }
     Grid &g = c->g;
     if (g.nx != (int)shape[0] || g.ny != (int)shape[1] || g.nz != (int)shape[2]) c->grad_valid = false;
+    if (dist_mat && !T_grad) return fail(XB_E_ARG, "xb_set_grid: dist_mat without T_grad");
     g.nx = (int)shape[0]; g.ny = (int)shape[1]; g.nz = (int)shape[2];
     g.nyz = g.ny * g.nz;
     g.x0 = (int)x0; g.x1 = (int)x1;
     if (dist_mat) {
+        if (memcmp(g.dist, dist_mat, sizeof g.dist) != 0) c->grad_valid = false;   // the tabulated ongrid successors depend on it
         memcpy(g.dist, dist_mat, sizeof g.dist);
         HIPCHK(hipMemcpyAsync(c->dist_dev, dist_mat, sizeof g.dist, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->dist_dev + 27, T_grad, sizeof g.T, hipMemcpyHostToDevice, c->stream));
