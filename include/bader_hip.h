@@ -23,7 +23,8 @@ extern "C" {
 
 typedef struct xb_ctx xb_ctx;
 
-enum { XB_OK = 0, XB_E_ARG = -1, XB_E_HIP = -2, XB_E_STATE = -3, XB_E_LIMIT = -4, XB_E_COMM = -5 };
+enum { XB_OK = 0, XB_E_ARG = -1, XB_E_HIP = -2, XB_E_STATE = -3, XB_E_LIMIT = -4, XB_E_COMM = -5,
+       XB_E_SHORT = -6 /* xb_parse_density_text: fewer numbers in the text than voxels in the grid */ };
 
 /* label dtype codes accepted at the boundary: the reference narrows/widens labels between
  * int8/16/32/64 (utils.py:15-37 dtype_calc, jits.py:22-38 dtype matrix) */

@@ -76,7 +76,11 @@ _lib = None
 
 
 class BaderHipError(RuntimeError):
-    pass
+    """carries the library's XB_E_* code in `.code` (None for host-side failures)"""
+    code = None
+
+
+XB_E_SHORT = -6   # xb_parse_density_text: the text holds fewer numbers than the grid has voxels
 
 
 def load():
@@ -97,7 +101,9 @@ def load():
 
 def check(rc):
     if rc != 0:
-        raise BaderHipError(f"libbader_hip error {rc}: {load().xb_last_error().decode()}")
+        err = BaderHipError(f"libbader_hip error {rc}: {load().xb_last_error().decode()}")
+        err.code = rc
+        raise err
 
 
 def _ptr(a):
@@ -120,6 +126,9 @@ class Context:
         check(self.lib.xb_create(int(device), C.byref(h)))
         self.h = h
         self.shape = None
+        # utils.resident(): identity of the host array the caller pinned / of the one whose content is on the device
+        self.pinned_density = None
+        self.resident_density = None
         self.n_maxima = 0
 
     def close(self):
@@ -150,10 +159,12 @@ class Context:
     def upload_density(self, rho):
         rho = _f64(rho)
         assert rho.shape == self.shape, (rho.shape, self.shape)
+        self.resident_density = None
         check(self.lib.xb_upload_density(self.h, _ptr(rho)))
 
     def synth_density(self, lattice, atoms, background):
         lat, at = _f64(lattice).reshape(9), _f64(atoms)
+        self.resident_density = None
         check(self.lib.xb_synth_density(self.h, lat.ctypes.data_as(_pdbl), at.ctypes.data_as(_pdbl),
                                         at.shape[0], float(background)))
 
@@ -237,6 +248,7 @@ class Context:
         buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else text
         assert buf.dtype == np.uint8 and buf.flags.c_contiguous
         a, b = C.c_int64(), C.c_int64()
+        self.resident_density = None            # also when the parse fails midway: rho is partly rewritten
         check(self.lib.xb_parse_density_text(self.h, _ptr(buf), buf.size, float(divisor), C.byref(a), C.byref(b)))
         return a.value, b.value
 

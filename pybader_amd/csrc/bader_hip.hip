@@ -404,7 +404,7 @@ int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double di
     if (e == hipSuccess && rc == XB_OK) e = hipStreamSynchronize(c->stream);
     const long long tokens = (long long)last_off + last_count;
     if (e == hipSuccess && rc == XB_OK && tokens < c->N)
-        rc = fail(XB_E_ARG, "xb_parse_density_text: %lld numbers in the text, the grid has %lld voxels", tokens, (long long)c->N);
+        rc = fail(XB_E_SHORT, "xb_parse_density_text: %lld numbers in the text, the grid has %lld voxels", tokens, (long long)c->N);
     if (e == hipSuccess && rc == XB_OK) {
         k_text_parse<<<nblk, TPB, 0, c->stream>>>(dtext, nbytes, counts, dp10, divisor, g.nx, g.ny, g.nz, c->rho, dtodo,
                                                  c->counters + 6, todo_cap);
@@ -480,7 +480,13 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
         else k_widen<long long><<<nblocks(c->N), TPB, 0, c->stream>>>((const long long *)c->stage, c->labels, c->N);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // vacuum voxels present?  (the reference's callers hand bader_calc the volumes_init map: -1 only with a vacuum_tol)
+    HIPCHK(hipMemsetAsync(c->counters + 14, 0, sizeof(int), c->stream));
+    k_any_equal<<<2048, TPB, 0, c->stream>>>(c->labels, c->N, -1, c->counters + 14);
+    HIPCHK(hipGetLastError());
+    int any = 0;
+    if (int rc = read_counter(c, 14, &any)) return rc;
+    c->has_vacuum = any != 0;
     return XB_OK;
 }
 int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {

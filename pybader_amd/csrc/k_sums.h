@@ -107,6 +107,12 @@ __global__ void k_widen(const T *__restrict__ in, int *__restrict__ out, long lo
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)in[i];
 }
+// does any label equal `value`?  (xb_upload_labels: "no vacuum voxel" unlocks the region fast paths)
+__global__ __launch_bounds__(TPB) void k_any_equal(const int *__restrict__ a, long long n, int value, int *flag) {
+    bool hit = false;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) hit |= (a[i] == value);
+    if (__any(hit) && threadIdx.x % XB_WAVE == 0) *flag = 1;
+}
 template <typename T>
 __global__ void k_narrow(const int *__restrict__ in, T *__restrict__ out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

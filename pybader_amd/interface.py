@@ -9,7 +9,7 @@ bit-identical)."""
 import numpy as np
 
 from .thread_handlers import assign_to_atoms, bader_calc, dtype_calc, refine, surface_distance
-from .utils import charge_sum, vacuum_assign
+from .utils import charge_sum, resident, vacuum_assign
 
 
 def distance_matrix(voxel_lattice):
@@ -179,6 +179,14 @@ class Bader:
         with the reference class (out of the hot path)."""
         for k, v in kwargs.items():
             setattr(self, k, v)
+        ref = self.reference
+        if isinstance(ref, np.ndarray) and ref.dtype == np.float64 and ref.flags.c_contiguous:
+            with resident(ref):          # held still (and read-only) for the run: uploaded once, not per call
+                self._run()
+        else:
+            self._run()
+
+    def _run(self):
         self.volumes_init()
         self.bader_calc()
         if not self.speed_flag:

@@ -42,7 +42,12 @@ def _block_bytes(mm, start, n_values):
     first, nxt = _line(mm, start)
     per_line = max(1, len(first.split()))
     width = max(1, nxt - start)
-    return min(len(mm) - start, (n_values // per_line + 3) * width)
+    end = min(len(mm), start + (n_values // per_line + 3) * width)
+    # never cut a number in two: with lines of uneven width the estimate may end inside the last token it needs,
+    # and the token count would still come out right -- end the slice on white space (or the end of the file)
+    while end < len(mm) and mm[end] not in b' \t\r\n\x0b\x0c':
+        end += 1
+    return end - start
 
 
 def read(fn, charge_flag=True, spin_flag=False, buffer_size=64, ctx=None):
@@ -114,7 +119,9 @@ def read(fn, charge_flag=True, spin_flag=False, buffer_size=64, ctx=None):
                 start, nbytes = blocks[key]
                 try:
                     ctx.parse_density_text(view[start:start + nbytes], lattice_vol)
-                except _lib.BaderHipError:
+                except _lib.BaderHipError as err:
+                    if err.code != _lib.XB_E_SHORT:                         # OOM, a malformed token, ...: not a sizing problem
+                        raise
                     ctx.parse_density_text(view[start:], lattice_vol)      # odd line widths: take the rest of the file
                 density[key] = ctx.download_density()
             if 'charge' in density:

@@ -6,9 +6,6 @@ import numpy as np
 
 from . import _lib
 
-_fingerprints = {}
-
-
 def dtype_calc(max_val):
     """utils.dtype_calc (utils.py:15-37): smallest dtype holding max_val; a negative argument asks
     for a signed type able to hold 2*|max_val|."""
@@ -19,30 +16,63 @@ def dtype_calc(max_val):
     return ('int8', 'int16', 'int32', 'int64')[width] if signed else ('uint8', 'uint16', 'uint32', 'uint64')[width]
 
 
-def _fingerprint(a):
-    flat = a.reshape(-1)
-    step = max(1, flat.shape[0] // 65536)
-    s = flat[::step]
-    return (a.ctypes.data, a.shape, a.strides, float(s.sum()), float(flat[0]), float(flat[-1]))
+# ---- which host array is resident on the device -------------------------------------------------------------
+# The reference passes the same `density` ndarray to bader_calc, refine and charge_sum.  By default every call
+# uploads it again (about 0.1 s per GiB): nothing is assumed about the content of a host array.  A caller who
+# holds the array still for a while says so with `resident(density)`: inside that block the array is uploaded
+# once, is read-only (an in-place edit raises instead of being missed) and is recognised by identity (address,
+# shape, strides).  The token lives in the Context, and every route that rewrites the device density (upload,
+# CHGCAR text parse -- also a failed one --, synthetic generator) clears it.
+def _identity(a):
+    return (a.ctypes.data, a.shape, a.strides)
+
+
+class resident:
+    """with resident(density): ... -- a promise not to modify `density` inside the block; uploaded at most once."""
+
+    def __init__(self, density, ctx=None):
+        self.array = density
+        self.ctx = ctx
+
+    def __enter__(self):
+        a = self.array
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+            raise ValueError('resident(): a C-contiguous float64 ndarray is required')
+        self.ctx = self.ctx or _lib.default_context()
+        self._was_writeable = bool(a.flags.writeable)
+        a.flags.writeable = False
+        self.ctx.pinned_density = _identity(a)
+        return a
+
+    def __exit__(self, *exc):
+        self.ctx.pinned_density = None
+        self.ctx.resident_density = None
+        if self._was_writeable:
+            self.array.flags.writeable = True
+        return False
 
 
 def ensure_density(ctx, density):
-    """Upload `density` unless this very array (same memory, same sampled content) is resident."""
+    """Make `density` the device density: uploads, unless the caller pinned this very array with `resident()` and
+    it is the one on the device."""
     density = np.ascontiguousarray(density, dtype=np.float64)
-    fp = _fingerprint(density)
-    if _fingerprints.get(id(ctx)) != fp:
-        ctx.upload_density(density)
-        _fingerprints[id(ctx)] = fp
+    ident = _identity(density)
+    if ctx.pinned_density is not None and ctx.pinned_density == ident and ctx.resident_density == ident:
+        return density
+    ctx.upload_density(density)                 # clears ctx.resident_density
+    if ctx.pinned_density == ident:
+        ctx.resident_density = ident
     return density
 
 
 def remember_density(ctx, density):
-    """Declare `density` (a host array just downloaded from the context) as the resident one."""
-    _fingerprints[id(ctx)] = _fingerprint(np.ascontiguousarray(density, dtype=np.float64))
+    """`density` (a pinned host array) was just downloaded from the context: it is the resident one."""
+    if ctx.pinned_density is not None and ctx.pinned_density == _identity(density):
+        ctx.resident_density = _identity(density)
 
 
 def forget_density(ctx):
-    _fingerprints.pop(id(ctx), None)
+    ctx.resident_density = None
 
 
 def vacuum_assign(reference, volumes, vac_tol, density, voxel_volume):
