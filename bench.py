@@ -54,6 +54,28 @@ def cpu_baseline(size, method, mode, iters, lattice, atoms, background):
             'assign_mvox_s': n / (t1 - t0) / 1e6}, (rho, dm, tg, main, bmax)
 
 
+def traffic_from_profile(kernel, method):
+    """(bytes per launch, 'file sha256[:16]') of `kernel` from the newest committed PMC summary of this command, or
+    (None, None).  Lines look like `FETCH_SIZE  k_name<...>   launches=  1 KB=  1315370`."""
+    import glob
+    import hashlib
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_fetch_write_512_{method}.txt')),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(f))])
+    for path in reversed(files):
+        kb, launches = 0.0, 0
+        with open(path) as f:
+            text = f.read()
+        for line in text.splitlines():
+            m = re.match(r'(FETCH_SIZE|WRITE_SIZE)\s+(\S+).*launches=\s*(\d+)\s+KB=\s*(\d+)', line)
+            if m and m.group(2).split('<')[0] == kernel:
+                kb += float(m.group(4))
+                launches = max(launches, int(m.group(3)))
+        if launches:
+            return kb * 1024.0 / launches, f'{os.path.relpath(path, ROOT)} sha256:{hashlib.sha256(text.encode()).hexdigest()[:16]}'
+    return None, None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N rank processes of this script (fresh interpreters
     that have not touched the GPU; this parent never does), wait, relay rank 0's output.  Returns the exit code."""
@@ -158,7 +180,7 @@ def main():
         ctx.set_option(3, int(os.environ['XB_OPT_DBG']))
     if 'XB_OPT_TPB' in os.environ:
         ctx.set_option(2, int(os.environ['XB_OPT_TPB']))
-    for key in (7, 8, 9, 10, 11):
+    for key in (7, 8, 9, 10, 11, 12):
         if f'XB_OPT_{key}' in os.environ:
             ctx.set_option(key, int(os.environ[f'XB_OPT_{key}']))
     if 'XB_OPT_EC_GROUPS' in os.environ:
@@ -194,23 +216,23 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     # HIP-event timings on the library's own stream (xb_kernel_time)
     tm = {name: ctx.kernel_time(i) for i, name in enumerate(
-        ['assign_after_table(fill+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
-         'table_build(k_grad_field+trapping_regions)', 'k_grad_field', 'k_ng_trace'])}
+        ['assign_after_masks(walk_list+k_brick_records+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
+         'masks+trapping_regions', 'k_brick_masks', 'k_ng_trace_p', 'k_brick_records'])}
     avg = {k: (ms / n if n else 0.0) for k, (ms, n) in tm.items()}
     # the dominant single kernel of the path (HIP events around that launch alone)
     if args.method == 'neargrid':
-        dom = 'k_grad_field' if avg['k_grad_field'] >= avg['k_ng_trace'] else 'k_ng_trace'
+        dom = 'k_brick_masks' if avg['k_brick_masks'] >= avg['k_ng_trace_p'] else 'k_ng_trace_p'
         k_avg, k_n = avg[dom], tm[dom][1]
         own_frac = (runner.x_range[1] - runner.x_range[0]) / shape[0]
         units = nvox * own_frac   # voxels this rank labels (its k_grad_field also covers the window margin)
     else:
         dom, k_avg, k_n, units = 'k_og_pointer', avg['k_og_pointer'], tm['k_og_pointer'][1], nvox
     achieved = BYTES_ASSIGN * units / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (same command, 512^3):
-    # profiles/r1_final_pmc_fetch_write_512_neargrid.txt -- FETCH_SIZE + WRITE_SIZE as reported (KB)
-    traffic = None
-    if args.size == 512 and args.method == 'neargrid' and world == 1:
-        traffic = {'k_grad_field': (1314801 + 4196362) * 1024.0, 'k_ng_trace': (4146778 + 213734) * 1024.0}[dom]
+    # HBM bytes per launch of the dominant kernel: read at run time from the committed summary of the rocprofv3
+    # --pmc passes of this very command (tools/profile_round.sh + tools/pmc_summary.py), named with its hash
+    traffic, traffic_src = None, None
+    if args.size == 512 and world == 1:
+        traffic, traffic_src = traffic_from_profile(dom, args.method)
 
     out = {
         'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',
@@ -235,12 +257,9 @@ def main():
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_note': 'bytes/launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from the committed rocprofv3 --pmc passes '
-                                     '(profiles/r1_final_pmc_fetch_write_512_neargrid.txt).  k_grad_field: WRITE_SIZE equals the '
-                                     '32 B/voxel table exactly; its reads are 8 B/lane row loads (1.78 GB requested, 1.07 GB '
-                                     'unique) and FETCH_SIZE reports 1.32 GB, so the gfx950 x2 rule for 16 B/lane streams does '
-                                     'not apply (it would exceed the bytes requested).  k_ng_trace: scattered 32-B gathers, '
-                                     'uncalibrated',
+                     'traffic_note': 'bytes/launch = (FETCH_SIZE + WRITE_SIZE) x 1024 of that kernel in ' + str(traffic_src) +
+                                     ' (separate rocprofv3 --pmc passes of this command; 8 B/lane row loads and 32 B record '
+                                     'stores, so the gfx950 x2 rule for 16 B/lane streams does not apply)',
                      'algorithmic_bytes_per_voxel': BYTES_ASSIGN, 'kernel_ms_avg': k_avg, 'launches': int(k_n),
                      'whole_path': {'bytes_per_voxel': BYTES_PATH,
                                     'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
@@ -249,6 +268,7 @@ def main():
     }
 
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
+    out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
     out['config']['refine_escape_fallbacks'] = runner.n_fallbacks
     if runner.timing is not None:   # XB_SLAB_TIMING=1: wall-clock per scheduler phase (adds a device sync around each)
         out['config']['slab_phase_ms_avg'] = {k: v / args.steps * 1e3 for k, v in runner.timing.items()}

@@ -185,6 +185,9 @@ int xb_set_option(xb_ctx *c, int key, int value);
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);
 /* trajectories / retraces handed to the exact slow kernel since the context was created */
 int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total);
+/* retraces redone by the from-rho kernel since the context was created (their walk went on through a brick whose
+ * records the sparse table does not hold) */
+int xb_deferred_stats(xb_ctx *c, int64_t *refine_total);
 
 #ifdef __cplusplus
 }

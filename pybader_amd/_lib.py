@@ -70,6 +70,7 @@ SYMBOLS = {
     'xb_set_option': (_int, [_vp, _int, _int]),
     'xb_box_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_slow_path_stats': (_int, [_vp, _pi64, _pi64]),
+    'xb_deferred_stats': (_int, [_vp, _pi64]),
 }
 
 _lib = None
@@ -363,6 +364,11 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_slow_path_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def deferred_stats(self):
+        a = C.c_int64()
+        check(self.lib.xb_deferred_stats(self.h, C.byref(a)))
+        return a.value
 
     def sync(self):
         check(self.lib.xb_sync(self.h))

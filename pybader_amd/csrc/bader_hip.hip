@@ -16,6 +16,7 @@
 // =============================================================================================
 #include "k_common.h"
 #include "k_table.h"
+#include "k_masks.h"
 #include "k_fused.h"
 #include "k_trace.h"
 #include "k_ongrid.h"
@@ -72,17 +73,23 @@ struct xb_ctx {
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
+    bool regions_labels = false;   // the resident labels are the last neargrid assignment's (+ refinement): every voxel of a
+                                   // trapping-region brick (blab > 0) still carries the region's label
     int n_walk = 0;                // bricks on the walk list of the last assignment
     int *walk = nullptr;           // ... and where that list lives (inside `list`)
     int table_margin = -1;         // planes of table each side of the slab (slabs); -1: whole grid
     bool table_prebuilt = false;   // xb_table_finish done: the next xb_assign_trace must not rebuild
     int table_stage = 0;           // windowed build: 1 = records + masks done, 2 = trapping regions done
     std::vector<int> window_seeds; // maxima found in the owned planes (windowed build)
+    long long stat_deferred = 0;   // retraces redone by the from-rho kernel (sparse table)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
     int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
     bool grad_valid = false;
+    int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
+    unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
+    int opt_sparse = 1;        // single-GPU neargrid assignment: brick masks for every voxel + records for the walk-list bricks only
     int grad_rule = 0;         // which tie rule the resident table obeys: 0 refinement.py:111, 1 methods.py:324, 2 both
                                // (the density has no voxel where they differ)
     int *labels = nullptr;
@@ -217,6 +224,7 @@ static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
     hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->labels_zero_pending = false;
+    c->brick_rec = nullptr; c->grad_cover = 0;
     c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
@@ -468,7 +476,7 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     c->labels_zero_pending = false;   // every label is overwritten
     c->list_valid = false;
     c->has_vacuum = true;
-    c->buni_valid = false;
+    c->buni_valid = false; c->regions_labels = false;
     const size_t sz = dtype_size(dtype);
     if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
     if (dtype == XB_I32) {
@@ -521,7 +529,7 @@ int xb_download_known(xb_ctx *c, int8_t *known_host) {
 
 int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume) {
     NEED_GRID_RAW("xb_vacuum_assign");
-    c->buni_valid = false;
+    c->buni_valid = false; c->regions_labels = false;
     c->labels_zero_pending = false;
     if (vac_tol != vac_tol) {
         // vacuum_tol=None reaches the reference's sweep as NaN (interface.py:459): `rho <= NaN` is never
@@ -568,6 +576,21 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
     c->g.main_ties = main_rule ? 1 : 0;   // the trace / slow kernels of this phase follow the same rule
     if (c->grad_valid && !force && (c->grad_rule == 2 || c->grad_rule == (main_rule ? 1 : 0))) return XB_OK;
     const Grid &g = c->g;
+    if (c->grad_valid && !force && !boxes && c->grad_cover == 1 && c->brick_rec) {
+        // records exist for the flagged bricks only, under the other tie rule: redo exactly those
+        const int nbr = (g.nx / BRK) * (g.ny / BRK) * (g.nz / BRK);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        ScopedTimer t(c, 4);
+        GridS gs;
+        if (sym_grid(g, gs))
+            k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, nullptr, nullptr, nbr, g.ny / BRK, g.nz / BRK, c->brick_rec, small);
+        else
+            k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, nullptr, nullptr, nbr, g.ny / BRK, g.nz / BRK, c->brick_rec, small);
+        HIPCHK(hipGetLastError());
+        c->grad_rule = main_rule ? 1 : 0;
+        return XB_OK;
+    }
+    c->grad_cover = 0;
     ScopedTimer t(c, 4);
     HIPCHK(hipMemsetAsync(c->counters + 9, 0, 2 * sizeof(int), c->stream));
     // brick growth needs a grid made of whole 8^3 bricks; its scratch is carved from `list`
@@ -969,7 +992,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
         k_set_rank<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
         HIPCHK(hipGetLastError());
     }
-    c->buni_valid = false;
+    c->buni_valid = false; c->regions_labels = false;
     if (c->regions_pending && c->blab) {
         if (g.nz % 4 == 0)
             k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
@@ -1017,9 +1040,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     const GridL gl0 = light(g);
     const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
     if (c->blab_alloc < nbr) {
-        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0;
-        HIPCHK(hipMalloc(&c->blab_buf, (size_t)nbr * sizeof(int)));
+        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->brick_rec = nullptr;
+        if (c->grad_cover) { c->grad_cover = 0; c->grad_valid = false; }
+        HIPCHK(hipMalloc(&c->blab_buf, (size_t)nbr * sizeof(int) + (size_t)nbr + 16));
         c->blab_alloc = nbr;
+        c->brick_rec = reinterpret_cast<unsigned char *>(c->blab_buf + nbr);
     }
     int *fs = c->fs;
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
@@ -1035,19 +1060,24 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     }
     c->first_clean = false;
     c->regions_pending = false;
-    c->buni_valid = false;
+    c->buni_valid = false; c->regions_labels = false;
     c->list_valid = false;
     g.main_ties = 1;   // methods.neargrid's tie test (methods.py:324)
     const GridL gl = light(g);
     (void)gl0;
-    {   // table + brick masks + seeds
+    const bool sparse = c->opt_sparse != 0;
+    {   // brick masks + seeds (+ the full table on the round-1 route, opt_sparse = 0)
         ScopedTimer t4(c, 4);
         {
             ScopedTimer t5(c, 5);
             const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
             dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
             GridS gs;
-            if (sym_grid(g, gs))
+            const bool sym = sym_grid(g, gs);
+            if (sparse) {
+                if (sym) k_brick_masks<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
+                else k_brick_masks<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
+            } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);
             else
@@ -1056,10 +1086,14 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         }
         c->grad_valid = true;
         c->grad_rule = 1;
+        c->grad_cover = sparse ? 1 : 0;
         // closed seed cubes around the maxima, then brick growth -- all decided on the device
         k_box_setup<<<1, 64, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
         const long long wmax = 2LL * XB_BOX_K + 1;
-        k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
+        if (sparse)   // no record exists yet: the shells derive their move intervals from rho
+            k_box_shells_dev<true><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
+        else
+            k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
         k_box_pick<<<1, 64, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
         k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
         const int launches = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
@@ -1067,7 +1101,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG);
         k_fill<int><<<1, 64, 0, c->stream>>>(box_first, XB_INT_MAX, 64);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr);
         HIPCHK(hipGetLastError());
     }
     c->blab = c->blab_buf;
@@ -1084,6 +1118,15 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                                                                                                   fs + FS_N_WALK);
         } else
             k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK);
+        if (sparse) {   // pass B: records for the bricks of the walk list only
+            ScopedTimer t7(c, 7);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            GridS gs;
+            if (sym_grid(g, gs))
+                k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, walk, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
+            else
+                k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, walk, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
+        }
         if (c->has_vacuum)
             k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
                                                                 fs + FS_N_MAX, c->max_cap);
@@ -1134,6 +1177,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
         c->regions_pending = false;
         c->buni_valid = !c->has_vacuum;   // k_buni_from_regions + k_label_uniform_list ran
+        c->regions_labels = !c->has_vacuum;
         c->first_clean = true;
         if (n_maxima) *n_maxima = nmax;
         return XB_OK;
@@ -1238,7 +1282,8 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
         }
         dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
         k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
-                                                       c->counters + 5, small, buni, c->grad_valid ? c->grad : nullptr);
+                                                       c->counters + 5, small, buni, c->grad_valid ? c->grad : nullptr,
+                                                       c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr, c->has_vacuum ? 0 : 1);
         if (!whole)
             k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
     }
@@ -1356,7 +1401,7 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         if (e == hipSuccess) e = hipMemcpyAsync(dkn, kn, n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) k_scatter_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, dlab, dkn, c->labels, c->known);
         c->list_valid = false;
-        c->buni_valid = false;
+        c->buni_valid = false; c->regions_labels = false;
     } else {
         if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
         if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -1391,9 +1436,16 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
         if (int rc = ensure_grad(c, false, false, false)) return rc;
         {
             ScopedTimer t(c, 3);
-            (table_windowed(c) ? k_refine_trace<2, true> : k_refine_trace<2, false>)<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
-                                                                c->counters + 2, c->counters + 3, c->ovf_list,
-                                                                c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev);
+            const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
+            if (table_windowed(c) || brec)   // slabs / sparse table off the fused path: the kernel with the from-rho fallback
+                k_refine_trace<2, true><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
+                                                                           c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                           c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0);
+            else
+                k_refine_trace<2, false><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
+                                                                            c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                            c->ovf_cap, maxsteps, c->rho, c->dist_dev, nullptr, (int *)c->stage,
+                                                                            c->counters + 15, 0);
         }
         HIPCHK(hipGetLastError());
         int novf = 0;
@@ -1495,7 +1547,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
     int *fs = c->fs;
     c->g.main_ties = 0;
     const GridL gl = light(g);
-    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 4 * sizeof(int), c->stream));   // edges, changed, escaped, overflows
+    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 5 * sizeof(int), c->stream));   // edges, changed, escaped, overflows, deferred
     {
         ScopedTimer t(c, 2);
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
@@ -1510,7 +1562,8 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         }
         dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (g.nx + ET_X - 1) / ET_X);
         k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, 0, g.nx, c->list, fs + FS_N_EDGES, small, buni,
-                                                       c->grad_valid ? c->grad : nullptr);
+                                                       c->grad_valid ? c->grad : nullptr, c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr,
+                                                       c->has_vacuum ? 0 : 1);
         k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
     }
     c->list_valid = false;
@@ -1520,14 +1573,21 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
         k_refine_trace<2, false><<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, fs + FS_N_EDGES,
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
-                                                              c->ovf_cap, maxsteps, c->rho, c->dist_dev);
+                                                              c->ovf_cap, maxsteps, c->rho, c->dist_dev,
+                                                              c->grad_cover == 1 ? c->brick_rec : nullptr, (int *)c->stage, fs + FS_R_DEFER,
+                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0);
+        if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
+            k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
+                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
+                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *edges = c->host_ints[0];
     *changed = c->host_ints[1];
     const int novf = c->host_ints[3];
+    c->stat_deferred += c->host_ints[4];
     if (c->host_ints[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", c->host_ints[2]);
     if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
     c->stat_ovf_refine += novf;
@@ -1623,7 +1683,7 @@ int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *char
 
 int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap) {
     NEED_GRID("xb_volume_assign");
-    c->buni_valid = false;
+    c->buni_valid = false; c->regions_labels = false;
     if (n_swap <= 0) return XB_OK;
     if (n_swap > c->max_cap) return fail(XB_E_LIMIT, "xb_volume_assign: swap table too long");
     std::vector<int> s(n_swap);
@@ -1785,7 +1845,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     const size_t es = which == 0 ? 4 : 1;
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
-    if (to_device) { c->list_valid = false; c->has_vacuum = true; c->buni_valid = false; }
+    if (to_device) { c->list_valid = false; c->has_vacuum = true; c->buni_valid = false; c->regions_labels = false; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1806,7 +1866,13 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 9 && value >= 1 && value <= 4096) c->opt_trace_chunk = value;
     else if (key == 10) c->opt_trace_xcd = value != 0;
     else if (key == 11) c->opt_morton = value != 0;
+    else if (key == 12) c->opt_sparse = value != 0;   // 0: the round-1 route (a 32-byte record for every voxel)
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
+    return XB_OK;
+}
+int xb_deferred_stats(xb_ctx *c, int64_t *refine_total) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    if (refine_total) *refine_total = c->stat_deferred;
     return XB_OK;
 }
 int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total) {

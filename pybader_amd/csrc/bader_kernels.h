@@ -153,6 +153,11 @@ __device__ __forceinline__ GradRec fetch_rec(const GradRec *__restrict__ G, int 
 __device__ __forceinline__ double pack_key(double rho, int code, int og) {
     return __longlong_as_double((__double_as_longlong(rho) & ~0x1FFFFFLL) | (long long)(code | (og << 6)));
 }
+// the largest value with all-equal record bits that is <= every key pack_key can make of `rho` (round down on those bits)
+__device__ __forceinline__ double key_floor(double rho) {
+    const long long b = __double_as_longlong(rho);
+    return __longlong_as_double(b >= 0 ? (b & ~0x1FFFFFLL) : (b | 0x1FFFFFLL));
+}
 __device__ __forceinline__ int key_bits(double key) { return (int)(__double_as_longlong(key) & 0x1FFFFFLL); }
 __device__ __forceinline__ int key_code(double key) { return key_bits(key) & 63; }
 __device__ __forceinline__ int key_og(double key) { return (key_bits(key) >> 6) & 31; }

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
                                                          int8_t *__restrict__ known, int xa, int nplanes,
                                                          int *__restrict__ list, int *list_count, int small,
                                                          const int *__restrict__ buni,
-                                                         const GradRec *__restrict__ G) {
+                                                         const GradRec *__restrict__ G,
+                                                         const unsigned char *__restrict__ brick_rec, int no_vacuum) {
     __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
     const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
     if (buni) {
@@ -276,7 +277,13 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
                 o = 2;
                 if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
                     bool is_max = true, decided = false;
-                    if (G && plane_in_window(g, x)) {  // (slabs: the table covers a window of planes only)
+                    const int binfo = brick_rec ? brick_rec[((x >> 3) * (g.ny >> 3) + (y >> 3)) * (g.nz >> 3) + (z >> 3)] : 1;
+                    if (brick_rec && no_vacuum && !(binfo & 2)) {
+                        // no voxel of this brick is a 26-neighbour maximum: each has a strictly denser neighbour
+                        // (weighted > rho(v) implies rho(n) > rho(v)), and without vacuum no neighbour is skipped
+                        is_max = false;
+                        decided = true;
+                    } else if (G && plane_in_window(g, x) && (binfo & 1)) {  // (slabs: a window of planes; sparse table: flagged bricks)
                         // the table knows the best distance-weighted neighbour of v; if there is one
                         // (and it is not vacuum) that neighbour is denser than v: not a maximum.
                         // (weighted > rho(v) implies rho(n) > rho(v); the converse can fail by
@@ -393,12 +400,24 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int 
 // write their own start voxel, so they are independent -- exactly as in the reference, where the
 // +5 marks are per-trace scratch.  `known` therefore doubles as `rknown`.
 // ---------------------------------------------------------------------------------------------
-template <int K, bool WIN>
+// RHO: the kernel carries the from-rho fallback (make_rec_rho, register hungry) for voxels whose record is not in the
+// table -- outside the table window of a slab, or (sparse table, `brick_rec`) in a brick without records.  The
+// lean instantiation (single GPU) never derives one:
+//  * regions_ok (the labels are the last neargrid assignment's, no vacuum): a brick without records is a brick of a
+//    trapping region; the region is closed under every possible move of both tie rules (k_brick_masks), so the
+//    retrace can only end inside it -- on a known == 2 voxel or on the maximum -- and every voxel of the region
+//    carries the region's label: the retrace stops at q and takes labels[q] (refinement.py:283-303);
+//  * otherwise the retrace goes to `defer_list` (redone by the RHO instantiation), but only if its walk has to go ON
+//    through the missing record: the path-membership test only needs a value <= the key q would have been pushed
+//    with (key_floor).
+template <int K, bool RHO>
 __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n_host,
                                                       const int *n_dev, int *changed, int *escaped, int *ovf_list,
                                                       int *ovf_count, int ovf_cap, int maxsteps,
-                                                      const double *__restrict__ rho, const double *__restrict__ gc) {
+                                                      const double *__restrict__ rho, const double *__restrict__ gc,
+                                                      const unsigned char *__restrict__ brick_rec, int *defer_list,
+                                                      int *defer_count, int regions_ok) {
     const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
     int n_ch = 0, n_es = 0;
   for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     const bool valid = t < n;
     const int v = valid ? list[t] : 0;
     bool moving = false;
-    int result = -3;  // terminal voxel index; -2 overflow; -4 escaped
+    int result = -3;  // terminal voxel index; -2 overflow; -4 escaped; -5 deferred to the from-rho kernel
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
     double dr0 = 0., dr1 = 0., dr2 = 0.;
     GradRec rec = {0., 0., 0., 0.};
@@ -420,8 +439,12 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         lp = v;
         rec = fetch_rec(G, v);
         vol_num = labels[v];
-        w.init(v, rec.key);
         moving = true;
+        if (!(plane_in_window(g, px) && rec_exists(brick_rec, g, px, py, pz))) {   // an edge voxel without a record
+            if (RHO) rec = make_rec_rho(g, rho, gc, px, py, pz);
+            else { result = regions_ok ? v : -5; moving = false; }   // inside a trapping region: it ends there, label unchanged
+        }
+        w.init(v, rec.key);
     }
     while (__any(moving)) {
         if (moving) {
@@ -450,10 +473,15 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                 GradRec nr = fetch_rec(G, in_win ? lq : lp);
                 const bool ok_plane = plane_valid(g, qx);
                 const int8_t kq = known[ok_plane ? lq : lp];  // in flight together with the record
-                if (WIN && ok_plane && !in_win) nr = make_rec_rho(g, rho, gc, qx, qy, qz);  // outside the table window: from rho
+                const bool missing = !(in_win && rec_exists(brick_rec, g, qx, qy, qz));
+                if (missing && ok_plane) {
+                    if (RHO) nr = make_rec_rho(g, rho, gc, qx, qy, qz);
+                    else nr.key = key_floor(rho[lq]);
+                }
                 if (!ok_plane) { result = -4; moving = false; }
-                else if ((!WIN && !in_win) || (!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
+                else if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
                 else if (kq == 2) { result = lq; moving = false; }  // refinement.py:294-303
+                else if (!RHO && missing) { result = regions_ok ? lq : -5; moving = false; }
                 else {
                     w.push(lq, nr.key);
                     px = qx; py = qy; pz = qz; lp = lq; rec = nr;
@@ -471,6 +499,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
             const int k = atomicAdd(ovf_count, 1);
             if (k < ovf_cap) ovf_list[k] = v;
         } else if (result == -4) { known[v] = -6; es = 1; }  // left the valid slab: parked for the fallback
+        else if (result == -5) defer_list[atomicAdd(defer_count, 1)] = v;   // the list takes every voxel: no overflow
     }
     n_ch += ch; n_es += es;
   }

@@ -28,6 +28,7 @@ enum {
     FS_ERR,              // loud failures (bit 0: ongrid chase did not terminate)
     FS_N_EDGES,          // refinement: edge list length
     FS_CHANGED, FS_ESCAPED, FS_R_OVF,
+    FS_R_DEFER,          // refinement: retraces handed to the from-rho kernel (their walk goes on through a brick without records)
     FS_COUNT = 64,
     // 8 per-XCD work cursors of the persistent trace, one per 128-byte line: device-scope atomics on ONE line
     // serialise at ~88 per microsecond whatever the word (measured: 8 cursors in one line = one cursor)
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
 // numbering needs one note per region, not one per brick.
 __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restrict__ seed, const int *__restrict__ buf0,
                                                      const int *__restrict__ buf1, int *fs, int *__restrict__ blab,
-                                                     int *box_first) {
+                                                     int *box_first, const int *__restrict__ bmask, unsigned char *brick_rec) {
     __shared__ int s_first[64];
     const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
     const int nbx = fs[FS_N_BOXES];
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restr
     for (int b = blockIdx.x * TPB + threadIdx.x; b < nbr; b += gridDim.x * TPB) {
         const int l = nbx ? src[b] : 0;
         blab[b] = l;
+        if (brick_rec) brick_rec[b] = (unsigned char)(((bmask[b] >> 27) & 1) << 1);   // no records yet; bit 1: holds a maximum
         cnt += (l > 0);
         if (l > 0 && l <= 64 && s_first[l - 1] > b) atomicMin(&s_first[l - 1], b);
     }
