@@ -1075,8 +1075,9 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             GridS gs;
             const bool sym = sym_grid(g, gs);
             if (sparse) {
-                if (sym) k_brick_masks<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
-                else k_brick_masks<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
+                // the assignment's tie rule (methods.py:324) is the template argument
+                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
+                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
             } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);

@@ -26,25 +26,145 @@
 // of width 1e-12, equal everywhere else (soundness only needs a superset).
 #define BM_EPS 2e-12
 
-// thread -> (y, z) column of the 8 x 32 tile face: the columns on a y- or z-face of their brick (28 of 64 per brick)
-// come first, so that waves 0-1 hold the border columns (+16 interior ones) and waves 2-3 only interior columns --
-// an interior column needs the 27-point ongrid scan on the two x-faces of the brick only.
+// thread -> (y, z) column of the 8 x 32 tile face.  The columns on a y- or z-face of their brick (28 of 64 per brick)
+// come first, sorted by side: wave 0 holds the low-side columns (y == 0 or z == 0) and the four mixed corners per
+// tile row, wave 1 the purely high-side ones (y == 7 or z == 7), waves 2-3 (and the last lanes of 0-1) interior
+// columns.  An interior column needs the 27-point ongrid scan on the two x-faces of the brick only, and a field
+// that points the same way across the tile leaves one of the two border waves without any face to test.
 __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
-    if (t < 112) {
-        const int bz = t / 28, i = t - bz * 28;
-        int yy, zz;
-        if (i < 8) { yy = 0; zz = i; }
-        else if (i < 16) { yy = 7; zz = i - 8; }
-        else { yy = 1 + ((i - 16) >> 1); zz = ((i - 16) & 1) ? 7 : 0; }
-        ty = yy; tz = bz * 8 + zz;
-    } else {
-        const int u = t - 112;
-        const int bz = u / 36, i = u - bz * 36;
-        ty = 1 + i / 6; tz = bz * 8 + 1 + i % 6;
+    int bz, yy, zz;
+    if (t < 60) {            // wave 0: per brick 13 low-side columns + 2 mixed corners
+        bz = t / 15;
+        const int i = t - bz * 15;
+        if (i < 7) { yy = 0; zz = i; }                    // y == 0, z 0..6
+        else if (i < 13) { yy = i - 6; zz = 0; }          // z == 0, y 1..6
+        else if (i == 13) { yy = 0; zz = 7; }             // mixed corners
+        else { yy = 7; zz = 0; }
+    } else if (t < 64) {     // 4 interior columns fill wave 0
+        bz = t - 60; yy = 1; zz = 1;
+    } else if (t < 116) {    // wave 1: per brick 13 high-side columns
+        const int u = t - 64;
+        bz = u / 13;
+        const int i = u - bz * 13;
+        if (i < 7) { yy = 7; zz = i + 1; }                // y == 7, z 1..7
+        else { yy = i - 6; zz = 7; }                      // z == 7, y 1..6
+    } else {                 // the other 35 interior columns of each brick: 12 lanes of wave 1, waves 2-3
+        const int u = t - 116;
+        bz = u / 35;
+        const int i = u - bz * 35 + 1;                    // 1..35 of the 6 x 6 interior, (1,1) is taken
+        yy = 1 + i / 6; zz = 1 + i % 6;
+    }
+    ty = yy; tz = bz * 8 + zz;
+}
+
+// v_max_f64 without the canonicalisation fmax() adds for operands that come straight from memory (no NaNs in a density)
+__device__ __forceinline__ double max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// One tie rule's contribution to the face-crossing booleans of a voxel at (k, ty, zz) of its brick.  MT: methods.py:324
+// (1) or refinement.py:111 (0), compile time -- with the rule in a register both variants were evaluated and blended.
+template <int MT, int K, typename GT>
+__device__ __forceinline__ void bm_cross(const GT &g, double c, double hx, double lx, double hy, double ly, double hz, double lz,
+                                         int ty, int zz, bool &xl, bool &xh, bool &yl, bool &yh, bool &zl, bool &zh) {
+    // methods.py:324-327 / refinement.py:111-130: the gradient direction before its normalisation
+    const bool f0 = MT ? (hx <= c && c >= lx) : (hx < c && c > lx);
+    const bool f1 = MT ? (hy <= c && c >= ly) : (hy < c && c > ly);
+    const bool f2 = MT ? (hz <= c && c >= lz) : (hz < c && c > lz);
+    const double g0 = f0 ? 0. : (hx - lx) / 2.;
+    const double g1 = f1 ? 0. : (hy - ly) / 2.;
+    const double g2 = f2 ? 0. : (hz - lz) / 2.;
+    const double d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
+    const double d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
+    const double d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
+    const double mg = fmax(fmax(fabs(d0), fabs(d1)), fabs(d2));
+    const bool moves = !(mg < 1E-14);   // max_grad < 1E-14: the ongrid step only
+    const double tiny = mg * BM_EPS, nearm = mg * (1. - BM_EPS);
+    if (K == 0) xl |= moves && d0 < tiny;
+    if (K <= 1) xl |= moves && d0 < -nearm;
+    if (K == GT_X - 1) xh |= moves && d0 > -tiny;
+    if (K >= GT_X - 2) xh |= moves && d0 > nearm;
+    yl |= moves && ((ty == 0 && d1 < tiny) || (ty <= 1 && d1 < -nearm));
+    yh |= moves && ((ty == 7 && d1 > -tiny) || (ty >= 6 && d1 > nearm));
+    zl |= moves && ((zz == 0 && d2 < tiny) || (zz <= 1 && d2 < -nearm));
+    zh |= moves && ((zz == 7 && d2 > -tiny) || (zz >= 6 && d2 > nearm));
+}
+
+// one x-position K of the column: everything below the window update
+template <int MT, int K, typename GT>
+__device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3], double dface, bool in, int v, int ty, int zz,
+                                         int &mine, bool &any_tie, int *seeds, int *seed_count, int seed_cap) {
+    const double c = a[1][1][1];
+    const double hx = a[2][1][1], lx = a[0][1][1], hy = a[1][2][1], ly = a[1][0][1], hz = a[1][1][2], lz = a[1][1][0];
+    const bool tie = axis_tie(hx, c, lx) || axis_tie(hy, c, ly) || axis_tie(hz, c, lz);
+    any_tie |= in && tie;
+    // can a move of this voxel leave its brick through the low / high face of each axis?  A move reaches offset
+    // -1 when d < tiny and -2 when d < -nearm (mirrored upwards), so at position p of 0..7 the low face is crossed
+    // iff (p == 0 and d < tiny) or (p <= 1 and d < -nearm).  Booleans throughout: they stay lane masks.
+    bool xl = false, xh = false, yl = false, yh = false, zl = false, zh = false;
+    bm_cross<MT, K>(g, c, hx, lx, hy, ly, hz, lz, ty, zz, xl, xh, yl, yh, zl, zh);
+    // a voxel with a tie axis has TWO gradient directions (methods.py:324 zeroes the axis, refinement.py:111 does
+    // not): it gets the union, so that a trapping region is closed for the assignment's walkers AND for the
+    // refinement's retraces (k_refine_trace stops a retrace that enters a region)
+    if (__any(tie)) bm_cross<!MT, K>(g, c, hx, lx, hy, ly, hz, lz, ty, zz, xl, xh, yl, yh, zl, zh);
+    // Does this voxel need its exact ongrid successor?  (a) it lies on a face of its brick that its gradient
+    // interval does not cross already (an ongrid move is one voxel long: only face voxels can leave the brick
+    // by it); (b) it may be a 26-neighbour maximum: not ruled out by a face neighbour whose weighted value
+    // (bounded from below with the smallest face distance; fl(.) is monotone) exceeds c.
+    const double r6 = max_raw(max_raw(max_raw(hx, lx), max_raw(hy, ly)), max_raw(hz, lz));
+    double wq = (r6 - c) * dface;
+    wq += c;
+    const bool not_max = wq > c;
+    const bool need = (K == 0 && !xl) || (K == GT_X - 1 && !xh) || (ty == 0 && !yl) || (ty == 7 && !yh) ||
+                      (zz == 0 && !zl) || (zz == 7 && !zh) || !not_max;
+    bool is_max = false;
+#ifdef BM_NO_OG
+    if (false) {
+#else
+    if (__any(need && in)) {
+#endif
+        // methods.py:87-117: strict '>' first-wins scan in (ix,iy,iz) ascending order
+        double max_val = c;
+        int og = XB_OG_SELF;
+#pragma unroll
+        for (int ix = 0; ix < 3; ix++)
+#pragma unroll
+            for (int iy = 0; iy < 3; iy++)
+#pragma unroll
+                for (int iz = 0; iz < 3; iz++) {
+                    if (ix == 1 && iy == 1 && iz == 1) continue;   // (c - c) * d + c is never > c
+                    double w = a[ix][iy][iz];
+                    w = (w - c) * dist_at(g, ix, iy, iz);
+                    w += c;
+                    og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
+                    max_val = fmax(max_val, w);
+                }
+        is_max = og == XB_OG_SELF;
+        // og = ix*9 + iy*3 + iz: ix == 0 <=> og < 9, ix == 2 <=> og >= 18, ...
+        const int oyz = og % 9, oz = og % 3;
+        if (K == 0) xl |= og < 9;
+        if (K == GT_X - 1) xh |= og >= 18;
+        yl |= ty == 0 && oyz < 3;
+        yh |= ty == 7 && oyz >= 6;
+        zl |= zz == 0 && oz == 0;
+        zh |= zz == 7 && oz == 2;
+    }
+    if (in) {
+        if (is_max) {
+            const int q = atomicAdd(seed_count, 1);
+            if (q < seed_cap) seeds[q] = v;
+            mine |= 1 << 27;
+        }
+        // per axis the set of brick offsets {-1,0,+1} a move can reach (0 always: bit 1), then the 27-bit outer
+        // product z -> y -> x by shifts (bit = (dx+1)*9 + (dy+1)*3 + (dz+1))
+        const int pc = 2 | (zl ? 1 : 0) | (zh ? 4 : 0);
+        const int yz = (pc << 3) | (yl ? pc : 0) | (yh ? pc << 6 : 0);
+        mine |= (yz << 9) | (xl ? yz : 0) | (xh ? yz << 18 : 0);
     }
 }
 
-template <typename GT>
+template <typename GT, int MT>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int *seeds, int *seed_count,
                                                      int seed_cap, int small, int *__restrict__ bmask, int *tie_count) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
@@ -97,90 +217,20 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
         }
     int mine = 0;
     bool any_tie = false;
-#pragma unroll
-    for (int k = 0; k < GT_X; k++) {
-#pragma unroll
-        for (int iy = 0; iy < 3; iy++)
-#pragma unroll
-            for (int iz = 0; iz < 3; iz++) {
-                a[0][iy][iz] = a[1][iy][iz];
-                a[1][iy][iz] = a[2][iy][iz];
-                a[2][iy][iz] = tile[k + 2][ty + iy][tz + iz];
-            }
-        const int x = x0 + k;
-        const bool in = col_in && x < g.nx;
-        const double c = a[1][1][1];
-        const double hx = a[2][1][1], lx = a[0][1][1], hy = a[1][2][1], ly = a[1][0][1], hz = a[1][1][2], lz = a[1][1][0];
-        const bool tie = ((int)axis_tie(hx, c, lx) | (int)axis_tie(hy, c, ly) | (int)axis_tie(hz, c, lz)) != 0;
-        any_tie |= in && tie;
-        int lo0 = 1, hi0 = -1, lo1 = 1, hi1 = -1, lo2 = 1, hi2 = -1;   // empty: max_grad < 1E-14 moves by the ongrid step only
-        // a voxel with a tie axis has TWO gradient directions (methods.py:324 zeroes the axis, refinement.py:111 does
-        // not): its interval is the union, so that a trapping region is closed for the assignment's walkers AND for
-        // the refinement's retraces (k_refine_trace stops a retrace that enters a region)
-        const int rules = __any(tie) ? 2 : 1;
-        for (int rule = 0; rule < rules; rule++) {
-            const int mt = rule ? !g.main_ties : g.main_ties;
-            // methods.py:324-327 / refinement.py:111-130: the gradient direction before its normalisation
-            const double g0 = axis_flat(mt, hx, c, lx) ? 0. : (hx - lx) / 2.;
-            const double g1 = axis_flat(mt, hy, c, ly) ? 0. : (hy - ly) / 2.;
-            const double g2 = axis_flat(mt, hz, c, lz) ? 0. : (hz - lz) / 2.;
-            const double d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
-            const double d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
-            const double d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
-            const double mg = fmax(fmax(fabs(d0), fabs(d1)), fabs(d2));
-            if (!(mg < 1E-14)) {
-                const double tiny = mg * BM_EPS, nearm = mg * (1. - BM_EPS);
-                lo0 = min(lo0, -(int)(d0 < tiny) - (int)(d0 < -nearm)); hi0 = max(hi0, (int)(d0 > -tiny) + (int)(d0 > nearm));
-                lo1 = min(lo1, -(int)(d1 < tiny) - (int)(d1 < -nearm)); hi1 = max(hi1, (int)(d1 > -tiny) + (int)(d1 > nearm));
-                lo2 = min(lo2, -(int)(d2 < tiny) - (int)(d2 < -nearm)); hi2 = max(hi2, (int)(d2 > -tiny) + (int)(d2 > nearm));
-            }
-        }
-        // Does this voxel need its exact ongrid successor?  (a) it lies on a face of its brick that its gradient
-        // interval does not cross already (an ongrid move is one voxel long: only face voxels can leave the brick
-        // by it); (b) it may be a 26-neighbour maximum: not ruled out by a face neighbour whose weighted value
-        // (bounded from below with the smallest face distance; fl(.) is monotone) exceeds c.
-        const double r6 = fmax(fmax(fmax(hx, lx), fmax(hy, ly)), fmax(hz, lz));
-        double wq = (r6 - c) * dface;
-        wq += c;
-        const bool not_max = wq > c;
-        const bool need = ((k == 0 && lo0 > -1) || (k == GT_X - 1 && hi0 < 1) || (ty == 0 && lo1 > -1) || (ty == 7 && hi1 < 1) ||
-                           (zz == 0 && lo2 > -1) || (zz == 7 && hi2 < 1) || !not_max);
-        int og = -1;   // unknown (and irrelevant)
-        if (__any(need && in)) {
-            // methods.py:87-117: strict '>' first-wins scan in (ix,iy,iz) ascending order
-            double max_val = c;
-            og = XB_OG_SELF;
-#pragma unroll
-            for (int ix = 0; ix < 3; ix++)
-#pragma unroll
-                for (int iy = 0; iy < 3; iy++)
-#pragma unroll
-                    for (int iz = 0; iz < 3; iz++) {
-                        double w = a[ix][iy][iz];
-                        w = (w - c) * dist_at(g, ix, iy, iz);
-                        w += c;
-                        og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
-                        max_val = fmax(max_val, w);
-                    }
-            const int ox = og / 9 - 1, oy = (og / 3) % 3 - 1, oz = og % 3 - 1;
-            lo0 = min(lo0, ox); hi0 = max(hi0, ox);
-            lo1 = min(lo1, oy); hi1 = max(hi1, oy);
-            lo2 = min(lo2, oz); hi2 = max(hi2, oz);
-        }
-        if (in) {
-            if (og == XB_OG_SELF) {
-                const int q = atomicAdd(seed_count, 1);
-                if (q < seed_cap) seeds[q] = (x * g.ny + y) * g.nz + z;
-                mine |= 1 << 27;
-            }
-            // per axis the set of brick offsets {-1,0,+1} a move can reach (0 always), then the 27-bit outer product
-            const int pa = 2 | (k + lo0 < 0) | ((k + hi0 >= 8) << 2);
-            const int pb = 2 | (ty + lo1 < 0) | ((ty + hi1 >= 8) << 2);
-            const int pc = 2 | (zz + lo2 < 0) | ((zz + hi2 >= 8) << 2);
-            const int yz = pc * (8 | (pb & 1) | ((pb & 4) << 4));
-            mine |= yz * (512 | (pa & 1) | ((pa & 4) << 16));
-        }
+#define BM_STEP(K)                                                                                                   \
+    {                                                                                                                \
+        _Pragma("unroll") for (int iy = 0; iy < 3; iy++) _Pragma("unroll") for (int iz = 0; iz < 3; iz++) {          \
+            a[0][iy][iz] = a[1][iy][iz];                                                                             \
+            a[1][iy][iz] = a[2][iy][iz];                                                                             \
+            a[2][iy][iz] = tile[K + 2][ty + iy][tz + iz];                                                            \
+        }                                                                                                            \
+        const int x = x0 + K;                                                                                        \
+        bm_voxel<MT, K>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie, seeds,    \
+                        seed_count, seed_cap);                                                                       \
     }
+    BM_STEP(0) BM_STEP(1) BM_STEP(2) BM_STEP(3) BM_STEP(4) BM_STEP(5) BM_STEP(6) BM_STEP(7)
+#undef BM_STEP
+    static_assert(GT_X == 8, "eight x-positions per column");
     if (__any(any_tie) && threadIdx.x % XB_WAVE == 0) atomicAdd(tie_count, 1);  // only != 0 matters
     atomicOr(&s_mask[tz >> 3], mine);
     __syncthreads();
