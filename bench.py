@@ -7,8 +7,8 @@ on a synthetic 512^3 grid (BASELINE config 3), data resident in HBM, on N GPUs o
 
 A "step" is one full pass of the hot path over the grid: volumes_init (label reset) -> bader_calc
 -> refine, exactly the call sequence of Bader.__call__ (interface.py:406-409).  N > 1: one rank per
-GPU, either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
-environment) or -- `python bench.py --gpus N` as typed -- by this script itself, which then spawns N fresh
+GPU (no PyTorch in the ranks: RCCL through the library's C ABI), either launched by torch.distributed.run
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or -- `python bench.py --gpus N` as typed -- by this script itself, which then spawns N fresh
 rank processes BEFORE anything touches the GPU, relays rank 0's JSON line and exits non-zero if any rank
 failed.  The grid is cut into axis-0 slabs (strong scaling: the 512^3 grid is fixed, north_star: ">= 6x at
 8 GPUs").  Rank 0 prints ONE JSON line.
@@ -137,21 +137,18 @@ def main():
             raise SystemExit(spawn_ranks(args.gpus))   # nothing has touched the GPU in this process
         args.gpus = world
 
-    from pybader_amd import _lib, slab, synth
+    from pybader_amd import _lib, comm as xcomm, slab, synth
     from pybader_amd.interface import distance_matrix, gradient_transform
 
-    dist = None
+    store = None
+    dev_index = 0
     if world > 1:
-        # torch first: PyTorch-ROCm bundles its HIP runtime, libbader_hip.so must load after it
-        import torch
-        import torch.distributed as dist
-        dev_index = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a full node
-        torch.cuda.set_device(dev_index)
-        try:
-            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{dev_index}'))
-        except Exception:  # noqa: BLE001  (no RCCL: fall back to gloo + host-staged planes)
-            dist.init_process_group('gloo')
-        comm = slab.TorchComm(dist, device=torch.device(f'cuda:{dev_index}'))
+        # one process per GPU; no PyTorch: host rendezvous over TCP (pybader_amd/comm.py), planes and counters over
+        # RCCL through the library's own C ABI (csrc/comm.h)
+        store = xcomm.SocketStore(rank, world)
+        dev_index = local_rank % max(1, _lib.load().xb_device_count())   # == local_rank on a full node
+        ctx = _lib.Context(dev_index)
+        comm = xcomm.RcclComm(ctx, store)
     else:
         class _Solo:
             rank, size, transport = 0, 1, 'none'
@@ -160,6 +157,7 @@ def main():
             def max_float(self, x):
                 return x
         comm = _Solo()
+        ctx = _lib.Context(0)
 
     shape = (args.size,) * 3
     lattice, atoms, background = synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND
@@ -167,8 +165,6 @@ def main():
     dm, tg = distance_matrix(vl), gradient_transform(vl)
     voxel_volume = abs(np.linalg.det(lattice)) / float(np.prod(shape))
 
-    dev_index = dev_index if world > 1 else 0
-    ctx = _lib.Context(dev_index)
     halo = args.halo if args.halo is not None else (64 if world > 1 else 8)
     runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=halo)
     windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
@@ -195,8 +191,6 @@ def main():
 
     def fence():
         ctx.sync()
-        if world > 1:
-            torch.cuda.synchronize()
         comm.barrier()
         ctx.sync()
 
@@ -291,8 +285,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if store is not None:
+        comm.barrier()
+        ctx.close()
+        store.close()
 
 
 if __name__ == '__main__':

@@ -165,6 +165,9 @@ int64_t xb_plane_elems(xb_ctx *c);
 /* copy whole x-planes [xa,xb) of labels/known between host and device (halo transport over the
  * host / gloo; the RCCL transport works on the device pointers above) */
 int xb_copy_planes(xb_ctx *c, int which /*0 labels,1 known*/, int to_device, void *host, int64_t xa, int64_t xb);
+/* the chunk [first, first+count) of the per-brick move masks (xb_brick_masks) from (to_device 1) or to (0) host
+ * memory -- the host-staged fallback of xb_comm_share_brick_masks */
+int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, int64_t count);
 int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that hold valid neighbour data */
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -188,6 +191,24 @@ int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total);
 /* retraces redone by the from-rho kernel since the context was created (their walk went on through a brick whose
  * records the sparse table does not hold) */
 int xb_deferred_stats(xb_ctx *c, int64_t *refine_total);
+
+/* ---- multi-GPU transport: RCCL over xGMI, one process per GPU (no PyTorch) ------------------------------------
+ * Replaces nothing in the reference -- its thread blocks share one address space (thread_handlers.py:28-58,
+ * 154-205); these calls move what the slab scheduler (pybader_amd/slab.py) has to move between GPUs.  librccl is
+ * loaded on the first call.  Rank 0 makes the unique id, the host side distributes its 128 bytes. */
+int xb_comm_unique_id(uint8_t id_out[128]);
+int xb_comm_init(xb_ctx *c, int rank, int nranks, const uint8_t id_in[128]);
+int xb_comm_destroy(xb_ctx *c);
+/* planes [xa, xb) of the label (which 0) / known (which 1) array to and from ring neighbours, one ncclGroup */
+int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *send_peer, const int64_t *send_xa,
+                            const int64_t *send_xb, int n_recv, const int32_t *recv_peer, const int64_t *recv_xa,
+                            const int64_t *recv_xb);
+/* n int64 reduced in place over the ranks (op 0 sum, 1 min, 2 max): the counters thread_handlers.refine sums */
+int xb_comm_allreduce_i64(xb_ctx *c, int64_t *inout, int64_t n, int op);
+/* n int64 from every rank, out[size * n] in rank order: maxima tables (thread_handlers.py:59-65), seeds */
+int xb_comm_allgather_i64(xb_ctx *c, const int64_t *in, int64_t n, int64_t *out);
+/* every rank's chunk [first[r], first[r]+count[r]) of the brick move masks (xb_brick_masks) to every rank */
+int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *count);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ SYMBOLS = {
     'xb_density_ptr': (_vp, [_vp]),
     'xb_plane_elems': (_i64, [_vp]),
     'xb_copy_planes': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
+    'xb_brick_masks_copy': (_int, [_vp, _int, _vp, _i64, _i64]),
     'xb_set_halo': (_int, [_vp, _i64]),
     'xb_kernel_time': (_int, [_vp, _int, _pdbl, _pi64]),
     'xb_kernel_time_reset': (_int, [_vp]),
@@ -71,6 +72,13 @@ SYMBOLS = {
     'xb_box_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_slow_path_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_deferred_stats': (_int, [_vp, _pi64]),
+    'xb_comm_unique_id': (_int, [_vp]),
+    'xb_comm_init': (_int, [_vp, _int, _int, _vp]),
+    'xb_comm_destroy': (_int, [_vp]),
+    'xb_comm_exchange_planes': (_int, [_vp, _int, _int, _vp, _pi64, _pi64, _int, _vp, _pi64, _pi64]),
+    'xb_comm_allreduce_i64': (_int, [_vp, _pi64, C.c_int64, _int]),
+    'xb_comm_allgather_i64': (_int, [_vp, _pi64, C.c_int64, _pi64]),
+    'xb_comm_share_brick_masks': (_int, [_vp, _pi64, _pi64]),
 }
 
 _lib = None
@@ -341,6 +349,59 @@ class Context:
         check(self.lib.xb_copy_planes(self.h, int(which), int(to_device), _ptr(host), int(xa), int(xb)))
 
     # -- measurement ------------------------------------------------------------------------
+    def plane_elems(self):
+        return int(self.lib.xb_plane_elems(self.h))
+
+    def brick_masks_copy(self, host, first, count):
+        """the chunk [first, first+count) of the per-brick move masks: host=None downloads it, else uploads `host`"""
+        if host is None:
+            out = np.empty(int(count), np.int32)
+            check(self.lib.xb_brick_masks_copy(self.h, 0, _ptr(out), int(first), int(count)))
+            return out
+        buf = np.ascontiguousarray(host, np.int32)
+        assert buf.size == int(count)
+        check(self.lib.xb_brick_masks_copy(self.h, 1, _ptr(buf), int(first), int(count)))
+
+    # -- multi-GPU transport (csrc/comm.h: RCCL through the C ABI) ---------------------------------
+    def comm_unique_id(self):
+        buf = np.zeros(128, np.uint8)
+        check(self.lib.xb_comm_unique_id(_ptr(buf)))
+        return buf.tobytes()
+
+    def comm_init(self, rank, size, unique_id):
+        buf = np.frombuffer(unique_id, np.uint8).copy()
+        assert buf.size == 128
+        check(self.lib.xb_comm_init(self.h, int(rank), int(size), _ptr(buf)))
+        self.comm_size = int(size)
+
+    def comm_allreduce(self, vals, op='sum'):
+        a = np.array([int(v) for v in vals], np.int64)
+        check(self.lib.xb_comm_allreduce_i64(self.h, a.ctypes.data_as(_pi64), a.size, {'sum': 0, 'min': 1, 'max': 2}[op]))
+        return a.tolist()
+
+    def comm_allgather(self, vals, size=None):
+        a = np.ascontiguousarray(vals, np.int64).reshape(-1)
+        n = int(self.comm_size if size is None else size)
+        out = np.empty(n * a.size, np.int64)
+        check(self.lib.xb_comm_allgather_i64(self.h, a.ctypes.data_as(_pi64), a.size, out.ctypes.data_as(_pi64)))
+        return out
+
+    def comm_exchange_planes(self, which, sends, recvs):
+        def cols(ops):
+            peer = np.array([o[0] for o in ops], np.int32)
+            xa = np.array([o[1] for o in ops], np.int64)
+            xb = np.array([o[2] for o in ops], np.int64)
+            return peer, xa, xb
+        sp, sa, sb = cols(sends)
+        rp, ra, rb = cols(recvs)
+        check(self.lib.xb_comm_exchange_planes(self.h, int(which), len(sends), _ptr(sp), sa.ctypes.data_as(_pi64),
+                                               sb.ctypes.data_as(_pi64), len(recvs), _ptr(rp), ra.ctypes.data_as(_pi64),
+                                               rb.ctypes.data_as(_pi64)))
+
+    def comm_share_brick_masks(self, first, count):
+        f, n = np.array(first, np.int64), np.array(count, np.int64)
+        check(self.lib.xb_comm_share_brick_masks(self.h, f.ctypes.data_as(_pi64), n.ctypes.data_as(_pi64)))
+
     def enable_timing(self, on=True):
         check(self.lib.xb_enable_timing(self.h, int(on)))
 

@@ -49,8 +49,10 @@ struct TimedKernel {
     long long launches = 0;
 };
 
+namespace xbcomm { struct State; }
 struct xb_ctx {
     int device = 0;
+    xbcomm::State *comm = nullptr;   // RCCL transport (comm.h), one process per GPU
     hipStream_t stream = nullptr;
     Grid g{};
     bool has_grid = false;
@@ -230,10 +232,12 @@ static void free_grid(xb_ctx *c) {
     c->n_alloc = 0; c->stage_bytes = 0;
 }
 
+int xb_comm_destroy(xb_ctx *c);
 void xb_destroy(xb_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    xb_comm_destroy(c);
     for (auto &t : c->tk)
         for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     free_grid(c);
@@ -1853,6 +1857,17 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     return XB_OK;
 }
 
+int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, int64_t count) {
+    NEED_GRID("xb_brick_masks_copy");
+    const int64_t nbr = c->N / 512;
+    if (!host || first < 0 || count < 0 || first + count > nbr) return fail(XB_E_ARG, "xb_brick_masks_copy: bad chunk");
+    int *masks = c->list + nbr;
+    if (to_device) HIPCHK(hipMemcpyAsync(masks + first, host, count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(hipMemcpyAsync(host, masks + first, count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
 int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (key == 0) c->opt_trace = value;
@@ -1925,3 +1940,5 @@ int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches) {
 }
 
 }  // extern "C"
+
+#include "comm.h"

@@ -6,9 +6,9 @@ arrays, so a slab and its halo planes are contiguous memory).  The float64 densi
 every GPU (8 GiB at 1024^3 of 288 GB): every trajectory step is a local read and the remainder `dr`
 is carried exactly, which keeps the N-slab result identical to the 1-GPU result.  Labels / known
 flags are full-size arrays on every rank of which only the owned planes + `halo` planes each side
-are kept valid; halos are refreshed by point-to-point plane exchange (RCCL send/recv through
-torch.distributed when the arrays are device tensors, gloo when they are host tensors in the CPU
-tests) before every edge sweep.  Collectives: only tiny ones (maxima tables, counters).
+are kept valid; halos are refreshed by point-to-point plane exchange (RCCL send/recv through the library's
+own C ABI, pybader_amd/comm.py; the CPU tests plug in a gloo or TCP transport over a host backend) before
+every edge sweep.  Collectives: only tiny ones (maxima tables, counters).
 
 The scheduler is written against a small backend interface so that the CPU tests can drive it with a
 host backend; the product backend is `GpuBackend` (libbader_hip.so)."""
@@ -81,191 +81,28 @@ def halo_plan(ranges, rank, halo, nx):
     return sends, recvs
 
 
-class TorchComm:
-    """torch.distributed plumbing.  Default group: backend 'nccl' (= RCCL over xGMI) on the GPU box,
-    'gloo' in the CPU tests.  Device planes go rank-to-rank with batched isend/irecv on zero-copy
-    views of the library's arrays; if that transport fails its start-up self-test (or the default
-    group is gloo while the arrays live on the device) planes are staged through pinned host memory
-    over a gloo group instead -- slower, same result."""
-
-    def __init__(self, dist, device=None):
-        self.dist = dist
-        self.rank = dist.get_rank()
-        self.size = dist.get_world_size()
-        self.device = device
-        self.backend = dist.get_backend()
-        self.host_group = None
-        self.device_p2p = False
-        if device is not None:
-            if self.backend != 'gloo':
-                self.host_group = dist.new_group(backend='gloo')
-                self.device_p2p = self._selftest()
-        self.transport = 'rccl-p2p' if self.device_p2p else ('gloo' if device is None else 'host-staged-gloo')
-
-    def _selftest(self):
-        """ring exchange of a small device tensor + a device all-reduce; every rank must see the right
-        payload.  The verdict is agreed on over the gloo group, so all ranks pick the same transport."""
-        import torch
-        ok = True
-        try:
-            if self.size > 1:
-                src = torch.full((256,), float(self.rank), device=self.device)
-                dst = torch.full((256,), -1.0, device=self.device)
-                nxt, prv = (self.rank + 1) % self.size, (self.rank - 1) % self.size
-                ops = [self.dist.P2POp(self.dist.irecv, dst, prv), self.dist.P2POp(self.dist.isend, src, nxt)]
-                for w in self.dist.batch_isend_irecv(ops):
-                    w.wait()
-                t = torch.tensor([self.rank + 1, 1], dtype=torch.int64, device=self.device)
-                self.dist.all_reduce(t)
-                torch.cuda.synchronize(self.device)
-                ok = bool((dst == float(prv)).all().item()) and t.tolist() == [self.size * (self.size + 1) // 2, self.size]
-        except Exception:  # noqa: BLE001
-            ok = False
-        flags = [None] * self.size
-        self.dist.all_gather_object(flags, ok, group=self.host_group)
-        return all(flags)
-
-    def selftest_views(self, views):
-        """Second stage of the self-test, on the arrays that will really travel: zero-copy views of memory the
-        library allocated (not torch).  Plane 0 goes round the ring into the neighbour's plane 1; any
-        failure (exception or wrong payload on any rank) switches every rank to the host-staged transport.
-        Called once, right after the arrays were allocated (their contents do not matter yet)."""
-        if not self.device_p2p or self.size < 2:
-            return
-        import torch
-        ok = True
-        try:
-            nxt, prv = (self.rank + 1) % self.size, (self.rank - 1) % self.size
-            for t in views:
-                if t.shape[0] < 2:
-                    continue
-                t[0].fill_(self.rank + 1)
-                t[1].fill_(0)
-                torch.cuda.synchronize(t.device)
-                ops = [self.dist.P2POp(self.dist.irecv, t[1:2], prv), self.dist.P2POp(self.dist.isend, t[0:1], nxt)]
-                for w in self.dist.batch_isend_irecv(ops):
-                    w.wait()
-                torch.cuda.synchronize(t.device)
-                ok = ok and bool((t[1] == prv + 1).all().item())
-        except Exception:  # noqa: BLE001
-            ok = False
-        if not all(self.allgather(bool(ok))):
-            self.device_p2p = False
-            self.transport = 'host-staged-gloo'
-
-    def allgather(self, obj):
-        out = [None] * self.size
-        self.dist.all_gather_object(out, obj, group=self.host_group)
-        return out
-
-    def sum(self, *vals):
-        if self.device_p2p:          # RCCL all-reduce of a tiny device tensor (tens of microseconds)
-            import torch
-            t = torch.tensor([int(v) for v in vals], dtype=torch.int64, device=self.device)
-            self.dist.all_reduce(t)
-            return t.tolist()
-        got = self.allgather([int(v) for v in vals])
-        return [sum(g[i] for g in got) for i in range(len(vals))]
-
-    def max_float(self, x):
-        return max(self.allgather(float(x)))
-
-    def exchange(self, tensor, sends, recvs):
-        """tensor: (nx, plane) view aliasing the array; moves whole planes between ranks."""
-        import torch
-        if not sends and not recvs:
-            return
-        if tensor.is_cuda and not self.device_p2p:
-            return self._exchange_staged(tensor, sends, recvs)
-        ops = []
-        for peer, xa, xb in recvs:
-            ops.append(self.dist.P2POp(self.dist.irecv, tensor[xa:xb], peer))
-        for peer, xa, xb in sends:
-            ops.append(self.dist.P2POp(self.dist.isend, tensor[xa:xb], peer))
-        for w in self.dist.batch_isend_irecv(ops):
-            w.wait()
-        if tensor.is_cuda:
-            torch.cuda.synchronize(tensor.device)
-
-    def _exchange_staged(self, tensor, sends, recvs):
-        import torch
-        outs = [(peer, tensor[xa:xb].cpu()) for peer, xa, xb in sends]
-        ins = [(peer, xa, xb, torch.empty((xb - xa, tensor.shape[1]), dtype=tensor.dtype)) for peer, xa, xb in recvs]
-        ops = [self.dist.P2POp(self.dist.irecv, buf, peer, group=self.host_group) for peer, _, _, buf in ins]
-        ops += [self.dist.P2POp(self.dist.isend, buf, peer, group=self.host_group) for peer, buf in outs]
-        for w in self.dist.batch_isend_irecv(ops):
-            w.wait()
-        for _, xa, xb, buf in ins:
-            tensor[xa:xb].copy_(buf)
-        torch.cuda.synchronize(tensor.device)
-
-    def gather_chunks(self, tensor, chunks):
-        """tensor: 1-D array every rank holds in full size; chunks[r] = (first, count) is the part rank r has
-        computed.  Afterwards every rank holds every chunk (one broadcast per rank: chunks may differ in size)."""
-        import torch
-        if tensor.is_cuda and not self.device_p2p:
-            mine = tensor[chunks[self.rank][0]:chunks[self.rank][0] + chunks[self.rank][1]].cpu().numpy()
-            parts = self.allgather(mine)
-            for r, (first, count) in enumerate(chunks):
-                if r != self.rank and count:
-                    tensor[first:first + count].copy_(torch.from_numpy(parts[r]))
-            torch.cuda.synchronize(tensor.device)
-            return
-        for r, (first, count) in enumerate(chunks):
-            if count:
-                self.dist.broadcast(tensor[first:first + count], src=r)
-        if tensor.is_cuda:
-            torch.cuda.synchronize(tensor.device)
-
-    def barrier(self):
-        self.dist.barrier(group=self.host_group)
-
-
-class _DevArray:
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False),
-                                         'version': 2, 'strides': None}
-
-
 class GpuBackend:
-    """libbader_hip.so context + zero-copy torch views of its label / known arrays for RCCL."""
+    """libbader_hip.so context behind the scheduler's backend interface (no PyTorch: planes travel through the
+    library's own RCCL transport, pybader_amd/comm.py)."""
 
-    def __init__(self, ctx, device_index):
-        # NB torch (only needed for N > 1: RCCL plumbing) must have been imported before the first
-        # _lib.Context() of the process: PyTorch-ROCm bundles its HIP runtime and has to load first.
+    def __init__(self, ctx, device_index=0):
         self.ctx = ctx
         self.device_index = device_index
-        self._views = None
 
     def set_grid(self, shape, dist_mat, T_grad, x_range, halo):
         self.ctx.set_grid(shape, dist_mat, T_grad, x_range)
         self.sliced = tuple(x_range) != (0, shape[0])
         if self.sliced:
             self.ctx.set_halo(halo)
-        self._views = None
 
     def set_halo(self, halo):
         if self.sliced:
             self.ctx.set_halo(halo)
 
-    def mask_tensor(self):
-        """zero-copy view of the per-brick move masks + (first, count) of the bricks this rank computed"""
-        import torch
-        ptr, n, first, count = self.ctx.brick_masks()
-        t = torch.as_tensor(_DevArray(ptr, (n,), '<i4'), device=f'cuda:{self.device_index}')
-        return t, first, count
-
-    def tensors(self):
-        if self._views is None:
-            import torch
-            lib, h = self.ctx.lib, self.ctx.h
-            nx = self.ctx.shape[0]
-            plane = int(lib.xb_plane_elems(h))
-            dev = f'cuda:{self.device_index}'
-            lab = torch.as_tensor(_DevArray(lib.xb_labels_ptr(h), (nx, plane), '<i4'), device=dev)
-            kn = torch.as_tensor(_DevArray(lib.xb_known_ptr(h), (nx, plane), '|i1'), device=dev)
-            self._views = (lab, kn)
-        return self._views
+    def brick_mask_range(self):
+        """(first, count) of the bricks whose move masks this rank computed"""
+        _, _, first, count = self.ctx.brick_masks()
+        return int(first), int(count)
 
     def __getattr__(self, name):          # assign_trace, assign_finish, edge_find, refine_trace, sync ...
         return getattr(self.ctx, name)
@@ -303,9 +140,9 @@ class SlabRunner:
         self.n_maxima = 0
         self.n_fallbacks = 0
         self.timing = {} if os.environ.get('XB_SLAB_TIMING') else None
-        if comm.size > 1 and hasattr(comm, 'selftest_views') and hasattr(self.be, 'tensors'):
+        if comm.size > 1 and hasattr(comm, 'selftest_planes'):
             self.be.sync()
-            comm.selftest_views(self.be.tensors())
+            comm.selftest_planes(self.be, self.ranges)
 
     def enable_table_window(self, margin=32):
         """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks
@@ -336,10 +173,9 @@ class SlabRunner:
                 seeds = sorted(set(int(v) for part in self.comm.allgather(np.asarray(local).tolist()) for v in part))
             with _Phase(self, 'mask_exchange'):
                 self.be.sync()
-                t, first, count = self.be.mask_tensor()
                 if getattr(self, '_chunks', None) is None:      # static for a given decomposition
-                    self._chunks = self.comm.allgather((int(first), int(count)))
-                self.comm.gather_chunks(t, self._chunks)
+                    self._chunks = self.comm.allgather(self.be.brick_mask_range())
+                self.comm.share_brick_masks(self.be, self._chunks)
             with _Phase(self, 'table_finish'):
                 self.be.table_finish(np.array(seeds, dtype=np.int64))
         with _Phase(self, 'assign_trace'):
@@ -360,7 +196,7 @@ class SlabRunner:
         if self.comm.size > 1:
             with _Phase(self, 'label_halo'):
                 self.be.sync()
-                self.comm.exchange(self.be.tensors()[0], self.sends, self.recvs)
+                self.comm.exchange_planes(self.be, 0, self.sends, self.recvs)
 
     def _trace(self):
         with _Phase(self, 'refine_trace'):

@@ -34,6 +34,10 @@ class OracleSlabBackend:
     def tensors(self):
         return self._t
 
+    def planes(self, which):
+        """(nx, plane) numpy view of the label (0) / known (1) array (HostComm's transport)"""
+        return (self.labels if which == 0 else self.known).reshape(self.shape[0], -1)
+
     def sync(self):
         pass
 
@@ -163,8 +167,15 @@ def main():
     from conftest import case_density, load_golden
     case, method, mode, iters, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     halo = int(sys.argv[6]) if len(sys.argv) > 6 else 4
-    dist.init_process_group('gloo')
-    comm = slab.TorchComm(dist)
+    transport = sys.argv[7] if len(sys.argv) > 7 else 'gloo'
+    if transport == 'gloo':
+        dist.init_process_group('gloo')
+        from torch_comm import TorchComm
+        comm = TorchComm(dist)
+    else:                                   # the product's own host transport (pybader_amd/comm.py), no torch
+        from pybader_amd import comm as xcomm
+        store = xcomm.SocketStore()
+        comm = xcomm.HostComm(store)
     g = load_golden(case)
     rho = case_density(g)
     be = OracleSlabBackend(rho)
@@ -180,7 +191,11 @@ def main():
         full = np.concatenate([p[3] for p in sorted(parts, key=lambda p: p[0])])
         np.savez(out, pre=full_pre, post=full, n=n, log=np.array(log, np.int64).reshape(-1, 2),
                  maxima=np.asarray(runner.maxima), fallbacks=runner.n_fallbacks)
-    dist.destroy_process_group()
+    if transport == 'gloo':
+        dist.destroy_process_group()
+    else:
+        comm.barrier()
+        store.close()
 
 
 if __name__ == '__main__':

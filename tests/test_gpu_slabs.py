@@ -9,6 +9,7 @@ import pytest
 
 from conftest import case_density, load_golden
 from pybader_amd import _lib, slab
+from torch_comm import device_views
 
 pytestmark = pytest.mark.gpu
 
@@ -37,8 +38,9 @@ class ThreadComm:
         got = self.allgather([int(v) for v in vals])
         return [sum(g[i] for g in got) for i in range(len(vals))]
 
-    def exchange(self, tensor, sends, recvs):
+    def exchange_planes(self, backend, which, sends, recvs):
         import torch
+        tensor = device_views(backend.ctx)[which]
         self.sh.cur[self.rank] = tensor
         self.sh.barrier.wait()
         for peer, xa, xb in recvs:
@@ -46,8 +48,9 @@ class ThreadComm:
         torch.cuda.synchronize()
         self.sh.barrier.wait()
 
-    def gather_chunks(self, tensor, chunks):
+    def share_brick_masks(self, backend, chunks):
         import torch
+        tensor = device_views(backend.ctx)[2]
         self.sh.cur[self.rank] = tensor
         self.sh.barrier.wait()
         for r, (first, count) in enumerate(chunks):
@@ -152,3 +155,52 @@ def test_windowed_table_is_used_and_exact():
     assert np.array_equal(pre, g['ng_F'].astype(np.int32)) and np.array_equal(post, g['ng_changed_2'].astype(np.int32))
     pre2, post2, *_ = run_slabs(8, g, rho, 'neargrid', 'changed', 2, 2, None, window=False)
     assert not any(run_slabs.last_windowed) and np.array_equal(pre, pre2) and np.array_equal(post, post2)
+
+
+def test_rccl_transport_through_the_c_abi_single_rank():
+    """xb_comm_* with a one-rank communicator: librccl is dlopen'ed, every entry point is exercised (the collectives
+    are identities, the brick-mask broadcast has itself as root).  More ranks need more GPUs: RCCL refuses two ranks
+    on one device, which bench.py --gpus 2 on this box answers with its host-staged transport (next test)."""
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    ctx = _lib.Context(0)
+    ctx.set_grid(rho.shape, g['dist_mat'], g['T_grad'])
+    ctx.upload_density(rho)
+    ctx.comm_init(0, 1, ctx.comm_unique_id())
+    assert ctx.comm_allreduce([5, -3, 1 << 40]) == [5, -3, 1 << 40]
+    assert ctx.comm_allreduce([7], 'max') == [7] and ctx.comm_allreduce([7], 'min') == [7]
+    assert ctx.comm_allgather([4, 9, 2]).tolist() == [4, 9, 2]
+    ctx.comm_exchange_planes(0, [], [])
+    ctx.vacuum_assign(None, 1.0)
+    n = ctx.assign('neargrid')
+    before = ctx.download_labels(np.int32)
+    nbr = rho.size // 512
+    ctx.comm_share_brick_masks([0], [nbr])
+    ctx.comm_exchange_planes(1, [], [])
+    assert n == 8 and np.array_equal(ctx.download_labels(np.int32), before)
+    with pytest.raises(_lib.BaderHipError):
+        ctx.comm_exchange_planes(0, [(0, 0, 1)], [])       # a send to myself is refused
+    ctx.close()
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` as typed: the script spawns its ranks, they rendezvous over the file/TCP store,
+    RCCL refuses two ranks on one device, every rank falls back to the host-staged transport, rank 0 prints ONE
+    JSON line whose map statistics equal the one-rank run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for n in (1, 2):
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--size', '128', '--steps', '2',
+                            '--warmup', '1', '--no-cpu'], capture_output=True, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        outs.append(json.loads(lines[0]))
+    one, two = outs
+    assert two['n_gpus'] == 2 and 'host-staged-tcp' in two['config']['parallelism']
+    assert two['config']['basins'] == one['config']['basins'] == 8
+    assert two['config']['refine_log'] == one['config']['refine_log']

@@ -14,13 +14,13 @@ from pybader_amd import slab
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(n, args, tmp_path, port, halo=4):
+def run_world(n, args, tmp_path, port, halo=4, transport='gloo'):
     out = str(tmp_path / 'out.npz')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(n))
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'slab_worker.py')] + args + [out, str(halo)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'slab_worker.py')] + args + [out, str(halo), transport],
                                       env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         o, _ = p.communicate(timeout=600)
@@ -78,3 +78,14 @@ def test_slabs_equal_single_rank_and_golden(n, case, method, mode, iters, port, 
         oracle.refine('neargrid', (mode, iters), rho, v, g['dist_mat'], g['T_grad'], 1, log=log)
         assert np.array_equal(r['post'], v)
         assert np.array_equal(r['log'], np.array(log, np.int64).reshape(-1, 2))
+
+
+def test_slabs_over_the_products_own_host_transport(tmp_path):
+    """the same scheduler over pybader_amd.comm.SocketStore / HostComm (file rendezvous + TCP star), 3 ranks"""
+    r = run_world(3, ['c40x48x56_tric', 'ongrid', 'all', '3'], tmp_path, 29621, 3, transport='tcp')
+    assert int(r['fallbacks']) > 0
+    g = load_golden('c40x48x56_tric')
+    assert np.array_equal(r['pre'], g['og_main'].astype(np.int32))
+    r2 = run_world(2, ['c12_cubic', 'neargrid', 'changed', '2'], tmp_path, 29622, 4, transport='tcp')
+    g2 = load_golden('c12_cubic')
+    assert np.array_equal(r2['post'], g2['ng_changed_2'].astype(np.int32))
