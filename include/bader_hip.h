@@ -120,6 +120,14 @@ int xb_gather_voxels(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *labels_o
 int xb_scatter_voxels(xb_ctx *c, const int64_t *idx, int64_t n, const int32_t *labels_in, const int8_t *known_in);
 /* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels) */
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
+/* refinement.edge_check across slabs ('changed' refinement on N GPUs): the greedy scan of refinement.py:420-427 is
+ * global, so every rank resolves the global list of changed voxels.  _local: the owned changed voxels and their
+ * edge&maximum class; _local_fetch copies them out; _global takes the all-gathered lists (label and known halos
+ * refreshed before), resolves them and re-classifies the boxes that touch this rank's planes; `edges` counts the new
+ * edges in the owned planes (the scheduler sums over ranks). */
+int xb_edge_check_local(xb_ctx *c, int64_t *n_out);
+int xb_edge_check_local_fetch(xb_ctx *c, int64_t *idx_out, int8_t *cls_out);
+int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64_t n, int64_t *checked, int64_t *edges);
 /* thread_handlers.refine (thread_handlers.py:128-236): the iteration driver on one GPU.
  * iters < 0 => until nothing changes.  log[2*k] = edges, log[2*k+1] = changed of iteration k+1. */
 int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters);

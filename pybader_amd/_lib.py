@@ -46,6 +46,9 @@ SYMBOLS = {
     'xb_gather_voxels': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'xb_scatter_voxels': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'xb_edge_check': (_int, [_vp, _pi64, _pi64]),
+    'xb_edge_check_local': (_int, [_vp, _pi64]),
+    'xb_edge_check_local_fetch': (_int, [_vp, _vp, _vp]),
+    'xb_edge_check_global': (_int, [_vp, _vp, _vp, _i64, _pi64, _pi64]),
     'xb_refine': (_int, [_vp, _int, _i64, _vp, _i64, _pi64]),
     'xb_charge_sum': (_int, [_vp, _dbl, _i64, _vp, _vp]),
     'xb_volume_assign': (_int, [_vp, _vp, _i64]),
@@ -290,6 +293,22 @@ class Context:
     def edge_check(self):
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_edge_check(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def edge_check_local(self):
+        """slabs: the owned changed voxels (int64 linear indices) and their edge&maximum class (int8)"""
+        n = C.c_int64()
+        check(self.lib.xb_edge_check_local(self.h, C.byref(n)))
+        idx, cls = np.empty(n.value, np.int64), np.empty(n.value, np.int8)
+        if n.value:
+            check(self.lib.xb_edge_check_local_fetch(self.h, _ptr(idx), _ptr(cls)))
+        return idx, cls
+
+    def edge_check_global(self, idx, cls):
+        """slabs: resolve the all-gathered list; returns (checked, new edges in the owned planes)"""
+        idx, cls = np.ascontiguousarray(idx, np.int64), np.ascontiguousarray(cls, np.int8)
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_edge_check_global(self.h, _ptr(idx), _ptr(cls), idx.size, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def refine(self, mode, iters):

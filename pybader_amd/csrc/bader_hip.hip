@@ -83,6 +83,7 @@ struct xb_ctx {
     bool table_prebuilt = false;   // xb_table_finish done: the next xb_assign_trace must not rebuild
     int table_stage = 0;           // windowed build: 1 = records + masks done, 2 = trapping regions done
     std::vector<int> window_seeds; // maxima found in the owned planes (windowed build)
+    int ec_local_n = 0;            // xb_edge_check_local -> xb_edge_check_local_fetch
     long long stat_deferred = 0;   // retraces redone by the from-rho kernel (sparse table)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
@@ -1467,29 +1468,29 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     return XB_OK;
 }
 
-int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
-    NEED_GRID("xb_edge_check");
+// edge_check on the listed voxels c->list[0..n) (all flagged -2 in `known`): the greedy resolution by dependency
+// counters (k_edges.h), then apply / restore / ring / finish.  `cls`: per list entry the edge&maximum class computed
+// elsewhere (slabs: by the owner of the voxel), or null to derive it here.  Only entries within `near_np` planes
+// from plane `near_xa` re-classify their boxes (slabs: the boxes that can touch this rank's valid planes), new
+// edges are counted in the linear index range [count_lo, count_hi) (slabs: the owned planes).
+static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, int near_np, long long count_lo,
+                              long long count_hi, int64_t *checked, int64_t *edges) {
     const Grid &g = c->g;
-    c->list_valid = false;
-    c->buni_valid = false;
-    if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: 'changed' mode is single-slab only; slabs use mode 'all'");
-    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
-    int n = 0;
-    if (int rc = compact(c, -2, &n)) return rc;
     if (checked) *checked = 0;
     if (edges) *edges = 0;
     if (!n) return XB_OK;
     {
-        // greedy resolution by dependency counters (k_edges.h): counters + classes for the whole list, round 1
-        // over the whole list, then the dependency chains are chased asynchronously by a small grid of
-        // workgroups; queue overflows seed another launch.  Scratch: two seed / overflow lists of N ints in the
-        // staging buffer, 16 bits per voxel for the counters (only 'changed' refinement needs them).
+        // counters + classes for the whole list, round 1 over the whole list, then the dependency chains are
+        // chased asynchronously by a small grid of workgroups; queue overflows seed another launch.  Scratch: two
+        // seed / overflow lists of N ints in the staging buffer, 16 bits per voxel for the counters (only
+        // 'changed' refinement needs them).
         const int cap = (int)std::min<long long>(c->N, 1LL << 30);
         int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
         if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 2 * (size_t)c->N + 16));
         unsigned int *pend_w = c->ec_pend;
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-        k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, reinterpret_cast<uint16_t *>(pend_w));
+        if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, reinterpret_cast<uint16_t *>(pend_w));
+        else k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, reinterpret_cast<uint16_t *>(pend_w));
         k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
                                                                                          c->counters + 6, cap);
         HIPCHK(hipGetLastError());
@@ -1515,6 +1516,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
         if (int rc = read_counter(c, 6, &undecided)) return rc;
         if (undecided) return fail(XB_E_STATE, "xb_edge_check: %d edge voxels left undecided", undecided);
     }
+    if (near_np < g.nx) k_ec_keep_near<<<nblocks(n), TPB, 0, c->stream>>>(g, c->list, n, c->st, near_xa, near_np);
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     const int new_cap = (int)std::min<long long>(c->N - n, 1LL << 30);   // the rest of `list` behind the compacted edges
     HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
@@ -1527,7 +1529,8 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
         if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
         else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new, nullptr);
     }
-    k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64);
+    k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64,
+                                                                                                      count_lo, count_hi);
     HIPCHK(hipGetLastError());
     unsigned long long r[2];
     HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));
@@ -1535,6 +1538,87 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (edges) *edges = (int64_t)r[0];
     if (checked) *checked = (int64_t)(r[1] + r[0]);  // refinement.py:479 + 504
     return XB_OK;
+}
+
+int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
+    NEED_GRID("xb_edge_check");
+    const Grid &g = c->g;
+    c->list_valid = false;
+    c->buni_valid = false;
+    if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: one slab only; slabs use xb_edge_check_local + xb_edge_check_global");
+    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
+    int n = 0;
+    if (int rc = compact(c, -2, &n)) return rc;
+    return edge_check_resolve(c, n, nullptr, 0, g.nx, 0, c->N, checked, edges);
+}
+
+// ---- 'changed' refinement across slabs ------------------------------------------------------------------------
+// refinement.edge_check is ONE lexicographic greedy scan of the whole grid (refinement.py:420-427): whether a changed
+// voxel is processed depends on its C-order earlier changed neighbours, in chains that run through slab boundaries.
+// The chains only involve the changed voxels themselves (a few 10^5 at 512^3) and one class bit each, so every rank
+// resolves the GLOBAL list: (1) each rank lists its owned changed voxels with their class (xb_edge_check_local);
+// (2) the scheduler all-gathers the lists; (3) each rank flags the whole list in its full-size `known`, resolves it
+// with the same dependency-counter kernels as one GPU, and applies the boxes that touch its own valid planes
+// (xb_edge_check_global).  Needs label AND known halos refreshed beforehand.
+int xb_edge_check_local(xb_ctx *c, int64_t *n_out) {
+    NEED_GRID("xb_edge_check_local");
+    c->list_valid = false;
+    int n = 0;
+    if (int rc = compact(c, -2, &n)) return rc;   // owned planes only
+    if (n) {
+        k_ec_class<<<nblocks(n), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, c->list, n, c->st);
+        HIPCHK(hipGetLastError());
+    }
+    c->ec_local_n = n;
+    if (n_out) *n_out = n;
+    return XB_OK;
+}
+int xb_edge_check_local_fetch(xb_ctx *c, int64_t *idx_out, int8_t *cls_out) {
+    NEED_GRID("xb_edge_check_local_fetch");
+    const int n = c->ec_local_n;
+    if (!n) return XB_OK;
+    std::vector<int> tmp(n);
+    HIPCHK(hipMemcpyAsync(tmp.data(), c->list, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cls_out, c->st, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) idx_out[i] = tmp[i];
+    return XB_OK;
+}
+int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64_t n, int64_t *checked, int64_t *edges) {
+    NEED_GRID("xb_edge_check_global");
+    const Grid &g = c->g;
+    c->list_valid = false;
+    c->buni_valid = false;
+    if (checked) *checked = 0;
+    if (edges) *edges = 0;
+    if (n < 0 || n > c->N) return fail(XB_E_ARG, "xb_edge_check_global: bad list length");
+    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
+    if (c->halo < 3 && g.vlen < g.nx) return fail(XB_E_STATE, "xb_edge_check_global: needs a halo of at least 3 planes");
+    if (!n) return XB_OK;
+    std::vector<int> i32(n);
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= c->N) return fail(XB_E_ARG, "xb_edge_check_global: voxel index out of range");
+        i32[k] = (int)idx[k];
+    }
+    // planes outside this rank's valid range hold stale flags: neutralise them, then flag the whole global list
+    if (g.vlen < g.nx) {
+        const int a = g.vx0 + g.vlen;   // invalid planes: [a, a + nx - vlen) modulo nx
+        const int len = g.nx - g.vlen, first = a % g.nx, run1 = std::min(len, g.nx - first);
+        HIPCHK(hipMemsetAsync(c->known + (size_t)first * g.nyz, 2, (size_t)run1 * g.nyz, c->stream));
+        if (len > run1) HIPCHK(hipMemsetAsync(c->known, 2, (size_t)(len - run1) * g.nyz, c->stream));
+    }
+    int8_t *dcls = c->st + (c->N - n);   // the tail of `st` (its head receives the decisions of k_ec_collect)
+    if (2 * n > c->N) return fail(XB_E_LIMIT, "xb_edge_check_global: list longer than half the grid");
+    HIPCHK(hipMemcpyAsync(c->list, i32.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dcls, cls, n, hipMemcpyHostToDevice, c->stream));
+    k_scatter_byte<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->known, c->list, (int)n, (int8_t)-2);
+    HIPCHK(hipGetLastError());
+    // a processed voxel re-classifies its box (one plane each side) and a new edge among those rings its own box
+    // (one more plane): voxels within two planes of the known-valid range [vx0, vx0 + vlen) can reach it
+    int near_xa = 0, near_np = g.nx;
+    if (g.vlen + 4 < g.nx) { near_xa = (g.vx0 - 2 + g.nx) % g.nx; near_np = g.vlen + 4; }
+    const int rc = edge_check_resolve(c, (int)n, dcls, near_xa, near_np, (long long)g.x0 * g.nyz, (long long)g.x1 * g.nyz, checked, edges);
+    return rc;   // (host vectors outlive the copies: edge_check_resolve waits on the stream)
 }
 
 // The retraces of a refinement need the gradient-field table anyway; built before the first edge sweep it also

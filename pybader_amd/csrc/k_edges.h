@@ -613,6 +613,50 @@ __global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restric
     }
     pend[v] = (uint16_t)(cnt | (cls1 ? EC_CLS1 : 0u));
 }
+// Slabs: the class bit alone, for the owned listed voxels (their 27-boxes lie in label-valid planes) ...
+__global__ __launch_bounds__(TPB) void k_ec_class(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
+                                                  const int *__restrict__ list, int n, int8_t *cls) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    bool is_edge, is_max;
+    classify27(g, rho, labels, x, r / g.nz, r % g.nz, v, is_edge, is_max);
+    cls[t] = (is_edge && is_max) ? 1 : 0;
+}
+// ... and the 16 bits of every voxel of the GLOBAL list from the classes their owners computed
+__global__ __launch_bounds__(TPB) void k_ec_init_cls(Grid g, const int8_t *__restrict__ known, const int *__restrict__ list, int n,
+                                                     const int8_t *__restrict__ cls, uint16_t *pend) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    const int v = list[t];
+    const int x = v / g.nyz;
+    const int r = v - x * g.nyz;
+    const int y = r / g.nz, z = r - y * g.nz;
+    int rows[9];
+    unsigned int w[9];
+    ec_box(g, known, x, y, z, rows, w);
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 27; j++) {
+        const int8_t k = (int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff);
+        cnt += (ec_box_voxel(g, rows, z, j) < v) & (k == -2);
+    }
+    pend[v] = (uint16_t)(cnt | (cls[t] ? EC_CLS1 : 0u));
+}
+__global__ void k_scatter_byte(int8_t *a, const int *__restrict__ idx, int n, int8_t value) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[idx[t]] = value;
+}
+// st[t] = 0 for the entries whose 27-box cannot touch the planes [xa, xa + np) (mod nx): their boxes are not applied
+__global__ void k_ec_keep_near(Grid g, const int *__restrict__ list, int n, int8_t *st, int xa, int np) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int d = list[t] / g.nyz - xa;
+    if (d < 0) d += g.nx;
+    if (d >= np) st[t] = 0;
+}
 // Decide v if its 16 bits allow it and tell the later listed neighbours; push(u) receives every voxel that became
 // decidable through this decision.  A voxel from the blanket scan of round 1 may not be decidable yet; one from
 // a queue always is.
@@ -803,7 +847,9 @@ __global__ void k_ec_restore(int8_t *known, const int *list, int n) {
     if (k == EC_PROC || k == EC_SKIP) known[list[t]] = -2;
 }
 // count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread and step, one atomic per block
-__global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges) {
+// (count_lo, count_hi): only the -3 voxels with a linear index in that range are counted (a slab counts its own planes)
+__global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges, long long count_lo,
+                                                   long long count_hi) {
     __shared__ unsigned int s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
@@ -815,12 +861,11 @@ __global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, u
             unsigned int c = 0;
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (b[k] == -3) { b[k] = -2; c++; }
+                if (b[k] == -3) { b[k] = -2; c++; cnt += (base + k >= count_lo) & (base + k < count_hi); }
             if (c) *reinterpret_cast<uint4 *>(known + base) = w;
-            cnt += c;
         } else {
             for (long long k = base; k < N; k++)
-                if (known[k] == -3) { known[k] = -2; cnt++; }
+                if (known[k] == -3) { known[k] = -2; cnt += (k >= count_lo && k < count_hi); }
         }
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);

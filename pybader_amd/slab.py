@@ -277,6 +277,26 @@ class SlabRunner:
         self.be.scatter_voxels(starts[sel], np.where(moved, new_lab, old)[sel], np.where(moved, -2, -1).astype(np.int8)[sel])
         return int(moved.sum()), int((~done).sum())
 
+    def _edge_check_slabs(self):
+        """refinement.edge_check (refinement.py:409-508) across slabs.  Its greedy scan is global -- whether a changed
+        voxel is processed depends on its C-order earlier changed neighbours, in chains that run through slab
+        boundaries -- but it only involves the changed voxels and one class bit each: every rank lists its owned
+        changed voxels with their class, the lists are all-gathered, and every rank resolves the global list with
+        the single-GPU kernels and applies the boxes that touch its own planes (xb_edge_check_local / _global)."""
+        with _Phase(self, 'label_halo'):
+            self.be.sync()
+            self.comm.exchange_planes(self.be, 0, self.sends, self.recvs)
+            self.comm.exchange_planes(self.be, 1, self.sends, self.recvs)     # the flags the retraces rewrote
+        with _Phase(self, 'edge_check'):
+            idx, cls = self.be.edge_check_local()
+            parts = self.comm.allgather((idx, cls))
+            gidx = np.concatenate([p[0] for p in parts])
+            gcls = np.concatenate([p[1] for p in parts])
+            _, edges = self.be.edge_check_global(gidx, gcls)
+        with _Phase(self, 'sums'):
+            edges, = self.comm.sum(edges)
+        return edges
+
     def refine(self, mode, iters):
         """thread_handlers.refine (thread_handlers.py:128-236) across slabs.  Returns [(edges, changed)]."""
         log = []
@@ -309,8 +329,7 @@ class SlabRunner:
             elif changed == 0:
                 edges = 0                      # no voxel is flagged -2: edge_check is the identity
             else:
-                raise NotImplementedError("'changed' refinement with relabelled voxels across slabs: "
-                                          "use mode 'all' or one GPU")
+                edges = self._edge_check_slabs()
             changed = self._trace()
             log.append((edges, changed))
             if changed == 0:

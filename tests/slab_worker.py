@@ -160,6 +160,30 @@ class OracleSlabBackend:
         import oracle
         return oracle.edge_check(self.known, self.rho, self.labels)
 
+    # 'changed' refinement across slabs.  The product resolves the all-gathered list of changed voxels on every rank
+    # (xb_edge_check_local / _global); this host stand-in checks the scheduler's choreography: it assembles the
+    # global arrays from every rank's owned planes (test-only shortcut through `self.comm`), runs the oracle's
+    # sequential edge_check on them and keeps the planes a slab may rely on -- everything else is poisoned again.
+    def edge_check_local(self):
+        mask = np.zeros(self.shape, bool)
+        mask[self.x0:self.x1] = True
+        idx = np.flatnonzero((self.known == -2) & mask).astype(np.int64)
+        return idx, np.zeros(idx.size, np.int8)
+
+    def edge_check_global(self, gidx, gcls):
+        import oracle
+        parts = self.comm.allgather((self.x0, self.x1, self.labels[self.x0:self.x1].copy(), self.known[self.x0:self.x1].copy()))
+        lab = np.concatenate([p[2] for p in sorted(parts, key=lambda p: p[0])])
+        kn = np.concatenate([p[3] for p in sorted(parts, key=lambda p: p[0])])
+        assert sorted(np.flatnonzero(kn == -2).tolist()) == sorted(np.asarray(gidx).tolist())
+        # the halo planes this rank holds must already equal their owners' (label + known halo refreshed before)
+        ok = self._planes(self.halo - 2)
+        assert np.array_equal(self.labels[ok], lab[ok]) and np.array_equal(self.known[ok] == -2, kn[ok] == -2)
+        checked, _ = oracle.edge_check(kn, self.rho, lab)
+        self.known[...] = 2
+        self.known[self.valid] = kn[self.valid]
+        return checked, int((kn[self.x0:self.x1] == -2).sum())
+
 
 def main():
     import torch.distributed as dist
@@ -179,6 +203,7 @@ def main():
     g = load_golden(case)
     rho = case_density(g)
     be = OracleSlabBackend(rho)
+    be.comm = comm
     runner = slab.SlabRunner(be, comm, rho.shape, g['dist_mat'], g['T_grad'], halo=halo)
     tol = float(g['vacuum_tol'])
     be.vacuum_assign(None if np.isnan(tol) else tol)

@@ -204,3 +204,23 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert two['n_gpus'] == 2 and 'host-staged-tcp' in two['config']['parallelism']
     assert two['config']['basins'] == one['config']['basins'] == 8
     assert two['config']['refine_log'] == one['config']['refine_log']
+
+
+@pytest.mark.parametrize('n,name,halo,iters', [(2, 'c64_cubic', 8, 2), (3, 'c40x48x56_tric', 6, 3), (4, 'c40x48x56_tric', 8, -1),
+                                               (4, 'c64_cubic', 4, 2)])
+def test_ongrid_plus_refine_changed_slabs(n, name, halo, iters):
+    """'changed' refinement with relabelled voxels across slabs: edge_check's global greedy scan resolved on every
+    rank from the all-gathered list (xb_edge_check_local / _global); logs and maps equal the one-GPU / oracle ones."""
+    import oracle
+    g = load_golden(name)
+    rho = case_density(g)
+    pre, post, log, maxima, ch, vo, fb = run_slabs(n, g, rho, 'ongrid', 'changed', iters, halo, tol_of(g))
+    assert np.array_equal(pre, g['og_main'].astype(np.int32))
+    v = g['og_main'].astype(np.int32)
+    olog = []
+    oracle.refine('neargrid', ('changed', iters), rho, v, g['dist_mat'], g['T_grad'], 1, log=olog)
+    assert any(c > 0 for _, c in olog[:1]), 'the case is meant to relabel voxels'
+    assert log == [tuple(x) for x in olog]
+    assert np.array_equal(post, v)
+    if iters == 2:
+        assert np.array_equal(post, g['og_ngrefine_changed_2'].astype(np.int32))

@@ -57,6 +57,7 @@ def test_merge_maxima_tables():
     (2, 'c48_cubic_vac', 'neargrid', 'changed', 2, 29613, 4),
     (2, 'c40x48x56_tric', 'ongrid', 'all', 3, 29614, 6),
     (3, 'c40x48x56_tric', 'ongrid', 'all', 3, 29615, 3),      # narrow halo: traces escape -> fallback
+    (3, 'c40x48x56_tric', 'ongrid', 'changed', 3, 29616, 6),  # relabelled voxels: edge_check across slabs
 ])
 def test_slabs_equal_single_rank_and_golden(n, case, method, mode, iters, port, halo, tmp_path):
     import oracle
