@@ -111,3 +111,40 @@ def test_trapping_regions_do_not_change_the_map(size, lattice):
     assert nv2 > nv1
     assert n0 == n2 and np.array_equal(max0, max2) and np.array_equal(lab0, lab2)
     ctx.close()
+
+
+def test_config4_1024_one_gpu_and_two_slabs():
+    """BASELINE config 4 (1024^3, axis-0 slabs) as far as one GPU carries it: the whole grid in one context (66.6 GB),
+    then two logical slabs of 512 planes on the same device (2 x 66.6 GB: eight do not fit 288 GB, every rank keeps
+    full-size arrays) -- properties of the map, and N-slab == 1-slab bit for bit (int8 labels, hashed)."""
+    import hashlib
+    from test_gpu_slabs import run_slabs
+    size = 1024
+    shape = (size,) * 3
+    dm, tg = matrices(shape, synth.CUBIC6)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    ctx.vacuum_assign(None, 1.0)
+    n = ctx.assign('neargrid')
+    maxima = ctx.maxima()
+    log = ctx.refine('changed', 2)
+    assert n == 8 and all(c == 0 for _, c in log) and log[0][0] > 0
+    ch, vo = ctx.charge_sum(1.0, n)
+    assert vo.sum() == float(size) ** 3 and np.all(vo > 0)
+    lab = ctx.download_labels(np.int8)
+    assert np.array_equal(lab[tuple(maxima.T)], np.arange(n))          # every maximum carries its own label
+    assert np.array_equal(np.bincount(lab.reshape(-1), minlength=n).astype(np.float64), vo)
+    first = np.array([int(np.argmax(lab.reshape(-1) == k)) for k in range(n)])
+    assert np.all(np.diff(first) > 0)                                   # numbered by first appearance in C order
+    sha = hashlib.sha256(lab).hexdigest()
+    del lab
+    ctx.close()
+    g = {'dist_mat': dm, 'T_grad': tg}
+    pre, post, slog, mx, ch2, vo2, fb = run_slabs(2, g, None, 'neargrid', 'changed', 2, 16, None, shape=shape,
+                                                  synth_args=(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND),
+                                                  label_dtype=np.int8, keep_pre=False, margin=32)
+    assert hashlib.sha256(np.ascontiguousarray(post)).hexdigest() == sha
+    assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
+    assert np.array_equal(vo2, vo) and np.allclose(ch2, ch, rtol=1e-12)
+    assert [tuple(x) for x in slog] == [tuple(x) for x in log]

@@ -63,7 +63,10 @@ class ThreadComm:
         self.sh.barrier.wait()
 
 
-def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True):
+def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None, synth_args=None, label_dtype=np.int32,
+              keep_pre=True, margin=8):
+    """rho=None + synth_args=(lattice, atoms, background): every context generates the density on the device"""
+    shape = rho.shape if rho is not None else tuple(shape)
     sh = Shared(n)
     res = [None] * n
 
@@ -71,15 +74,18 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True):
         try:
             ctx = _lib.Context(0)
             comm = ThreadComm(sh, rank)
-            runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), comm, rho.shape, g['dist_mat'], g['T_grad'], halo=halo)
-            win = runner.enable_table_window(8) if window else False
-            ctx.upload_density(rho)
+            runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), comm, shape, g['dist_mat'], g['T_grad'], halo=halo)
+            win = runner.enable_table_window(margin) if window else False
+            if rho is not None:
+                ctx.upload_density(rho)
+            else:
+                ctx.synth_density(*synth_args)
             ctx.vacuum_assign(tol, 1.0)
             nb = runner.assign(method)
             x0, x1 = runner.x_range
-            pre = ctx.download_labels(np.int32)[x0:x1].copy()
+            pre = ctx.download_labels(label_dtype)[x0:x1].copy() if keep_pre else np.zeros((0,) + tuple(shape[1:]), label_dtype)
             log = runner.refine(mode, iters)
-            post = ctx.download_labels(np.int32)[x0:x1].copy()
+            post = ctx.download_labels(label_dtype)[x0:x1].copy()
             ch, vo = ctx.charge_sum(1.0, nb)
             res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats())
             ctx.close()
