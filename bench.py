@@ -31,27 +31,44 @@ BYTES_ASSIGN = 12              # read rho f64 once + write int32
 BYTES_PATH = 25                # assign 12 + first refine sweep 13 (rho 8 + label 4 + known 1)
 
 
-def cpu_baseline(size, method, mode, iters, lattice, atoms, background):
-    """The CPU oracle (a faithful sequential port of the reference's threads=1 path) timed on this
-    host, on a bounded sample: the same atoms on a size^3 grid.  Reported, never the target."""
+def cpu_baseline(size, method, mode, iters, lattice, atoms, background, full_size):
+    """The CPU oracle (a C restatement of the reference, bit-identical to it on the golden vectors) timed on this host.
+    Two legs: (i) one core, the reference's threads=1 path, on a bounded `size`^3 sample of the workload; (ii) every
+    core of the box's CPU share, the reference's threads=N path -- factor_3d blocks, methods.neargrid per block,
+    merge, threaded refinement (oracle/bader_oracle_blocks.c, OpenMP over the blocks) -- on the configuration's own
+    `full_size`^3 grid.  Reported, never the target."""
     import oracle
     from pybader_amd.interface import distance_matrix, gradient_transform
-    shape = (size,) * 3
-    rho = oracle.synth_density(shape, lattice, atoms, background)
-    vl = np.divide(lattice, shape)
-    dm, tg = distance_matrix(vl), gradient_transform(vl)
-    vol = np.zeros(shape, np.int32)
-    t0 = time.perf_counter()
-    vol, _, _ = oracle.vacuum_assign(rho, vol, float('nan'), rho, 1.0)
-    bmax, main = oracle.bader_calc(method, rho, vol, dm, tg, 1)
-    t1 = time.perf_counter()
-    oracle.refine('neargrid', (mode, iters), rho, main, dm, tg, 1)
-    t2 = time.perf_counter()
-    n = float(size) ** 3
-    return {'value': n / (t2 - t0) / 1e6, 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{size}^3 grid, same 8 atoms/cell, {method} assign + refine ({mode},{iters}), '
-                      f'assign {t1 - t0:.2f}s + refine {t2 - t1:.2f}s, single thread C port of the numba path',
-            'assign_mvox_s': n / (t1 - t0) / 1e6}, (rho, dm, tg, main, bmax)
+
+    def run(n, threads):
+        shape = (n,) * 3
+        rho = oracle.synth_density(shape, lattice, atoms, background)
+        vl = np.divide(lattice, shape)
+        dm, tg = distance_matrix(vl), gradient_transform(vl)
+        vol = np.zeros(shape, np.int32)
+        t0 = time.perf_counter()
+        vol, _, _ = oracle.vacuum_assign(rho, vol, float('nan'), rho, 1.0)
+        bmax, main = oracle.bader_calc(method, rho, vol, dm, tg, threads, workers=threads)
+        t1 = time.perf_counter()
+        oracle.refine('neargrid', (mode, iters), rho, main, dm, tg, threads, workers=threads)
+        t2 = time.perf_counter()
+        return float(n) ** 3, t1 - t0, t2 - t1, (rho, dm, tg, main, bmax)
+
+    nvox, ta, tr, sample = run(size, 1)
+    out = {'value': nvox / (ta + tr) / 1e6, 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{size}^3 grid, same 8 atoms/cell, {method} assign + refine ({mode},{iters}), '
+                     f'assign {ta:.2f}s + refine {tr:.2f}s, single thread C port of the numba path (threads=1)',
+           'assign_mvox_s': nvox / ta / 1e6}
+    cores = min(16, len(os.sched_getaffinity(0)))          # the box's CPU share for one GPU
+    if method == 'neargrid' and cores > 1:
+        nvox, ta, tr, _ = run(full_size, cores)
+        out['single_core'] = {k: out[k] for k in ('value', 'cores', 'sample', 'assign_mvox_s')}
+        out.update({'value': nvox / (ta + tr) / 1e6, 'cores': cores, 'assign_mvox_s': nvox / ta / 1e6,
+                    'sample': f'{full_size}^3 grid (the configuration itself), {method} assign + refine ({mode},{iters}), '
+                              f'assign {ta:.2f}s + refine {tr:.2f}s, C port of the reference\'s threads={cores} path '
+                              f'(factor_3d blocks {oracle.factor_3d(cores)}, OpenMP over the blocks; edge_find / edge_check '
+                              'sequential as in the reference)'})
+    return out, sample
 
 
 def traffic_from_profile(kernel, method):
@@ -120,6 +137,7 @@ def main():
     ap.add_argument('--refine', default='changed:2')
     ap.add_argument('--cpu-size', type=int, default=320)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-config5', action='store_true', help='skip the ongrid configuration timed after the headline one')
     ap.add_argument('--halo', type=int, default=None,
                     help='label planes valid each side of a slab (default 64 for N > 1: retraces glide along the '
                          'dividing surfaces for tens of planes; the rest is finished by remote path queries)')
@@ -261,6 +279,30 @@ def main():
                      'stage_ms_avg': avg},
     }
 
+    # BASELINE config 5 (ongrid assign + neargrid edge refinement, the divergent-path stress case) in the same run, so
+    # that it is driver-timed too: same grid, same density, K steps, its own HIP-event stage times
+    if world == 1 and args.method == 'neargrid' and not args.no_config5:
+        def step5():
+            ctx.set_option(6, 1)
+            ctx.vacuum_assign(None, voxel_volume)
+            n5 = runner.assign('ongrid')
+            return n5, runner.refine(mode, iters)
+        step5()
+        ctx.kernel_time_reset()
+        fence()
+        t5 = time.perf_counter()
+        for _ in range(args.steps):
+            n5, log5 = step5()
+        fence()
+        dt5 = (time.perf_counter() - t5) / args.steps
+        tm5 = {name: ctx.kernel_time(i) for i, name in enumerate(
+            ['-', 'k_og_pointer_tiled', 'edge_find', 'k_refine_trace', 'table_for_retraces(k_grad_field)', 'k_grad_field'])}
+        out['config5'] = {'workload': f'{args.size}^3 same density, ongrid assign + neargrid edge refinement {mode}:{iters}',
+                          'value': nvox / dt5 / 1e6, 'unit': 'Mvoxels/s', 'ms_per_step': dt5 * 1e3, 'steps': args.steps,
+                          'basins': int(n5), 'refine_log': log5,
+                          'whole_path_frac_of_hbm_roofline': BYTES_PATH * nvox / dt5 / 1e9 / HBM_PEAK_GBS,
+                          'stage_ms_avg': {k: (ms / n if n else 0.0) for k, (ms, n) in tm5.items() if k != '-'}}
+
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
     out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
     out['config']['refine_escape_fallbacks'] = runner.n_fallbacks
@@ -268,7 +310,7 @@ def main():
         out['config']['slab_phase_ms_avg'] = {k: v / args.steps * 1e3 for k, v in runner.timing.items()}
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, (rho_s, dm_s, tg_s, want, bmax) = cpu_baseline(args.cpu_size, args.method, mode, iters,
-                                                           lattice, atoms, background)
+                                                           lattice, atoms, background, args.size)
         # the same sample through the GPU path doubles as an end-of-run parity check
         c2 = _lib.Context(0)
         c2.set_grid(rho_s.shape, dm_s, tg_s)

@@ -24,8 +24,8 @@ _i8p = np.ctypeslib.ndpointer(np.int8, flags='C_CONTIGUOUS')
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    src = os.path.join(_HERE, 'bader_oracle.c')
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ('bader_oracle.c', 'bader_oracle_blocks.c', 'Makefile')]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(['make', '-s', '-C', _HERE])
     return _SO
 
@@ -69,6 +69,15 @@ def lib():
         L.orc_synth_density.argtypes = [_i64p, _f64p, _f64p, C.c_int64, C.c_double, _f64p]
         L.orc_free.restype = None
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_factor_3d.restype = None
+        L.orc_factor_3d.argtypes = [C.c_int64, _i64p]
+        L.orc_block_table.restype = C.c_int64
+        L.orc_block_table.argtypes = [_i64p, C.c_int64, _i64p, _i64p, C.c_int64]
+        L.orc_bader_calc_blocks.restype = C.c_int64
+        L.orc_bader_calc_blocks.argtypes = [_f64p, _i64p, _i32p, _f64p, _f64p, C.c_int64, C.c_int64, pp]
+        L.orc_refine_neargrid_blocks.restype = C.c_int64
+        L.orc_refine_neargrid_blocks.argtypes = [_i8p, _i8p, _f64p, _i64p, _i32p, _f64p, _f64p, C.c_int64, C.c_int64]
+        L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
 
@@ -98,14 +107,39 @@ def dtype_calc(max_val):
     return names[3]
 
 
-def bader_calc(method, density, volumes, dist_mat, T_grad, threads=1):
-    """thread_handlers.bader_calc for threads in {0,1} (thread_handlers.py:15-75):
-    kernel -> volume_offset -> dtype narrowing.  Returns (bader_max int64[N,3], volumes)."""
-    assert threads in (0, 1), "the sequential oracle restates the single-block path only"
+def factor_3d(x):
+    """utils.factor_3d (utils.py:283-317)"""
+    out = np.zeros(3, np.int64)
+    lib().orc_factor_3d(int(x), out)
+    return tuple(int(v) for v in out)
+
+
+def block_table(shape, threads):
+    """the thread blocks of thread_handlers.py:28-47: (origins int64[n,3], shapes int64[n,3]) in submission order"""
+    sh = np.array(shape, np.int64)
+    cap = max(1, int(threads)) * 8 + 8
+    idx, ln = np.zeros((cap, 3), np.int64), np.zeros((cap, 3), np.int64)
+    n = lib().orc_block_table(sh, int(threads), idx.reshape(-1), ln.reshape(-1), cap)
+    return idx[:n].copy(), ln[:n].copy()
+
+
+def bader_calc(method, density, volumes, dist_mat, T_grad, threads=1, workers=0):
+    """thread_handlers.bader_calc (thread_handlers.py:15-75): kernel -> volume_offset -> merge -> dtype narrowing.
+    threads in {0,1}: one block.  threads > 1 (neargrid): the factor_3d block split with the blocks merged in
+    submission order (see bader_oracle_blocks.c), run by `workers` OpenMP threads (0: one per block).
+    Returns (bader_max int64[N,3], volumes)."""
     L = lib()
     rho = _c(density, np.float64)
     vol = _c(volumes, np.int32).copy()
     out = C.POINTER(C.c_int64)()
+    if threads > 1:
+        if method != 'neargrid':
+            raise NotImplementedError('the block path is restated for neargrid (the headline method) only')
+        n = L.orc_bader_calc_blocks(rho, _shape(rho), vol.reshape(-1), _c(dist_mat, np.float64), _c(T_grad, np.float64),
+                                    int(threads), int(workers), C.byref(out))
+        bader_max = np.ctypeslib.as_array(out, shape=(n, 3)).copy() if n else np.zeros((0, 3), np.int64)
+        L.orc_free(out)
+        return bader_max, vol.astype(dtype_calc(-n))
     if method == 'ongrid':
         n = L.orc_ongrid(rho, _shape(rho), vol, _c(dist_mat, np.float64), C.byref(out))
     elif method == 'neargrid':
@@ -132,24 +166,26 @@ def edge_check(known, density, volumes):
     return a.value, b.value
 
 
-def refine_neargrid(known, rknown, density, volumes, dist_mat, T_grad):
-    """refinement.neargrid (refinement.py:17-322); `known` and `volumes` (any int dtype) in place."""
+def refine_neargrid(known, rknown, density, volumes, dist_mat, T_grad, threads=1, workers=0):
+    """refinement.neargrid (refinement.py:17-322); `known` and `volumes` (any int dtype) in place.  threads > 1:
+    over the blocks of thread_handlers.refine (thread_handlers.py:154-205), `workers` OpenMP threads."""
     assert known.dtype == np.int8 and known.flags.c_contiguous
     vol = _c(volumes, np.int32)
-    if vol is volumes:
-        ch = lib().orc_refine_neargrid(known, _c(rknown, np.int8), _c(density, np.float64), _shape(density),
-                                       vol, _c(dist_mat, np.float64), _c(T_grad, np.float64))
-    else:
+    copy = vol is not volumes
+    if copy:
         vol = vol.copy()
-        ch = lib().orc_refine_neargrid(known, _c(rknown, np.int8), _c(density, np.float64), _shape(density),
-                                       vol, _c(dist_mat, np.float64), _c(T_grad, np.float64))
+    args = (known, _c(rknown, np.int8), _c(density, np.float64), _shape(density), vol, _c(dist_mat, np.float64),
+            _c(T_grad, np.float64))
+    ch = lib().orc_refine_neargrid_blocks(*args, int(threads), int(workers)) if threads > 1 else lib().orc_refine_neargrid(*args)
+    if copy:
         volumes[...] = vol
     return int(ch)
 
 
-def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads=1, log=None):
-    """thread_handlers.refine for threads in {0,1} (thread_handlers.py:128-236).  In place; returns
-    None like the reference.  `log` (a list) receives (edges, changed) per iteration."""
+def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads=1, log=None, workers=0):
+    """thread_handlers.refine (thread_handlers.py:128-236).  In place; returns None like the reference.  `log` (a
+    list) receives (edges, changed) per iteration.  threads > 1: the retraces run over the reference's blocks
+    (edge_find / edge_check stay sequential, as in the reference)."""
     if method != 'neargrid':      # getattr(refinement, method) AttributeError -> silent return
         return
     check_mode, iters = tuple(refine_mode)
@@ -159,7 +195,7 @@ def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads=1, l
     edges = edge_find(known, density, volumes)
     if edges == 0:
         return
-    changed = refine_neargrid(known, known.copy(), density, volumes, dist_mat, T_grad)
+    changed = refine_neargrid(known, known.copy(), density, volumes, dist_mat, T_grad, threads, workers)
     if log is not None:
         log.append((edges, changed))
     if iters < 0:
@@ -171,7 +207,7 @@ def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads=1, l
             edges = edge_find(known, density, volumes)
         else:
             _, edges = edge_check(known, density, volumes)
-        changed = refine_neargrid(known, known.copy(), density, volumes, dist_mat, T_grad)
+        changed = refine_neargrid(known, known.copy(), density, volumes, dist_mat, T_grad, threads, workers)
         if log is not None:
             log.append((edges, changed))
         if changed == 0:

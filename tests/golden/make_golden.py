@@ -323,6 +323,48 @@ def trajectory_vectors(name='traj_vectors', shape=(20, 18, 22), n_starts=400, n_
     print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
+def run_threads_case(name='threads_blocks'):
+    """The reference's threads > 1 path (thread_handlers.py:15-75, 128-236): factor_3d block split, methods.neargrid
+    per block with the block-extension branches, volume_offset / volume_merge / array_merge / edge_assign, then the
+    threaded refinement.  The reference merges blocks in COMPLETION order, which makes its numbering depend on thread
+    timing; here `as_completed` is replaced by submission order (a deterministic schedule of the same code), which is
+    what oracle/bader_oracle_blocks.c restates."""
+    t0 = time.time()
+    thread_handlers.as_completed = lambda fs: list(fs)        # dict of futures -> submission order; .result() waits
+    out = {}
+    cases = {'c12_cubic': [2, 4, 8], 'c40x48x56_tric': [2, 3, 6, 8], 'c48_cubic_vac': [4, 12], 'r40_noise04': [5, 8]}
+    out['cases_json'] = np.array(json.dumps(cases))
+    with nostdout():
+        for cname, tlist in cases.items():
+            if cname in CASES:
+                kw = CASES[cname]
+                lattice = np.asarray(kw['lattice'], np.float64)
+                rho = synth.synth_density(kw['shape'], lattice, synth.ATOMS8)
+                tol = kw.get('vacuum_tol')
+            else:
+                kw = ROUGH[cname]
+                lattice = np.asarray(kw['lattice'], np.float64)
+                rho = synth.rough_density(kw['shape'], lattice, synth.ATOMS8, noise=kw.get('noise', 0.), sig_digits=kw.get('sig_digits'),
+                                          quantum=kw.get('quantum'))
+                tol = kw.get('vacuum_tol')
+            atoms_cart = synth.atoms_cartesian(synth.ATOMS8, lattice)
+            out[cname + '_rho_sha256'] = np.array(sha(rho))
+            for t in tlist:
+                b = make_bader(rho, lattice, atoms_cart, vacuum_tol=tol)
+                b.threads = t
+                b.volumes_init()
+                b.bader_calc()
+                key = f'{cname}_t{t}'
+                out[key + '_main'] = b.bader_volumes.copy()
+                out[key + '_max'] = np.rint(b.bader_maxima_fractional * np.array(rho.shape)).astype(np.int64)
+                b.refine_mode = ('changed', 2)
+                b.refine_volumes(b.bader_volumes)
+                out[key + '_changed_2'] = b.bader_volumes.copy()
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 CASES = {
     # G6: tiny hand-checkable
     'c12_cubic': dict(shape=(12, 12, 12), lattice=synth.CUBIC6),
@@ -354,12 +396,14 @@ ROUGH = {
 
 if __name__ == '__main__':
     # warm the JIT on a tiny grid first
-    which = sys.argv[1:] or ['tables', 'traj_vectors'] + list(CASES) + list(ROUGH)
+    which = sys.argv[1:] or ['tables', 'traj_vectors', 'threads_blocks'] + list(CASES) + list(ROUGH)
     for name in which:
         if name == 'tables':
             tables()
         elif name == 'traj_vectors':
             trajectory_vectors()
+        elif name == 'threads_blocks':
+            run_threads_case()
         elif name in ROUGH:
             run_rough_case(name, **ROUGH[name])
         else:
