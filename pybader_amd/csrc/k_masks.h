@@ -119,36 +119,52 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
     const bool need = (K == 0 && !xl) || (K == GT_X - 1 && !xh) || (ty == 0 && !yl) || (ty == 7 && !yh) ||
                       (zz == 0 && !zl) || (zz == 7 && !zh) || !not_max;
     bool is_max = false;
-#ifdef BM_NO_OG
-    if (false) {
-#else
     if (__any(need && in)) {
-#endif
-        // methods.py:87-117: strict '>' first-wins scan in (ix,iy,iz) ascending order
-        double max_val = c;
-        int og = XB_OG_SELF;
+        // methods.py:87-117 picks the FIRST neighbour (ix,iy,iz ascending) whose weighted value w = fl(fl((rho_n - c) d_n) + c)
+        // is the largest and > c.  Only two things are needed of it here: whether any w exceeds c (else the voxel is a
+        // maximum), and whether the pick can lie in a face plane of the 3x3x3 box.  fl(. + c) is monotone, so the largest w
+        // of a set of neighbours is fl(max p + c) with p = fl((rho_n - c) d_n): one subtraction and one multiplication
+        // per neighbour, maxima per z-line, per plane and overall, and the final addition for the few maxima only.  A
+        // plane "can hold the pick" iff its largest w is > c and equals the overall largest (on an exact tie with a
+        // neighbour outside the plane the reference takes whichever comes first: counted as a crossing, a superset).
+        double pz[3][3][3];
 #pragma unroll
         for (int ix = 0; ix < 3; ix++)
 #pragma unroll
             for (int iy = 0; iy < 3; iy++)
 #pragma unroll
-                for (int iz = 0; iz < 3; iz++) {
-                    if (ix == 1 && iy == 1 && iz == 1) continue;   // (c - c) * d + c is never > c
-                    double w = a[ix][iy][iz];
-                    w = (w - c) * dist_at(g, ix, iy, iz);
-                    w += c;
-                    og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
-                    max_val = fmax(max_val, w);
+                for (int iz = 0; iz < 3; iz++)
+                    if (!(ix == 1 && iy == 1 && iz == 1)) pz[ix][iy][iz] = (a[ix][iy][iz] - c) * dist_at(g, ix, iy, iz);
+        double line[3][3];   // per (ix,iy): max over iz
+#pragma unroll
+        for (int ix = 0; ix < 3; ix++)
+#pragma unroll
+            for (int iy = 0; iy < 3; iy++)
+                line[ix][iy] = (ix == 1 && iy == 1) ? fmax(pz[1][1][0], pz[1][1][2]) : fmax(fmax(pz[ix][iy][0], pz[ix][iy][1]), pz[ix][iy][2]);
+        const double ax0 = fmax(fmax(line[0][0], line[0][1]), line[0][2]);
+        const double ax1 = fmax(fmax(line[1][0], line[1][1]), line[1][2]);
+        const double ax2 = fmax(fmax(line[2][0], line[2][1]), line[2][2]);
+        const double pm = fmax(fmax(ax0, ax1), ax2);
+        const double wm = pm + c;
+        is_max = !(wm > c);
+        const bool some = wm > c;
+        if (K == 0) xl |= some && (ax0 + c) == wm;
+        if (K == GT_X - 1) xh |= some && (ax2 + c) == wm;
+        {
+            const double ay0 = fmax(fmax(line[0][0], line[1][0]), line[2][0]), ay2 = fmax(fmax(line[0][2], line[1][2]), line[2][2]);
+            yl |= ty == 0 && some && (ay0 + c) == wm;
+            yh |= ty == 7 && some && (ay2 + c) == wm;
+            double az0 = pz[0][0][0], az2 = pz[0][0][2];
+#pragma unroll
+            for (int ix = 0; ix < 3; ix++)
+#pragma unroll
+                for (int iy = 0; iy < 3; iy++) {
+                    az0 = fmax(az0, pz[ix][iy][0]);
+                    az2 = fmax(az2, pz[ix][iy][2]);
                 }
-        is_max = og == XB_OG_SELF;
-        // og = ix*9 + iy*3 + iz: ix == 0 <=> og < 9, ix == 2 <=> og >= 18, ...
-        const int oyz = og % 9, oz = og % 3;
-        if (K == 0) xl |= og < 9;
-        if (K == GT_X - 1) xh |= og >= 18;
-        yl |= ty == 0 && oyz < 3;
-        yh |= ty == 7 && oyz >= 6;
-        zl |= zz == 0 && oz == 0;
-        zh |= zz == 7 && oz == 2;
+            zl |= zz == 0 && some && (az0 + c) == wm;
+            zh |= zz == 7 && some && (az2 + c) == wm;
+        }
     }
     if (in) {
         if (is_max) {
