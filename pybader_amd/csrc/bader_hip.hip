@@ -567,8 +567,9 @@ static int read_counter(xb_ctx *c, int idx, int *out);
 static GridL light(const Grid &g);
 
 // layout of the small device int buffer used by the table build (c->boxbuf)
-enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 4352, BB_BOXMAX = 4608, BB_EXT = 5632, BB_BAD = 8192,
-       BB_TOTAL = 1 << 20, XB_BOX_SEEDS_MAX = 64 };
+// (up to XB_BOX_SEEDS_MAX seed cubes: a cell with hundreds of atoms keeps its trapping regions)
+enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 7168, BB_BOXMAX = 8192, BB_EXT = 9216, BB_BAD = 16384,
+       BB_TOTAL = 1 << 20, XB_BOX_SEEDS_MAX = 1023 /* box ids fit the 10 key bits */ };
 
 // (re)build the gradient-field table from the resident density; with `boxes`, also find and stamp
 // the trapping boxes around the 26-neighbour maxima (k_box_scan)
@@ -1055,10 +1056,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
     int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
     int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP, *box_max = c->boxbuf + BB_BOXMAX,
-        *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * 64, *box_first = c->boxbuf + BB_EXT + 4 * 64, *bad = c->boxbuf + BB_BAD;
+        *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * XB_BOXES_MAX, *box_first = c->boxbuf + BB_EXT + 4 * XB_BOXES_MAX,
+        *bad = c->boxbuf + BB_BAD;
     const int stride = XB_BOX_K + 4;
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
-    HIPCHK(hipMemsetAsync(bad, 0, (size_t)64 * stride * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));
     if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
         k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
         HIPCHK(hipGetLastError());
@@ -1094,19 +1096,19 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         c->grad_rule = 1;
         c->grad_cover = sparse ? 1 : 0;
         // closed seed cubes around the maxima, then brick growth -- all decided on the device
-        k_box_setup<<<1, 64, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
+        k_box_setup<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
         const long long wmax = 2LL * XB_BOX_K + 1;
         if (sparse)   // no record exists yet: the shells derive their move intervals from rho
             k_box_shells_dev<true><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
         else
             k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
-        k_box_pick<<<1, 64, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
+        k_box_pick<<<1, XB_BOXES_MAX, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
         k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
         const int launches = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG);
-        k_fill<int><<<1, 64, 0, c->stream>>>(box_first, XB_INT_MAX, 64);
+        k_fill<int><<<1, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_BOXES_MAX);
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -1137,7 +1139,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
                                                                 fs + FS_N_MAX, c->max_cap);
         else {
-            k_note_regions<<<1, 64, 0, c->stream>>>(gl, nb1, nb2, fs, box_first, box_max, c->first, c->max_list, fs + FS_N_MAX, c->max_cap);
+            k_note_regions<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, nb1, nb2, fs, box_first, box_max, c->first, c->max_list, fs + FS_N_MAX, c->max_cap);
             c->regions_pending = true;
         }
         {

@@ -40,11 +40,13 @@ enum {
 
 // seeds (unsorted, appended atomically by the table pass) -> sorted seeds, their coordinates and the largest
 // radius each cube may take (stay clear of the nearest other maximum; a cube must not wrap onto itself)
-__global__ __launch_bounds__(64) void k_box_setup(GridL g, int *fs, int *seeds, int seed_cap, int max_seeds, int *mxyz, int *rcap) {
-    __shared__ int s[64];
+// (one block of XB_BOXES_MAX threads: a cell with hundreds of atoms has hundreds of maxima)
+#define XB_BOXES_MAX 1024
+__global__ __launch_bounds__(XB_BOXES_MAX) void k_box_setup(GridL g, int *fs, int *seeds, int seed_cap, int max_seeds, int *mxyz, int *rcap) {
+    __shared__ int s[XB_BOXES_MAX];
     const int t = threadIdx.x;
     int ns = fs[FS_N_SEEDS];
-    if (ns < 1 || ns > max_seeds || ns > seed_cap || ns > 64) ns = 0;
+    if (ns < 1 || ns > max_seeds || ns > seed_cap || ns > XB_BOXES_MAX) ns = 0;
     const int mine = t < ns ? seeds[t] : XB_INT_MAX;
     int rank = 0;
     if (t < ns) s[t] = mine;
@@ -95,10 +97,10 @@ __global__ __launch_bounds__(TPB) void k_box_shells_dev(Grid g, const double *__
     }
 }
 // the largest closed radius per seed; seeds with one become boxes (ids in seed order)
-__global__ __launch_bounds__(64) void k_box_pick(int *fs, const int *__restrict__ seeds, const int *__restrict__ mxyz,
+__global__ __launch_bounds__(XB_BOXES_MAX) void k_box_pick(int *fs, const int *__restrict__ seeds, const int *__restrict__ mxyz,
                                                  const int *__restrict__ rcap, const int *__restrict__ bad, int stride,
                                                  int *box_max, int *bx, int *br) {
-    __shared__ int best[64];
+    __shared__ int best[XB_BOXES_MAX];
     const int ns = fs[FS_N_SEEDS_EFF];
     const int t = threadIdx.x;
     if (t < ns) {
@@ -209,10 +211,10 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
 __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restrict__ seed, const int *__restrict__ buf0,
                                                      const int *__restrict__ buf1, int *fs, int *__restrict__ blab,
                                                      int *box_first, const int *__restrict__ bmask, unsigned char *brick_rec) {
-    __shared__ int s_first[64];
+    __shared__ int s_first[XB_BOXES_MAX];
     const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
     const int nbx = fs[FS_N_BOXES];
-    if (threadIdx.x < 64) s_first[threadIdx.x] = XB_INT_MAX;
+    for (int i = threadIdx.x; i < XB_BOXES_MAX; i += TPB) s_first[i] = XB_INT_MAX;
     __syncthreads();
     int cnt = 0;
     for (int b = blockIdx.x * TPB + threadIdx.x; b < nbr; b += gridDim.x * TPB) {
@@ -220,16 +222,17 @@ __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restr
         blab[b] = l;
         if (brick_rec) brick_rec[b] = (unsigned char)(((bmask[b] >> 27) & 1) << 1);   // no records yet; bit 1: holds a maximum
         cnt += (l > 0);
-        if (l > 0 && l <= 64 && s_first[l - 1] > b) atomicMin(&s_first[l - 1], b);
+        if (l > 0 && l <= XB_BOXES_MAX && s_first[l - 1] > b) atomicMin(&s_first[l - 1], b);
     }
     __syncthreads();
-    if (threadIdx.x < 64 && s_first[threadIdx.x] != XB_INT_MAX) atomicMin(&box_first[threadIdx.x], s_first[threadIdx.x]);
+    for (int i = threadIdx.x; i < XB_BOXES_MAX; i += TPB)
+        if (s_first[i] != XB_INT_MAX) atomicMin(&box_first[i], s_first[i]);
     int total;
     block_scan_excl(cnt, total);
     if (threadIdx.x == 0 && total) atomicAdd(&fs[FS_N_CERTAIN], total);
 }
 // one note per region (replaces a note per certain brick)
-__global__ __launch_bounds__(64) void k_note_regions(GridL g, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ box_first,
+__global__ __launch_bounds__(XB_BOXES_MAX) void k_note_regions(GridL g, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ box_first,
                                                      const int *__restrict__ box_max, int *first, int *max_list, int *max_count,
                                                      int max_cap) {
     const int t = threadIdx.x;

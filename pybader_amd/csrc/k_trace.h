@@ -109,14 +109,14 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions4_3d(GridL g, int *label
     }
 }
 // Brick-shaped version: a thread owns the 8 y-rows of one brick at one (x, z/4): ONE brick-label lookup (through a
-// per-block LDS table of the <= 64 region ranks) for 8 16-byte stores; a block covers 4 x-planes x 256 voxels of z.
+// per-block LDS table of the region ranks) for 8 16-byte stores; a block covers 4 x-planes x 256 voxels of z.
 __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *labels, const int *__restrict__ rank,
                                                                const int *__restrict__ blab, int nb1, int nb2,
                                                                const int *__restrict__ box_max, const int *__restrict__ fs,
                                                                const int *gate) {
-    __shared__ int s_rank[64];
+    __shared__ int s_rank[XB_BOXES_MAX];
     if (gate && !*gate) return;
-    if (threadIdx.x < 64) s_rank[threadIdx.x] = threadIdx.x < fs[FS_N_BOXES] ? rank[box_max[threadIdx.x]] : 0;
+    for (int i = threadIdx.x; i < fs[FS_N_BOXES]; i += TPB) s_rank[i] = rank[box_max[i]];
     __syncthreads();
     const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = blockIdx.z * 4 + (threadIdx.x >> 6);
     if (z >= g.nz || x >= g.nx) return;

@@ -148,3 +148,31 @@ def test_config4_1024_one_gpu_and_two_slabs():
     assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
     assert np.array_equal(vo2, vo) and np.allclose(ch2, ch, rtol=1e-12)
     assert [tuple(x) for x in slog] == [tuple(x) for x in log]
+
+
+def test_many_atoms_keep_their_trapping_regions():
+    """A cell with 216 atoms (more than the 64 seed cubes round 1 allowed): the trapping regions are built and the map
+    equals the plain full-trajectory trace; one more case with more maxima than seed cubes can be (plain tracing)."""
+    rng = np.random.default_rng(5)
+    k = 6
+    cells = np.stack(np.meshgrid(*(np.arange(k),) * 3, indexing='ij'), -1).reshape(-1, 3)
+    frac = (cells + 0.5 + 0.18 * (rng.random(cells.shape) - 0.5)) / k
+    atoms = np.concatenate([frac, 0.09 + 0.04 * rng.random((len(frac), 1)), 2.0 + 6.0 * rng.random((len(frac), 1))], 1)
+    shape = (256,) * 3
+    lattice = synth.CUBIC6
+    dm, tg = matrices(shape, lattice)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(lattice, atoms, synth.BACKGROUND)
+    out = []
+    for opt in (0, 3):                        # plain tracing / cubes + brick growth
+        ctx.set_option(1, opt)
+        ctx.vacuum_assign(None, 1.0)
+        n = ctx.assign('neargrid')
+        out.append((n, ctx.maxima(), ctx.download_labels(np.int32), ctx.box_stats()))
+    (n0, m0, l0, s0), (n1, m1, l1, s1) = out
+    assert n0 == n1 and n0 >= len(atoms) and np.array_equal(m0, m1) and np.array_equal(l0, l1)
+    assert s0 == (0, 0) and s1[0] > 64 and s1[1] > 0.3 * 256 ** 3, s1   # basins of ~5 bricks: about half the voxels
+    log = ctx.refine('changed', 2)
+    assert all(c == 0 for _, c in log) and np.array_equal(ctx.download_labels(np.int32), l1)
+    ctx.close()
