@@ -55,6 +55,8 @@ class Bader:
         self.threads = 1
         self.speed_flag = False
         self.spin_flag = False
+        self.export_mode = None
+        self.fortran_format = 0
         for k, v in kwargs.items():
             setattr(self, k, v)
 
@@ -198,3 +200,36 @@ class Bader:
             del self.bader_volumes
         self.min_surface_distance()
         self.sum_volumes()
+        self.export_volumes()
+
+    def export_volumes(self):
+        """The export loop of Bader.__call__ (interface.py:417-436): `export_mode` = ('volumes' | 'atoms', [numbers]),
+        [-2] meaning every volume / atom (and the vacuum when a tolerance is set)."""
+        if self.export_mode is None:
+            return
+        kind, which = self.export_mode[0], list(self.export_mode[1])
+        if kind not in ('volumes', 'atoms'):
+            return
+        if which[0] == -2:
+            which = list(range(self.bader_maxima.shape[0] if kind == 'volumes' else self.atoms.shape[0]))
+            if self.vacuum_tol is not None:
+                which.append(-1)
+        for vol_num in which:
+            self.write_volume(vol_num)
+
+    def write_volume(self, vol_num):
+        """Bader.write_volume (interface.py:600-621): the charge (and spin) density of one Bader volume or atom, zero
+        elsewhere (utils.volume_mask on the GPU), handed to the file type's own writer (`info['write_function']`,
+        pybader.io untouched)."""
+        from .utils import volume_mask
+        density = {}
+        volumes = self.bader_volumes if self.export_mode[0] == 'volumes' else self.atoms_volumes
+        if self.charge is not None:
+            density['charge'] = volume_mask(volumes, self.charge, vol_num)
+        if self.spin is not None:
+            density['spin'] = volume_mask(volumes, self.spin, vol_num)
+        num = vol_num if vol_num != -1 else 'vacuum'
+        self._file_info['comment'] = f"Bader {self.export_mode[0]}: {num}\n"
+        self._file_info['fortran_format'] = self.fortran_format
+        self.info['write_function'](f"Bader-{self.export_mode[0]}-{num}", self.atoms, self.lattice, density, self.info,
+                                    prefix=self.info['prefix'])

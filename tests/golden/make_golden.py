@@ -323,6 +323,39 @@ def trajectory_vectors(name='traj_vectors', shape=(20, 18, 22), n_starts=400, n_
     print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
+def run_export_case(name='export_volumes'):
+    """Bader.write_volume / the export loop of Bader.__call__ (interface.py:417-436, 600-621) with a capturing
+    write_function: file names, comments and sha256 of the masked densities."""
+    t0 = time.time()
+    out = {}
+    for cname, kw_b, mode in (('c40x48x56_tric', {}, ('volumes', [0, 3])), ('c40x48x56_tric', {}, ('atoms', [-2])),
+                              ('c48_cubic_vac', {'vacuum_tol': 0.03}, ('volumes', [-2]))):
+        kw = CASES[cname]
+        lattice = np.asarray(kw['lattice'], np.float64)
+        rho = synth.synth_density(kw['shape'], lattice, synth.ATOMS8)
+        spin = np.ascontiguousarray(rho[::-1] * 0.25)
+        calls = []
+
+        def capture(fname, atoms, lat, density, info, prefix='', **k):
+            calls.append((fname, info['comment'], info['fortran_format'], sha(density['charge']), sha(density['spin']),
+                          float(density['charge'].sum())))
+        info = {'filename': 'synth', 'prefix': '', 'file_type': 'synthetic', 'write_function': capture,
+                'voxel_offset': np.zeros(3), 'out_dest': os.devnull}
+        b = Bader({'charge': rho, 'spin': spin}, lattice, synth.atoms_cartesian(synth.ATOMS8, lattice), info, threads=1, **kw_b)
+        b.export_mode = mode
+        b.fortran_format = 2
+        with nostdout():
+            try:
+                b()
+            except AttributeError:       # to_file() cannot pickle the capturing writer; the export loop has run by then
+                pass
+        key = f'{cname}_{mode[0]}_{mode[1][0]}'
+        out[key] = np.array(json.dumps(calls))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 def run_threads_case(name='threads_blocks'):
     """The reference's threads > 1 path (thread_handlers.py:15-75, 128-236): factor_3d block split, methods.neargrid
     per block with the block-extension branches, volume_offset / volume_merge / array_merge / edge_assign, then the
@@ -396,7 +429,7 @@ ROUGH = {
 
 if __name__ == '__main__':
     # warm the JIT on a tiny grid first
-    which = sys.argv[1:] or ['tables', 'traj_vectors', 'threads_blocks'] + list(CASES) + list(ROUGH)
+    which = sys.argv[1:] or ['tables', 'traj_vectors', 'threads_blocks', 'export_volumes'] + list(CASES) + list(ROUGH)
     for name in which:
         if name == 'tables':
             tables()
@@ -404,6 +437,8 @@ if __name__ == '__main__':
             trajectory_vectors()
         elif name == 'threads_blocks':
             run_threads_case()
+        elif name == 'export_volumes':
+            run_export_case()
         elif name in ROUGH:
             run_rough_case(name, **ROUGH[name])
         else:

@@ -430,3 +430,39 @@ def test_slow_path_was_exercised(ctx):
     seen work, otherwise that code would be untested"""
     a, r = ctx.slow_path_stats()
     assert a > 0, (a, r)
+
+
+@pytest.mark.parametrize('key,cname,kw,mode', [
+    ('c40x48x56_tric_volumes_0', 'c40x48x56_tric', {}, ('volumes', [0, 3])),
+    ('c40x48x56_tric_atoms_-2', 'c40x48x56_tric', {}, ('atoms', [-2])),
+    ('c48_cubic_vac_volumes_-2', 'c48_cubic_vac', {'vacuum_tol': 0.03}, ('volumes', [-2])),
+])
+def test_export_path_equals_the_reference(ctx, key, cname, kw, mode):
+    """Bader.write_volume + the export loop (interface.py:417-436, 600-621) through the mirror: file names, comments,
+    fortran_format and the masked charge / spin densities (utils.volume_mask on the GPU) equal what the reference
+    handed to its writer (tests/golden/export_volumes.npz: sha256 of the arrays)."""
+    import hashlib
+    import json
+    from pybader_amd import thread_handlers
+    from pybader_amd.interface import Bader
+    thread_handlers.VERBOSE = False
+    want = json.loads(str(load_golden('export_volumes')[key]))
+    g = load_golden(cname)
+    rho = case_density(g)
+    spin = np.ascontiguousarray(rho[::-1] * 0.25)
+    calls = []
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    def capture(fname, atoms, lat, density, info, prefix='', **k):
+        calls.append([fname, info['comment'], info['fortran_format'], sha(density['charge']), sha(density['spin']),
+                      float(density['charge'].sum())])
+    info = {'filename': 'synth', 'prefix': '', 'write_function': capture, 'voxel_offset': np.zeros(3)}
+    b = Bader({'charge': rho, 'spin': spin}, g['lattice'], synth.atoms_cartesian(g['atoms'], g['lattice']), info, **kw)
+    b.export_mode, b.fortran_format = mode, 2
+    b()
+    assert len(calls) == len(want)
+    for got, ref in zip(calls, want):
+        assert got[:5] == ref[:5], (got[:3], ref[:3])
+        assert got[5] == pytest.approx(ref[5], rel=1e-12)
