@@ -576,6 +576,18 @@ enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 7168, BB_BOXM
 static bool table_windowed(const xb_ctx *c) { return c->g.wlen < c->g.nx; }
 static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks, bool ranges_from_rho = false);
 
+// per-brick arrays that outlive an assignment: blab_buf (nbr ints: region label per brick) and brick_rec (nbr bytes)
+static int ensure_brick_bytes(xb_ctx *c, int nbr) {
+    if (c->blab_alloc < nbr) {
+        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->brick_rec = nullptr;
+        if (c->grad_cover) { c->grad_cover = 0; c->grad_valid = false; }
+        HIPCHK(hipMalloc(&c->blab_buf, (size_t)nbr * sizeof(int) + (size_t)nbr + 16));
+        c->blab_alloc = nbr;
+        c->brick_rec = reinterpret_cast<unsigned char *>(c->blab_buf + nbr);
+    }
+    return XB_OK;
+}
+
 // main_rule: records under the assignment's tie test (methods.py:324) instead of the refinement's
 // (refinement.py:111); a table built for one rule serves the other when no voxel of the density has such a tie.
 static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
@@ -594,6 +606,34 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
             k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, nullptr, nullptr, nbr, g.ny / BRK, g.nz / BRK, c->brick_rec, small);
         HIPCHK(hipGetLastError());
         c->grad_rule = main_rule ? 1 : 0;
+        return XB_OK;
+    }
+    if (!force && !boxes && c->opt_sparse && !table_windowed(c) && g.x0 == 0 && g.x1 == g.nx && g.nx % BRK == 0 && g.ny % BRK == 0 &&
+        g.nz % BRK == 0 && g.nx >= 16 && g.ny >= 16 && g.nz >= 16) {
+        // a refinement without a table from an assignment (ongrid, uploaded labels): retraces only run near label
+        // boundaries, so only the bricks whose 27-brick surroundings are not of one label get records (k_masks.h);
+        // a retrace that walks on through a brick without records is redone by the from-rho kernel
+        const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+        if (int rc = ensure_brick_bytes(c, nbr)) return rc;
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        ScopedTimer t(c, 4);
+        int *buni = reinterpret_cast<int *>(c->st);
+        if (!c->buni_valid) k_label_uniform<<<(unsigned)nbr, TPB, 0, c->stream>>>(light(g), c->labels, nb1, nb2, buni);
+        c->buni_valid = true;
+        k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
+        k_flag_mixed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, buni + nbr, c->brick_rec);
+        GridS gs;
+        if (sym_grid(g, gs))
+            k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, nullptr, nullptr, nbr, nb1, nb2, c->brick_rec, small);
+        else
+            k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, nullptr, nullptr, nbr, nb1, nb2, c->brick_rec, small);
+        HIPCHK(hipGetLastError());
+        c->grad_valid = true;
+        c->grad_cover = 1;
+        c->grad_rule = main_rule ? 1 : 0;
+        c->regions_labels = false;
+        c->blab = nullptr;
+        c->table_stage = 0;
         return XB_OK;
     }
     c->grad_cover = 0;
@@ -1045,13 +1085,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     Grid &g = c->g;
     const GridL gl0 = light(g);
     const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
-    if (c->blab_alloc < nbr) {
-        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->brick_rec = nullptr;
-        if (c->grad_cover) { c->grad_cover = 0; c->grad_valid = false; }
-        HIPCHK(hipMalloc(&c->blab_buf, (size_t)nbr * sizeof(int) + (size_t)nbr + 16));
-        c->blab_alloc = nbr;
-        c->brick_rec = reinterpret_cast<unsigned char *>(c->blab_buf + nbr);
-    }
+    if (int rc = ensure_brick_bytes(c, nbr)) return rc;
     int *fs = c->fs;
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
     int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;

@@ -333,6 +333,14 @@ __global__ __launch_bounds__(TPB) void k_brick_records(GT g, const double *__res
     }
 }
 
+// refinement without a table from an assignment (after ongrid / uploaded labels): records are needed where retraces
+// run, i.e. in the bricks whose 3x3x3 surroundings do not carry one single label (buni3 == XB_MIXED_LABEL); bit 1
+// ("may hold a maximum") is set everywhere: nothing is known about the maxima here
+#define XB_MIXED_LABEL (-2147483647 - 1)
+__global__ void k_flag_mixed_bricks(int nbr, const int *__restrict__ buni3, unsigned char *brick_rec) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbr) brick_rec[b] = (unsigned char)(2 | (buni3[b] == XB_MIXED_LABEL ? 1 : 0));
+}
 // brick_rec[b]: bit 0 = the records of brick b exist, bit 1 = the brick holds a 26-neighbour maximum (k_grow_finish).
 // Does the record of voxel (x,y,z) exist?  (nullptr: the table covers the whole grid / window)
 __device__ __forceinline__ bool rec_exists(const unsigned char *__restrict__ brick_rec, const GridL &g, int x, int y, int z) {
