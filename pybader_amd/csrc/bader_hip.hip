@@ -1479,15 +1479,24 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
         {
             ScopedTimer t(c, 3);
             const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
-            if (table_windowed(c) || brec)   // slabs / sparse table off the fused path: the kernel with the from-rho fallback
+            const int regions_ok = brec && c->regions_labels && !c->has_vacuum ? 1 : 0;
+            if (table_windowed(c))   // slabs: the kernel with the from-rho fallback for voxels outside the table window
                 k_refine_trace<2, true><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
                                                                            c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
                                                                            c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0);
-            else
+            else {
+                // the lean kernel; the few retraces whose walk goes on through a brick without records are redone by
+                // the from-rho kernel (their count stays on the device: its grid strides over it)
+                HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
                 k_refine_trace<2, false><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
                                                                             c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
-                                                                            c->ovf_cap, maxsteps, c->rho, c->dist_dev, nullptr, (int *)c->stage,
-                                                                            c->counters + 15, 0);
+                                                                            c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, (int *)c->stage,
+                                                                            c->counters + 15, regions_ok);
+                if (brec)
+                    k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, (int *)c->stage, 0, c->counters + 15,
+                                                                        c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                        c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0);
+            }
         }
         HIPCHK(hipGetLastError());
         int novf = 0;
