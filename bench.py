@@ -77,8 +77,11 @@ def traffic_from_profile(kernel, method):
     import glob
     import hashlib
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_fetch_write_512_{method}.txt')),
-                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(f))])
+    def order(f):   # round number, then the round's final profile after its intermediate ones
+        name = os.path.basename(f)
+        m = re.match(r'r(\d+)', name)
+        return (int(m.group(1)) if m else -1, '_final_' in name, name)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_fetch_write_512_{method}.txt')), key=order)
     for path in reversed(files):
         kb, launches = 0.0, 0
         with open(path) as f:
