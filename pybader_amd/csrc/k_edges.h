@@ -248,6 +248,26 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
     }
     __syncthreads();
     const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+    // "some non-vacuum neighbour carries another label" (refinement.py:357-372) is separable: with vacuum (-1) read as
+    // the largest unsigned value, it holds iff the unsigned minimum of the 27 labels is below the voxel's own label or
+    // their signed maximum above it.  Minima / maxima along z per (x, y) row, then over y for the thread's two y
+    // positions, then over x per voxel: 108 LDS reads and ~40 operations per voxel instead of 216 and ~110.
+    unsigned ymin[ET_X + 2][2];
+    int ymax[ET_X + 2][2];
+#pragma unroll
+    for (int ex = 0; ex < ET_X + 2; ex++) {
+        unsigned rmin[6];
+        int rmax[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const int ey = tyb + r + (r >= 3 ? 1 : 0);   // rows tyb..tyb+2 (y = tyb) and tyb+4..tyb+6 (y = tyb + 4)
+            const int a = tile[ex][ey][tz], b = tile[ex][ey][tz + 1], c2 = tile[ex][ey][tz + 2];
+            rmin[r] = min(min((unsigned)a, (unsigned)b), (unsigned)c2);
+            rmax[r] = max(max(a, b), c2);
+        }
+        ymin[ex][0] = min(min(rmin[0], rmin[1]), rmin[2]); ymax[ex][0] = max(max(rmax[0], rmax[1]), rmax[2]);
+        ymin[ex][1] = min(min(rmin[3], rmin[4]), rmin[5]); ymax[ex][1] = max(max(rmax[3], rmax[4]), rmax[5]);
+    }
     int8_t out[8];
     int vidx[8];
     int cnt = 0;
@@ -264,16 +284,9 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
             const int lab = tile[tx + 1][ty + 1][tz + 1];
             int8_t o = 0;  // vacuum voxels are not classified (refinement.py:342-343)
             if (lab != -1) {
-                bool is_edge = false;
-#pragma unroll
-                for (int dx = 0; dx < 3; dx++)
-#pragma unroll
-                    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                        for (int dz = 0; dz < 3; dz++) {
-                            const int nv = tile[tx + dx][ty + dy][tz + dz];
-                            is_edge |= (nv != -1) & (nv != lab);
-                        }
+                const unsigned bmin = min(min(ymin[tx][k & 1], ymin[tx + 1][k & 1]), ymin[tx + 2][k & 1]);
+                const int bmax = max(max(ymax[tx][k & 1], ymax[tx + 1][k & 1]), ymax[tx + 2][k & 1]);
+                const bool is_edge = bmin < (unsigned)lab || bmax > lab;
                 o = 2;
                 if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
                     bool is_max = true, decided = false;
