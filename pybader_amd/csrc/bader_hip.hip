@@ -1694,10 +1694,21 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
             k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
             buni += nbr;
         }
-        dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (g.nx + ET_X - 1) / ET_X);
-        k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, 0, g.nx, c->list, fs + FS_N_EDGES, small, buni,
-                                                       c->grad_valid ? c->grad : nullptr, c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr,
-                                                       c->has_vacuum ? 0 : 1);
+        const unsigned char *brec = c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr;
+        if (buni) {
+            // flags preset to "known", then only the tiles that are not of one non-vacuum label with their surroundings
+            const int ntiles = ((g.nz + ET_Z - 1) / ET_Z) * (g.ny / ET_Y) * (g.nx / ET_X);
+            int *tiles = (int *)c->stage;
+            HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
+            HIPCHK(hipMemsetAsync(fs + FS_N_TILES, 0, sizeof(int), c->stream));
+            k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES);
+            k_edge_flag_listed<<<ntiles, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
+                                                           c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1, tiles, fs + FS_N_TILES);
+        } else {
+            dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (g.nx + ET_X - 1) / ET_X);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, 0, g.nx, c->list, fs + FS_N_EDGES, small, buni,
+                                                           c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1);
+        }
         k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
     }
     c->list_valid = false;

@@ -143,15 +143,13 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known
 #define ET_X 4
 #define ET_Y 8
 #define ET_Z 64
-__global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *__restrict__ rho,
-                                                         const int *__restrict__ labels,
-                                                         int8_t *__restrict__ known, int xa, int nplanes,
-                                                         int *__restrict__ list, int *list_count, int small,
-                                                         const int *__restrict__ buni,
-                                                         const GradRec *__restrict__ G,
-                                                         const unsigned char *__restrict__ brick_rec, int no_vacuum) {
+// one tile at (tx0 planes from xa, y0, z0); `buni` null: no uniformity shortcut (the caller knows the tile is mixed)
+__device__ __forceinline__ void edge_tile(const GridL &g, const double *__restrict__ rho, const int *__restrict__ labels,
+                                          int8_t *__restrict__ known, int xa, int nplanes, int *__restrict__ list,
+                                          int *list_count, int small, const int *__restrict__ buni,
+                                          const GradRec *__restrict__ G, const unsigned char *__restrict__ brick_rec,
+                                          int no_vacuum, int tx0, int y0, int z0) {
     __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
-    const int tx0 = blockIdx.z * ET_X, y0 = blockIdx.y * ET_Y, z0 = blockIdx.x * ET_Z;
     if (buni) {
         // `buni` here is buni3 (k_buni3): a brick entry says that the brick and all its 26 neighbours carry one
         // label, so the bricks the tile itself lies in (1-2 in x, one in y, ET_Z/8 in z) settle the tile plus
@@ -267,69 +265,81 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
         }
         ymin[ex][0] = min(min(rmin[0], rmin[1]), rmin[2]); ymax[ex][0] = max(max(rmax[0], rmax[1]), rmax[2]);
         ymin[ex][1] = min(min(rmin[3], rmin[4]), rmin[5]); ymax[ex][1] = max(max(rmax[3], rmax[4]), rmax[5]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the 18 LDS reads of one x-plane together: hoisted, all 108 cost a register each
     }
-    int8_t out[8];
+    // pass 1 (unrolled, registers only): which of the thread's 8 voxels have a foreign neighbour
+    unsigned cand = 0, inside = 0, vac = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+        if (tx0 + tx < nplanes && y0 + ty < g.ny && z0 + tz < g.nz) {
+            inside |= 1u << k;
+            const int lab = tile[tx + 1][ty + 1][tz + 1];
+            if (lab == -1) vac |= 1u << k;   // vacuum voxels are not classified (refinement.py:342-343)
+            else {
+                const unsigned bmin = min(min(ymin[tx][k & 1], ymin[tx + 1][k & 1]), ymin[tx + 2][k & 1]);
+                const int bmax = max(max(ymax[tx][k & 1], ymax[tx + 1][k & 1]), ymax[tx + 2][k & 1]);
+                if (bmin < (unsigned)lab || bmax > lab) cand |= 1u << k;
+            }
+        }
+    }
+    // pass 2 (a loop, not unrolled: it runs for the edge candidates only and its loads must not cost registers for
+    // all 8 voxels at once): refinement.py:374-383, an edge unless it is a 26-neighbour maximum
+    unsigned edges = 0;
+#pragma unroll 1
+    for (unsigned m = cand; m; m &= m - 1) {
+        const int k = __ffs(m) - 1;
+        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+        int x = xa + tx0 + tx;
+        if (x >= g.nx) x -= g.nx;
+        const int y = y0 + ty, z = z0 + tz;
+        const int v = (x * g.ny + y) * g.nz + z;
+        bool is_max = true, decided = false;
+        const int binfo = brick_rec ? brick_rec[((x >> 3) * (g.ny >> 3) + (y >> 3)) * (g.nz >> 3) + (z >> 3)] : 1;
+        if (brick_rec && no_vacuum && !(binfo & 2)) {
+            // no voxel of this brick is a 26-neighbour maximum: each has a strictly denser neighbour
+            // (weighted > rho(v) implies rho(n) > rho(v)), and without vacuum no neighbour is skipped
+            is_max = false;
+            decided = true;
+        } else if (G && plane_in_window(g, x) && (binfo & 1)) {  // (slabs: a window of planes; sparse table: flagged bricks)
+            // the table knows the best distance-weighted neighbour of v; if there is one (and it is not vacuum) that
+            // neighbour is denser than v: not a maximum.  (weighted > rho(v) implies rho(n) > rho(v); the converse can
+            // fail by rounding, so "no such neighbour" still takes the full test)
+            const int og = key_og(G[v].key);
+            if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
+                is_max = false;
+                decided = true;
+            }
+        }
+        if (!decided) {
+            const double c = rho[v];
+            for (int dx = -1; dx < 2; dx++) {
+                const int X = wrapi(x + dx, g.nx);
+                for (int dy = -1; dy < 2; dy++) {
+                    const int Y = wrapi(y + dy, g.ny);
+                    for (int dz = -1; dz < 2; dz++) {
+                        const int Z = wrapi(z + dz, g.nz);
+                        if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 && rho[(X * g.ny + Y) * g.nz + Z] > c) is_max = false;
+                    }
+                }
+            }
+        }
+        if (!is_max) edges |= 1u << k;
+    }
+    // pass 3: the flags, and the owned edge voxels for the list
     int vidx[8];
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
-        const int xr = tx0 + tx, y = y0 + ty, z = z0 + tz;
-        out[k] = 1;  // 1 = outside the grid / the plane range: nothing to store
         vidx[k] = -1;
-        if (xr < nplanes && y < g.ny && z < g.nz) {
-            int x = xa + xr;
+        if ((inside >> k) & 1u) {
+            const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+            int x = xa + tx0 + tx;
             if (x >= g.nx) x -= g.nx;
-            const int v = (x * g.ny + y) * g.nz + z;
-            const int lab = tile[tx + 1][ty + 1][tz + 1];
-            int8_t o = 0;  // vacuum voxels are not classified (refinement.py:342-343)
-            if (lab != -1) {
-                const unsigned bmin = min(min(ymin[tx][k & 1], ymin[tx + 1][k & 1]), ymin[tx + 2][k & 1]);
-                const int bmax = max(max(ymax[tx][k & 1], ymax[tx + 1][k & 1]), ymax[tx + 2][k & 1]);
-                const bool is_edge = bmin < (unsigned)lab || bmax > lab;
-                o = 2;
-                if (is_edge) {  // refinement.py:374-383: an edge unless it is a 26-neighbour maximum
-                    bool is_max = true, decided = false;
-                    const int binfo = brick_rec ? brick_rec[((x >> 3) * (g.ny >> 3) + (y >> 3)) * (g.nz >> 3) + (z >> 3)] : 1;
-                    if (brick_rec && no_vacuum && !(binfo & 2)) {
-                        // no voxel of this brick is a 26-neighbour maximum: each has a strictly denser neighbour
-                        // (weighted > rho(v) implies rho(n) > rho(v)), and without vacuum no neighbour is skipped
-                        is_max = false;
-                        decided = true;
-                    } else if (G && plane_in_window(g, x) && (binfo & 1)) {  // (slabs: a window of planes; sparse table: flagged bricks)
-                        // the table knows the best distance-weighted neighbour of v; if there is one
-                        // (and it is not vacuum) that neighbour is denser than v: not a maximum.
-                        // (weighted > rho(v) implies rho(n) > rho(v); the converse can fail by
-                        // rounding, so "no such neighbour" still takes the full test)
-                        const int og = key_og(G[v].key);
-                        if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
-                            is_max = false;
-                            decided = true;
-                        }
-                    }
-                    if (!decided) {
-                        const double c = rho[v];
-                        for (int dx = -1; dx < 2; dx++) {
-                            const int X = wrapi(x + dx, g.nx);
-                            for (int dy = -1; dy < 2; dy++) {
-                                const int Y = wrapi(y + dy, g.ny);
-                                for (int dz = -1; dz < 2; dz++) {
-                                    const int Z = wrapi(z + dz, g.nz);
-                                    if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 &&
-                                        rho[(X * g.ny + Y) * g.nz + Z] > c)
-                                        is_max = false;
-                                }
-                            }
-                        }
-                    }
-                    if (!is_max) {
-                        o = -2;
-                        if (x >= g.x0 && x < g.x1) { vidx[k] = v; cnt++; }
-                    }
-                }
-            }
-            out[k] = o;
-            known[v] = o;
+            const int v = (x * g.ny + y0 + ty) * g.nz + z0 + tz;
+            const bool e = (edges >> k) & 1u;
+            known[v] = ((vac >> k) & 1u) ? 0 : (e ? -2 : 2);
+            if (e && x >= g.x0 && x < g.x1) { vidx[k] = v; cnt++; }
         }
     }
     int total;
@@ -341,6 +351,69 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
 #pragma unroll
     for (int k = 0; k < 8; k++)
         if (vidx[k] >= 0) list[w++] = vidx[k];
+}
+
+__global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *__restrict__ rho,
+                                                         const int *__restrict__ labels,
+                                                         int8_t *__restrict__ known, int xa, int nplanes,
+                                                         int *__restrict__ list, int *list_count, int small,
+                                                         const int *__restrict__ buni,
+                                                         const GradRec *__restrict__ G,
+                                                         const unsigned char *__restrict__ brick_rec, int no_vacuum) {
+    edge_tile(g, rho, labels, known, xa, nplanes, list, list_count, small, buni, G, brick_rec, no_vacuum, blockIdx.z * ET_X,
+              blockIdx.y * ET_Y, blockIdx.x * ET_Z);
+}
+// One GPU, whole bricks: `known` is preset to 2 and only the tiles that are not of one non-vacuum label with their
+// surroundings are swept -- a sixth of the 65 536 tiles at 512^3, whose early-exit workgroups cost a third of the sweep.
+// k_edge_tile_list: one thread per tile, the buni3 test of edge_tile; entry = tile index, bit 31 set for a tile of
+// uniform VACUUM (its flags are 0, refinement.py:342-343).
+__global__ __launch_bounds__(TPB) void k_edge_tile_list(GridL g, const int *__restrict__ buni3, int *tiles, int *n_tiles) {
+    const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = g.ny / ET_Y, ntx = g.nx / ET_X;
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    bool hit = false;
+    unsigned entry = 0;
+    if (t < ntx * nty * ntz) {
+        const int tz = t % ntz, ty = (t / ntz) % nty, tx = t / (ntz * nty);
+        const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        const int bxa = (tx * ET_X) >> 3, bxb = (tx * ET_X + ET_X - 1) >> 3, nbz = min(ET_Z / 8, nb2 - ((tz * ET_Z) >> 3));
+        int lab = XB_MIXED;
+        bool mixed = false;
+        for (int k = 0; k < 2 * nbz; k++) {
+            const int l = buni3[(((k & 1) ? bxb : bxa) * nb1 + ((ty * ET_Y) >> 3)) * nb2 + ((tz * ET_Z) >> 3) + (k >> 1)];
+            if (l == XB_MIXED) mixed = true;
+            else if (lab == XB_MIXED) lab = l;
+            else if (lab != l) mixed = true;
+        }
+        hit = mixed || lab == -1;
+        entry = (unsigned)t | ((!mixed && lab == -1) ? 0x80000000u : 0u);
+    }
+    int total;
+    const int off = block_scan_excl(hit ? 1 : 0, total);
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(n_tiles, total) : 0;
+    __syncthreads();
+    if (hit) tiles[base_s + off] = (int)entry;
+}
+__global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double *__restrict__ rho, const int *__restrict__ labels,
+                                                          int8_t *__restrict__ known, int *__restrict__ list, int *list_count,
+                                                          int small, const GradRec *__restrict__ G,
+                                                          const unsigned char *__restrict__ brick_rec, int no_vacuum,
+                                                          const int *__restrict__ tiles, const int *n_tiles) {
+    // one tile per workgroup, the grid covers every tile: a loop over the list would make the compiler keep the ~60 LDS
+    // row addresses of edge_tile in registers across iterations (177 VGPRs, 2 waves per SIMD instead of 4)
+    if ((int)blockIdx.x >= *n_tiles) return;
+    const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = g.ny / ET_Y;
+    const unsigned entry = (unsigned)tiles[blockIdx.x];
+    const int t = (int)(entry & 0x7fffffffu);
+    const int tx0 = (t / (ntz * nty)) * ET_X, y0 = ((t / ntz) % nty) * ET_Y, z0 = (t % ntz) * ET_Z;
+    if (entry & 0x80000000u) {   // uniform vacuum: flags 0
+        for (int i = threadIdx.x; i < ET_X * ET_Y * ET_Z; i += TPB) {
+            const int z = z0 + (i % ET_Z), y = y0 + (i / ET_Z) % ET_Y, x = tx0 + i / (ET_Z * ET_Y);
+            if (z < g.nz) known[(x * g.ny + y) * g.nz + z] = 0;
+        }
+        return;
+    }
+    edge_tile(g, rho, labels, known, 0, g.nx, list, list_count, small, nullptr, G, brick_rec, no_vacuum, tx0, y0, z0);
 }
 
 // compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block

@@ -29,6 +29,7 @@ enum {
     FS_N_EDGES,          // refinement: edge list length
     FS_CHANGED, FS_ESCAPED, FS_R_OVF,
     FS_R_DEFER,          // refinement: retraces handed to the from-rho kernel (their walk goes on through a brick without records)
+    FS_N_TILES,          // refinement: tiles of the edge sweep that are not of one label with their surroundings
     FS_COUNT = 64,
     // 8 per-XCD work cursors of the persistent trace, one per 128-byte line: device-scope atomics on ONE line
     // serialise at ~88 per microsecond whatever the word (measured: 8 cursors in one line = one cursor)
