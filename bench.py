@@ -96,6 +96,39 @@ def traffic_from_profile(kernel, method):
     return None, None
 
 
+def dropin_leg(ctx, size=256, k=6, reps=3):
+    """bader_calc + refine through pybader_amd.thread_handlers on a 216-atom density (host numpy arrays at the boundary)"""
+    from pybader_amd import _lib, synth, thread_handlers, utils
+    from pybader_amd.interface import distance_matrix, gradient_transform
+    rng = np.random.default_rng(5)
+    cells = np.stack(np.meshgrid(*(np.arange(k),) * 3, indexing='ij'), -1).reshape(-1, 3)
+    frac = (cells + 0.5 + 0.18 * (rng.random(cells.shape) - 0.5)) / k
+    atoms = np.concatenate([frac, 0.09 + 0.04 * rng.random((len(frac), 1)), 2.0 + 6.0 * rng.random((len(frac), 1))], 1)
+    shape = (size,) * 3
+    lattice = synth.CUBIC6
+    vl = np.divide(lattice, shape)
+    dm, tg = distance_matrix(vl), gradient_transform(vl)
+    c2 = _lib.Context(0)
+    c2.set_grid(shape, dm, tg)
+    c2.synth_density(lattice, atoms, synth.BACKGROUND)
+    rho = c2.download_density()
+    c2.close()
+    thread_handlers.VERBOSE = False
+    times, n, stats = [], 0, (0, 0)
+    for _ in range(reps):
+        vol = np.zeros(shape, np.int32)
+        t0 = time.perf_counter()
+        bmax, vol = thread_handlers.bader_calc('neargrid', rho, vol, dm, tg, 1)
+        thread_handlers.refine('neargrid', ('changed', 2), rho, vol, dm, tg, 1)
+        times.append(time.perf_counter() - t0)
+        n, stats = bmax.shape[0], _lib.default_context().box_stats()
+    best = min(times)
+    return {'workload': f'{size}^3 grid, {len(atoms)} atoms, thread_handlers.bader_calc + refine (changed,2), host arrays in/out '
+                        '(density + label upload, label download every call)',
+            'value': float(size) ** 3 / best / 1e6, 'unit': 'Mvoxels/s', 'ms_per_call_pair': best * 1e3, 'basins': int(n),
+            'trapping_boxes': {'count': int(stats[0]), 'voxel_fraction': stats[1] / float(size) ** 3}}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N rank processes of this script (fresh interpreters
     that have not touched the GPU; this parent never does), wait, relay rank 0's output.  Returns the exit code."""
@@ -141,6 +174,7 @@ def main():
     ap.add_argument('--cpu-size', type=int, default=320)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-config5', action='store_true', help='skip the ongrid configuration timed after the headline one')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the thread_handlers leg on the 216-atom 256^3 density')
     ap.add_argument('--halo', type=int, default=None,
                     help='label planes valid each side of a slab (default 64 for N > 1: retraces glide along the '
                          'dividing surfaces for tens of planes; the rest is finished by remote path queries)')
@@ -305,6 +339,12 @@ def main():
                           'basins': int(n5), 'refine_log': log5,
                           'whole_path_frac_of_hbm_roofline': BYTES_PATH * nvox / dt5 / 1e9 / HBM_PEAK_GBS,
                           'stage_ms_avg': {k: (ms / n if n else 0.0) for k, (ms, n) in tm5.items() if k != '-'}}
+
+    # The Python drop-in (pybader_amd.thread_handlers, the reference's call signatures) on a density the headline does not
+    # flatter: 216 atoms on a 256^3 grid (more maxima than round 1's 64 seed cubes), host arrays in, host arrays out --
+    # label upload / download and the density upload included (PCIe), which `value` above never includes.
+    if world == 1 and args.method == 'neargrid' and not args.no_dropin:
+        out['dropin_many_atoms'] = dropin_leg(ctx)
 
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
     out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
