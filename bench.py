@@ -176,8 +176,8 @@ def main():
     ap.add_argument('--no-config5', action='store_true', help='skip the ongrid configuration timed after the headline one')
     ap.add_argument('--no-dropin', action='store_true', help='skip the thread_handlers leg on the 216-atom 256^3 density')
     ap.add_argument('--halo', type=int, default=None,
-                    help='label planes valid each side of a slab (default 64 for N > 1: retraces glide along the '
-                         'dividing surfaces for tens of planes; the rest is finished by remote path queries)')
+                    help='label planes valid each side of a slab (default 16 for N > 1: a retrace stops when it enters a '
+                         'trapping region; whatever still leaves the valid planes is finished by remote path queries)')
     ap.add_argument('--table-margin', type=int, default=32,
                     help='planes of gradient-field table each side of a slab (N > 1)')
     args = ap.parse_args()
@@ -220,7 +220,7 @@ def main():
     dm, tg = distance_matrix(vl), gradient_transform(vl)
     voxel_volume = abs(np.linalg.det(lattice)) / float(np.prod(shape))
 
-    halo = args.halo if args.halo is not None else (64 if world > 1 else 8)
+    halo = args.halo if args.halo is not None else (16 if world > 1 else 8)
     runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=halo)
     windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts

@@ -161,7 +161,10 @@ int xb_set_table_window(xb_ctx *c, int64_t margin);           /* margin < 0: who
 int xb_table_build(xb_ctx *c, int64_t *n_local_seeds);
 int xb_table_local_seeds(xb_ctx *c, int64_t *out, int64_t capacity);  /* linear voxel indices */
 int xb_brick_masks(xb_ctx *c, void **dev_ptr, int64_t *n_bricks, int64_t *own_first, int64_t *own_count);
-int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds);
+/* does this rank's window hold a voxel whose record depends on the tie rule (methods.py:324 vs refinement.py:111)? */
+int xb_table_ties(xb_ctx *c, int64_t *has_ties);
+/* any_ties: the OR of xb_table_ties over all ranks */
+int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t any_ties);
 
 /* ---- slab halo planes (multi-GPU) -------------------------------------------------------- */
 /* Device pointers of the label / known arrays and the plane size in elements, so that the slab

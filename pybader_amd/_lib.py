@@ -60,7 +60,8 @@ SYMBOLS = {
     'xb_table_build': (_int, [_vp, _pi64]),
     'xb_table_local_seeds': (_int, [_vp, _vp, _i64]),
     'xb_brick_masks': (_int, [_vp, C.POINTER(_vp), _pi64, _pi64, _pi64]),
-    'xb_table_finish': (_int, [_vp, _vp, _i64]),
+    'xb_table_ties': (_int, [_vp, _pi64]),
+    'xb_table_finish': (_int, [_vp, _vp, _i64, _i64]),
     'xb_labels_ptr': (_vp, [_vp]),
     'xb_known_ptr': (_vp, [_vp]),
     'xb_density_ptr': (_vp, [_vp]),
@@ -360,9 +361,14 @@ class Context:
         check(self.lib.xb_brick_masks(self.h, C.byref(p), C.byref(n), C.byref(f), C.byref(k)))
         return p.value, n.value, f.value, k.value
 
-    def table_finish(self, seeds):
+    def table_ties(self):
+        t = C.c_int64()
+        check(self.lib.xb_table_ties(self.h, C.byref(t)))
+        return bool(t.value)
+
+    def table_finish(self, seeds, any_ties=True):
         sd = np.ascontiguousarray(seeds, dtype=np.int64)
-        check(self.lib.xb_table_finish(self.h, _ptr(sd), sd.shape[0]))
+        check(self.lib.xb_table_finish(self.h, _ptr(sd), sd.shape[0], int(bool(any_ties))))
 
     def copy_planes(self, which, to_device, host, xa, xb):
         check(self.lib.xb_copy_planes(self.h, int(which), int(to_device), _ptr(host), int(xa), int(xb)))

@@ -129,6 +129,21 @@ class SocketStore:
         self.peers, self.sock, self._path = [], None, None
 
 
+class _stdout_to_stderr:
+    """librccl greets on stdout when a communicator is made; bench.py owes its caller exactly one JSON line there"""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class HostComm:
     """The scheduler's collectives on host objects only (the CPU tests drive a host backend with it; RcclComm
     builds on it).  `backend.planes(which)` must then be a writable (nx, plane) numpy view."""
@@ -176,11 +191,13 @@ class RcclComm(HostComm):
         self.transport = 'none' if self.size == 1 else 'host-staged-tcp'
         if self.size == 1:
             return
-        uid = ctx.comm_unique_id() if self.rank == 0 else None
+        with _stdout_to_stderr():
+            uid = ctx.comm_unique_id() if self.rank == 0 else None
         uid = self.allgather(uid)[0]
         ok = True
         try:
-            ctx.comm_init(self.rank, self.size, uid)
+            with _stdout_to_stderr():
+                ctx.comm_init(self.rank, self.size, uid)
             n = self.size
             ok = ctx.comm_allreduce([self.rank + 1, 1]) == [n * (n + 1) // 2, n]
             ok = ok and ctx.comm_allgather([self.rank, 7 * self.rank]).reshape(n, 2).tolist() == [[r, 7 * r] for r in range(n)]

@@ -83,6 +83,7 @@ struct xb_ctx {
     bool table_prebuilt = false;   // xb_table_finish done: the next xb_assign_trace must not rebuild
     int table_stage = 0;           // windowed build: 1 = records + masks done, 2 = trapping regions done
     std::vector<int> window_seeds; // maxima found in the owned planes (windowed build)
+    bool window_ties = true;       // the window holds a voxel whose record depends on the tie rule (windowed build)
     int ec_local_n = 0;            // xb_edge_check_local -> xb_edge_check_local_fetch
     long long stat_deferred = 0;   // retraces redone by the from-rho kernel (sparse table)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
@@ -672,7 +673,9 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
         HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 9, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         ns = c->host_ints[0];
-        if (c->host_ints[1] == 0) c->grad_rule = 2;
+        c->window_ties = c->host_ints[1] != 0;
+        // (a windowed table only knows its own planes: xb_table_finish decides with every rank's answer)
+        if (c->host_ints[1] == 0 && !table_windowed(c)) c->grad_rule = 2;
     }
     if (ns > BB_SEED_CAP) ns = XB_BOX_SEEDS_MAX + 1;  // list overflowed: far too many maxima for boxes anyway
     std::vector<int> seeds(std::max(ns, 0));
@@ -1057,6 +1060,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
         }
     } else
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, nullptr);
+    c->regions_labels = c->regions_pending && c->blab && !c->has_vacuum;   // certain bricks carry their region's label now
     c->regions_pending = false;
     HIPCHK(hipGetLastError());
     if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
@@ -1480,10 +1484,14 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
             ScopedTimer t(c, 3);
             const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
             const int regions_ok = brec && c->regions_labels && !c->has_vacuum ? 1 : 0;
+            // slabs: the regions' brick labels stop a retrace when the labels are this assignment's, there is no vacuum and
+            // the density has no tie voxel (the windowed masks are built under the assignment's tie rule only)
+            const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && c->grad_rule == 2 &&
+                                       g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
             if (table_windowed(c))   // slabs: the kernel with the from-rho fallback for voxels outside the table window
                 k_refine_trace<2, true><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
                                                                            c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
-                                                                           c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0);
+                                                                           c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0, slab_regions);
             else {
                 // the lean kernel; the few retraces whose walk goes on through a brick without records are redone by
                 // the from-rho kernel (their count stays on the device: its grid strides over it)
@@ -1491,11 +1499,11 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
                 k_refine_trace<2, false><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
                                                                             c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
                                                                             c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, (int *)c->stage,
-                                                                            c->counters + 15, regions_ok);
+                                                                            c->counters + 15, regions_ok, nullptr);
                 if (brec)
                     k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, (int *)c->stage, 0, c->counters + 15,
                                                                         c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
-                                                                        c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0);
+                                                                        c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0, nullptr);
             }
         }
         HIPCHK(hipGetLastError());
@@ -1720,11 +1728,11 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev,
                                                               c->grad_cover == 1 ? c->brick_rec : nullptr, (int *)c->stage, fs + FS_R_DEFER,
-                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0);
+                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0, nullptr);
         if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
             k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
                                                                fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
-                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0);
+                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1960,9 +1968,18 @@ int xb_brick_masks(xb_ctx *c, void **dev_ptr, int64_t *n_bricks, int64_t *own_fi
     if (own_count) *own_count = ((g.x1 - g.x0) / 8) * per_plane;
     return XB_OK;
 }
-int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds) {
+int xb_table_ties(xb_ctx *c, int64_t *has_ties) {
+    NEED_GRID("xb_table_ties");
+    if (c->table_stage < 1 || !c->grad_valid) return fail(XB_E_STATE, "xb_table_ties: call xb_table_build first");
+    if (has_ties) *has_ties = c->window_ties ? 1 : 0;
+    return XB_OK;
+}
+int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t any_ties) {
     NEED_GRID("xb_table_finish");
     if (c->table_stage < 1 || !c->grad_valid) return fail(XB_E_STATE, "xb_table_finish: call xb_table_build first");
+    // the records serve both tie rules (and the regions are closed for the refinement's retraces too) only when NO
+    // rank's window holds a tie voxel
+    c->grad_rule = any_ties ? 1 : 2;
     int rc = XB_OK;
     if (n_seeds >= 1 && n_seeds <= XB_BOX_SEEDS_MAX) {
         std::vector<int> sv(n_seeds);
@@ -1990,7 +2007,9 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     const size_t es = which == 0 ? 4 : 1;
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
-    if (to_device) { c->list_valid = false; c->has_vacuum = true; c->buni_valid = false; c->regions_labels = false; }
+    // (a slab's halo planes come from peers that ran the same assignment: the regions' labels stay what they are)
+    if (to_device) { c->list_valid = false; c->has_vacuum = c->has_vacuum || c->g.x1 - c->g.x0 == c->g.nx; c->buni_valid = false;
+                     if (c->g.x1 - c->g.x0 == c->g.nx) c->regions_labels = false; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

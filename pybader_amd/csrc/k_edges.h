@@ -503,7 +503,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                                                       int *ovf_count, int ovf_cap, int maxsteps,
                                                       const double *__restrict__ rho, const double *__restrict__ gc,
                                                       const unsigned char *__restrict__ brick_rec, int *defer_list,
-                                                      int *defer_count, int regions_ok) {
+                                                      int *defer_count, int regions_ok, const int *__restrict__ region_blab) {
     const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
     int n_ch = 0, n_es = 0;
   for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
@@ -526,6 +526,9 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         rec = fetch_rec(G, v);
         vol_num = labels[v];
         moving = true;
+        if (region_blab && region_blab[((px >> 3) * (g.ny >> 3) + (py >> 3)) * (g.nz >> 3) + (pz >> 3)] > 0) {
+            result = v; moving = false;   // slabs: an edge voxel inside a trapping region keeps its label (see below)
+        } else
         if (!(plane_in_window(g, px) && rec_exists(brick_rec, g, px, py, pz))) {   // an edge voxel without a record
             if (RHO) rec = make_rec_rho(g, rho, gc, px, py, pz);
             else { result = regions_ok ? v : -5; moving = false; }   // inside a trapping region: it ends there, label unchanged
@@ -563,7 +566,11 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                 GradRec nr = fetch_rec(G, in_win ? lq : lp);
                 const int8_t kq = known[ok_plane ? lq : lp];
                 const bool missing = !(in_win && rec_exists(brick_rec, g, qx, qy, qz));
-                if (!RHO && regions_ok && missing && ok_plane) {
+                // slabs (region_blab: the brick labels of the trapping regions, the same on every rank): a retrace that
+                // enters a region ends in it with the region's label -- it no longer glides along a dividing surface for
+                // tens of planes, so a narrow label halo is enough and the remote path queries become rare
+                const bool in_region = region_blab && ok_plane && region_blab[((qx >> 3) * (g.ny >> 3) + (qy >> 3)) * (g.nz >> 3) + (qz >> 3)] > 0;
+                if (in_region || (!RHO && regions_ok && missing && ok_plane)) {
                     // q lies in a trapping region (closed, one label): the retrace ends in it whatever happens next --
                     // no record, no density, no membership test needed (q cannot be an old path voxel: the path would
                     // not have left the region)

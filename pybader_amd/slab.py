@@ -170,14 +170,16 @@ class SlabRunner:
             with _Phase(self, 'table_build'):
                 local = self.be.table_build()
             with _Phase(self, 'seeds_allgather'):
-                seeds = sorted(set(int(v) for part in self.comm.allgather(np.asarray(local).tolist()) for v in part))
+                parts = self.comm.allgather((np.asarray(local).tolist(), bool(self.be.table_ties())))
+                seeds = sorted(set(int(v) for part, _ in parts for v in part))
+                any_ties = any(t for _, t in parts)
             with _Phase(self, 'mask_exchange'):
                 self.be.sync()
                 if getattr(self, '_chunks', None) is None:      # static for a given decomposition
                     self._chunks = self.comm.allgather(self.be.brick_mask_range())
                 self.comm.share_brick_masks(self.be, self._chunks)
             with _Phase(self, 'table_finish'):
-                self.be.table_finish(np.array(seeds, dtype=np.int64))
+                self.be.table_finish(np.array(seeds, dtype=np.int64), any_ties)
         with _Phase(self, 'assign_trace'):
             m, f = self.be.assign_trace(method)
         with _Phase(self, 'maxima_merge'):

@@ -203,8 +203,8 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
         p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--size', '128', '--steps', '2',
                             '--warmup', '1', '--no-cpu'], capture_output=True, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
-        lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
-        assert len(lines) == 1
+        lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+        assert len(lines) == 1 and lines[0].startswith('{'), lines[:3]   # ONE JSON line on stdout (librccl's greeting goes to stderr)
         outs.append(json.loads(lines[0]))
     one, two = outs
     assert two['n_gpus'] == 2 and 'host-staged-tcp' in two['config']['parallelism']
