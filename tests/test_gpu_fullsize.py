@@ -179,3 +179,36 @@ def test_many_atoms_keep_their_trapping_regions():
     log = ctx.refine('changed', 2)
     assert all(c == 0 for _, c in log) and np.array_equal(ctx.download_labels(np.int32), l1)
     ctx.close()
+
+
+@pytest.mark.parametrize('method', ['neargrid', 'ongrid'])
+def test_vacuum_at_scale_sparse_table_equals_full_table(method):
+    """256^3 with half of the cell declared vacuum: the sparse-table pipeline (brick masks, records for the walk-list /
+    mixed bricks only, deferred from-rho retraces -- no region stop with vacuum) against the round-1 route that writes a
+    record for every voxel, and against plain full-trajectory tracing; maps, maxima and refinement logs must agree."""
+    shape = (256,) * 3
+    dm, tg = matrices(shape, synth.CUBIC6)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    res = []
+    for sparse, boxes in ((1, 3), (0, 3), (0, 0)):
+        ctx.set_option(12, sparse)
+        ctx.set_option(1, boxes)
+        ctx.set_option(6, 1)
+        vc, vv = ctx.vacuum_assign(0.03, 1.0)
+        n = ctx.assign(method)
+        pre = ctx.download_labels(np.int32)
+        log = ctx.refine('changed', 2)
+        res.append((n, ctx.maxima(), pre, log, ctx.download_labels(np.int32), vv))
+    deferred = ctx.deferred_stats()
+    ctx.close()
+    assert 0.2 * 256 ** 3 < res[0][5] < 0.7 * 256 ** 3          # about half of the voxels are vacuum
+    for r in res[1:]:
+        assert r[0] == res[0][0] and np.array_equal(r[1], res[0][1])
+        assert np.array_equal(r[2], res[0][2])
+        assert r[3] == res[0][3] and np.array_equal(r[4], res[0][4])
+    assert (res[0][2] == -1).sum() == res[0][5]
+    if method == 'ongrid':
+        assert res[0][3][0][1] > 0                                # the refinement relabels voxels
+    print('deferred retraces', deferred)
