@@ -62,6 +62,7 @@ struct xb_ctx {
     GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
     double *dist_dev = nullptr; // dist_mat on the device
     int *boxbuf = nullptr;      // seeds / box tables of the table build (BB_* layout)
+    int *box_max_tab = nullptr; // region id - 1 -> voxel of the region's maximum (inside boxbuf: BB_BOXMAX or BB_REGMAX)
     int n_boxes = 0;
     long long box_voxels = 0;
     int opt_boxes = 1;
@@ -570,7 +571,8 @@ static GridL light(const Grid &g);
 // layout of the small device int buffer used by the table build (c->boxbuf)
 // (up to XB_BOX_SEEDS_MAX seed cubes: a cell with hundreds of atoms keeps its trapping regions)
 enum { BB_SEEDS = 0, BB_SEED_CAP = 4096, BB_MXYZ = 4096, BB_RCAP = 7168, BB_BOXMAX = 8192, BB_EXT = 9216, BB_BAD = 16384,
-       BB_TOTAL = 1 << 20, XB_BOX_SEEDS_MAX = 1023 /* box ids fit the 10 key bits */ };
+       BB_TOTAL = 1 << 20, XB_BOX_SEEDS_MAX = 1023 /* box ids fit the 10 key bits */,
+       BB_REGMAX = 1 << 16, BB_REGFIRST = 1 << 17 /* maximum / first brick of up to XB_REGIONS_MAX regions (k_seed_bricks) */ };
 
 // (re)build the gradient-field table from the resident density; with `boxes`, also find and stamp
 // the trapping boxes around the 26-neighbour maxima (k_box_scan)
@@ -702,6 +704,7 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
 // trapping regions from the list of all 26-neighbour maxima: closed seed cubes, then brick growth
 static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks, bool ranges_from_rho) {
     const Grid &g = c->g;
+    c->box_max_tab = c->boxbuf + BB_BOXMAX;
     const int ns = (int)seeds.size();
     const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
     (void)nbr_all;
@@ -1045,14 +1048,14 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     if (c->regions_pending && c->blab) {
         if (g.nz % 4 == 0)
             k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
-                                                                    c->nbk[2], c->boxbuf + BB_BOXMAX, nullptr);
+                                                                    c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
         else
             k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
-                                                                   c->boxbuf + BB_BOXMAX, nullptr);
+                                                                   (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
         if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, c->boxbuf + BB_BOXMAX, c->first, buni, nullptr);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), c->first, buni, nullptr);
             if (c->n_walk)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
                                                                                 c->walk, c->n_walk, nullptr, nullptr, buni);
@@ -1093,9 +1096,12 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     int *fs = c->fs;
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
     int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
-    int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP, *box_max = c->boxbuf + BB_BOXMAX,
-        *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * XB_BOXES_MAX, *box_first = c->boxbuf + BB_EXT + 4 * XB_BOXES_MAX,
-        *bad = c->boxbuf + BB_BAD;
+    const bool sparse = c->opt_sparse != 0;
+    int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP,
+        *box_max = c->boxbuf + (sparse ? BB_REGMAX : BB_BOXMAX), *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * XB_BOXES_MAX,
+        *box_first = c->boxbuf + (sparse ? BB_REGFIRST : BB_EXT + 4 * XB_BOXES_MAX), *bad = c->boxbuf + BB_BAD;
+    int *bmaxv = walk;   // (free until the walk list is made)
+    c->box_max_tab = box_max;
     const int stride = XB_BOX_K + 4;
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));
@@ -1110,7 +1116,6 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     g.main_ties = 1;   // methods.neargrid's tie test (methods.py:324)
     const GridL gl = light(g);
     (void)gl0;
-    const bool sparse = c->opt_sparse != 0;
     {   // brick masks + seeds (+ the full table on the round-1 route, opt_sparse = 0)
         ScopedTimer t4(c, 4);
         {
@@ -1121,8 +1126,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             const bool sym = sym_grid(g, gs);
             if (sparse) {
                 // the assignment's tie rule (methods.py:324) is the template argument
-                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
-                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small, bmask, fs + FS_TIES);
+                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES);
+                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES);
             } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);
@@ -1133,21 +1138,26 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         c->grad_valid = true;
         c->grad_rule = 1;
         c->grad_cover = sparse ? 1 : 0;
-        // closed seed cubes around the maxima, then brick growth -- all decided on the device
-        k_box_setup<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
-        const long long wmax = 2LL * XB_BOX_K + 1;
-        if (sparse)   // no record exists yet: the shells derive their move intervals from rho
-            k_box_shells_dev<true><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
-        else
+        if (sparse) {
+            // seeds: the bricks that hold exactly one maximum (no cubes, no cap on the number of maxima); they are not
+            // fixed: the kill iteration certifies them like every other brick
+            k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
+            k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
+        } else {
+            // closed seed cubes around the maxima, then brick growth -- all decided on the device
+            k_box_setup<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
+            const long long wmax = 2LL * XB_BOX_K + 1;
             k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
-        k_box_pick<<<1, XB_BOXES_MAX, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
-        k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
+            k_box_pick<<<1, XB_BOXES_MAX, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
+            k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
+        }
         const int launches = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
-            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG);
-        k_fill<int><<<1, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_BOXES_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr);
+            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, sparse ? 0 : 1);
+        k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, sparse ? XB_REGIONS_MAX : XB_BOXES_MAX);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr,
+                                                 sparse ? 0 : 1);
         HIPCHK(hipGetLastError());
     }
     c->blab = c->blab_buf;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(XB_BOXES_MAX) void k_box_pick(int *fs, const int *_
 // changed nothing and flips the current buffer otherwise.  See k_brick_grow for the iteration itself.
 __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
                                                                  const int *__restrict__ seed, int *buf0, int *buf1, int *fs,
-                                                                 int inner) {
+                                                                 int inner, int seeds_fixed) {
     __shared__ int lab[2][BG + 2][BG + 2][BG + 2];
     __shared__ int s_any;
     const int phase = fs[FS_GROW_PHASE];
@@ -152,7 +152,12 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
     const bool active = b0 < nb0 && b1 < nb1 && b2 < nb2;
     const int b = active ? (b0 * nb1 + b1) * nb2 + b2 : 0;
     const int m = active ? bmask[b] : 0;
-    const bool fixed = !active || (phase == 0 && (m >> 27)) || (phase == 1 && seed[b] != 0);
+    // seeds_fixed: the seeds are closed cubes, trapping regions on their own (they never die).  Otherwise the seeds are
+    // the bricks that hold exactly one maximum (k_seed_bricks): such a brick may keep ITS OWN label through the kill
+    // iteration, but only under the same closure rule as every other brick
+    const int sd = active ? seed[b] : 0;
+    const bool fixed = !active || (phase == 0 && (m >> 27)) || (phase == 1 && seeds_fixed && sd != 0);
+    const bool own_seed_ok = !seeds_fixed && sd != 0 && !((m >> 28) & 1);
     __syncthreads();
     const int first = lab[0][t0 + 1][t1 + 1][t2 + 1];
     int l = first, cur = 0;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
                     nl = best;
                 }
             } else if (l > 0) {
-                bool ok = !(m >> 27);
+                bool ok = !(m >> 27) || (own_seed_ok && sd == l);
                 for (unsigned mm = (unsigned)m & 0x7ffffffu; mm && ok; mm &= mm - 1) {
                     const int k = __ffs(mm) - 1;
                     ok = (lab[cur][t0 + k / 9][t1 + (k / 3) % 3][t2 + k % 3] == l);
@@ -211,10 +216,12 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
 // numbering needs one note per region, not one per brick.
 __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restrict__ seed, const int *__restrict__ buf0,
                                                      const int *__restrict__ buf1, int *fs, int *__restrict__ blab,
-                                                     int *box_first, const int *__restrict__ bmask, unsigned char *brick_rec) {
+                                                     int *box_first, const int *__restrict__ bmask, unsigned char *brick_rec,
+                                                     int seeds_fixed) {
     __shared__ int s_first[XB_BOXES_MAX];
+    // without a fixpoint only closed cubes are regions on their own; seed BRICKS alone certify nothing
     const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
-    const int nbx = fs[FS_N_BOXES];
+    const int nbx = (fs[FS_GROW_CONVERGED] || seeds_fixed) ? fs[FS_N_BOXES] : 0;
     for (int i = threadIdx.x; i < XB_BOXES_MAX; i += TPB) s_first[i] = XB_INT_MAX;
     __syncthreads();
     int cnt = 0;
@@ -223,7 +230,8 @@ __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restr
         blab[b] = l;
         if (brick_rec) brick_rec[b] = (unsigned char)(((bmask[b] >> 27) & 1) << 1);   // no records yet; bit 1: holds a maximum
         cnt += (l > 0);
-        if (l > 0 && l <= XB_BOXES_MAX && s_first[l - 1] > b) atomicMin(&s_first[l - 1], b);
+        if (l > 0 && l <= XB_BOXES_MAX) { if (s_first[l - 1] > b) atomicMin(&s_first[l - 1], b); }
+        else if (l > XB_BOXES_MAX) atomicMin(&box_first[l - 1], b);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < XB_BOXES_MAX; i += TPB)
@@ -236,11 +244,36 @@ __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restr
 __global__ __launch_bounds__(XB_BOXES_MAX) void k_note_regions(GridL g, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ box_first,
                                                      const int *__restrict__ box_max, int *first, int *max_list, int *max_count,
                                                      int max_cap) {
-    const int t = threadIdx.x;
-    if (t >= fs[FS_N_BOXES] || box_first[t] == XB_INT_MAX) return;
-    const int b = box_first[t];
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    note_maximum(box_max[t], ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list, max_count, max_cap);
+    for (int t = threadIdx.x; t < fs[FS_N_BOXES]; t += blockDim.x) {
+        if (box_first[t] == XB_INT_MAX) continue;
+        const int b = box_first[t];
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        note_maximum(box_max[t], ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list, max_count, max_cap);
+    }
+}
+// Seeds of the brick growth WITHOUT cubes (the route of k_brick_masks): a brick that holds exactly one 26-neighbour
+// maximum starts with that maximum's region id.  No cap but the table size: a density with thousands of maxima (noise in
+// the vacuum of a real CHGCAR) still gets the regions of its atoms, and a brick with several maxima is simply never
+// certified.  Ids are handed out in arrival order (the basin numbering is decided later, by first voxel).
+#define XB_REGIONS_MAX 65535
+__global__ void k_seed_bricks(int nbr, const int *__restrict__ bmask, const int *__restrict__ bmaxv, int *fs, int *seed, int *buf0,
+                              int *box_max) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbr) return;
+    int id = 0;
+    if (((bmask[b] >> 27) & 3) == 1) {
+        const int k = atomicAdd(&fs[FS_N_SEEDS], 1);
+        if (k < XB_REGIONS_MAX) { id = k + 1; box_max[k] = bmaxv[b]; }
+    }
+    seed[b] = id;
+    buf0[b] = id;
+}
+__global__ void k_seed_finish(int *fs) {
+    const int n = min(fs[FS_N_SEEDS], XB_REGIONS_MAX);
+    fs[FS_N_SEEDS_EFF] = n;
+    fs[FS_N_BOXES] = n;
+    fs[FS_GROW_PHASE] = n ? 0 : 2;   // nothing to grow without a seed
+    fs[FS_GROW_CONVERGED] = 0;
 }
 __global__ void k_brick_seed_dev(GridL g, int nb0, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ mxyz,
                                  const int *__restrict__ radius, int *blab, int *blab2) {

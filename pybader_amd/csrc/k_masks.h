@@ -94,7 +94,7 @@ __device__ __forceinline__ void bm_cross(const GT &g, double c, double hx, doubl
 // one x-position K of the column: everything below the window update
 template <int MT, int K, typename GT>
 __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3], double dface, bool in, int v, int ty, int zz,
-                                         int &mine, bool &any_tie, int *seeds, int *seed_count, int seed_cap) {
+                                         int &mine, bool &any_tie, int *s_cnt, int *s_mv) {
     const double c = a[1][1][1];
     const double hx = a[2][1][1], lx = a[0][1][1], hy = a[1][2][1], ly = a[1][0][1], hz = a[1][1][2], lz = a[1][1][0];
     const bool tie = axis_tie(hx, c, lx) || axis_tie(hy, c, ly) || axis_tie(hz, c, lz);
@@ -167,10 +167,9 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
         }
     }
     if (in) {
-        if (is_max) {
-            const int q = atomicAdd(seed_count, 1);
-            if (q < seed_cap) seeds[q] = v;
-            mine |= 1 << 27;
+        if (is_max) {   // how many 26-neighbour maxima the brick holds, and one of them
+            atomicAdd(s_cnt, 1);
+            *s_mv = v;
         }
         // per axis the set of brick offsets {-1,0,+1} a move can reach (0 always: bit 1), then the 27-bit outer
         // product z -> y -> x by shifts (bit = (dx+1)*9 + (dy+1)*3 + (dz+1))
@@ -181,12 +180,12 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
 }
 
 template <typename GT, int MT>
-__global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int *seeds, int *seed_count,
-                                                     int seed_cap, int small, int *__restrict__ bmask, int *tie_count) {
+__global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
+                                                     int *__restrict__ bmaxv, int *tie_count) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
-    __shared__ int s_mask[GT_Z / 8];
+    __shared__ int s_mask[GT_Z / 8], s_cnt[GT_Z / 8], s_mv[GT_Z / 8];
     const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
-    if (threadIdx.x < GT_Z / 8) s_mask[threadIdx.x] = 0;
+    if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; }
     {   // row-wise staging, every load of a wave in flight before the first wait (see k_grad_field)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
         int Z = z0 + lane - 1;
@@ -241,8 +240,8 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
             a[2][iy][iz] = tile[K + 2][ty + iy][tz + iz];                                                            \
         }                                                                                                            \
         const int x = x0 + K;                                                                                        \
-        bm_voxel<MT, K>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie, seeds,    \
-                        seed_count, seed_cap);                                                                       \
+        bm_voxel<MT, K>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie,           \
+                        &s_cnt[tz >> 3], &s_mv[tz >> 3]);                                                            \
     }
     BM_STEP(0) BM_STEP(1) BM_STEP(2) BM_STEP(3) BM_STEP(4) BM_STEP(5) BM_STEP(6) BM_STEP(7)
 #undef BM_STEP
@@ -252,7 +251,10 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     __syncthreads();
     if (threadIdx.x < GT_Z / 8 && z0 + threadIdx.x * 8 < g.nz) {
         const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
-        bmask[((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x] = s_mask[threadIdx.x] & ~(1 << 13);
+        // bits 0-26: the neighbour bricks a move can reach; bit 27: the brick holds a 26-neighbour maximum, bit 28: two or more
+        const int b = ((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x, n = s_cnt[threadIdx.x];
+        bmask[b] = (s_mask[threadIdx.x] & 0x7ffdfff) | (n >= 1 ? 1 << 27 : 0) | (n >= 2 ? 1 << 28 : 0);
+        bmaxv[b] = n == 1 ? s_mv[threadIdx.x] : -1;
     }
 }
 

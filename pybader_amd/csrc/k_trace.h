@@ -116,7 +116,7 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *lab
                                                                const int *gate) {
     __shared__ int s_rank[XB_BOXES_MAX];
     if (gate && !*gate) return;
-    for (int i = threadIdx.x; i < fs[FS_N_BOXES]; i += TPB) s_rank[i] = rank[box_max[i]];
+    for (int i = threadIdx.x; i < min(fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
     __syncthreads();
     const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = blockIdx.z * 4 + (threadIdx.x >> 6);
     if (z >= g.nz || x >= g.nx) return;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *lab
     int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + by * 8) * g.nz + z));
     const int stride = g.nz >> 2;   // int4 per row
     if (b > 0) {
-        const int l = s_rank[b - 1];
+        const int l = b <= XB_BOXES_MAX ? s_rank[b - 1] : rank[box_max[b - 1]];
         const int4 v = make_int4(l, l, l, l);
 #pragma unroll
         for (int r = 0; r < 8; r++) p[r * stride] = v;

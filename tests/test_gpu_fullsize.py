@@ -212,3 +212,30 @@ def test_vacuum_at_scale_sparse_table_equals_full_table(method):
     if method == 'ongrid':
         assert res[0][3][0][1] > 0                                # the refinement relabels voxels
     print('deferred retraces', deferred)
+
+
+def test_noisy_vacuum_keeps_the_atoms_regions():
+    """What a real CHGCAR looks like: smooth atoms, noise in the low-density region -- thousands of spurious maxima.  Round 1
+    dropped every trapping region beyond 64 maxima; with the growth seeded by the bricks that hold exactly one maximum the
+    atoms keep theirs (no cap but the table), and the map still equals plain full-trajectory tracing."""
+    shape = (256,) * 3
+    dm, tg = matrices(shape, synth.CUBIC6)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    rho = ctx.download_density()
+    rng = np.random.default_rng(11)
+    low = rho < 0.2
+    rho = np.ascontiguousarray(rho + np.where(low, 2e-3 * rng.random(shape), 0.0))
+    ctx.upload_density(rho)
+    out = []
+    for opt in (0, 3):
+        ctx.set_option(1, opt)
+        ctx.vacuum_assign(None, 1.0)
+        n = ctx.assign('neargrid')
+        out.append((n, ctx.maxima(), ctx.download_labels(np.int32), ctx.box_stats()))
+    (n0, m0, l0, s0), (n1, m1, l1, s1) = out
+    assert n0 == n1 and n0 > 2000, n0                       # thousands of maxima, most of them noise
+    assert np.array_equal(m0, m1) and np.array_equal(l0, l1)
+    assert s1[0] > 1023 and s1[1] > 0.25 * 256 ** 3, s1     # regions survive (round 1: none beyond 64 maxima)
+    ctx.close()
