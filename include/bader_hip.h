@@ -176,8 +176,8 @@ int64_t xb_plane_elems(xb_ctx *c);
 /* copy whole x-planes [xa,xb) of labels/known between host and device (halo transport over the
  * host / gloo; the RCCL transport works on the device pointers above) */
 int xb_copy_planes(xb_ctx *c, int which /*0 labels,1 known*/, int to_device, void *host, int64_t xa, int64_t xb);
-/* the chunk [first, first+count) of the per-brick move masks (xb_brick_masks) from (to_device 1) or to (0) host
- * memory -- the host-staged fallback of xb_comm_share_brick_masks */
+/* the chunk [first, first+count) of the per-brick move masks (xb_brick_masks) and of the bricks' single-maximum voxels
+ * (2 * count ints: masks, then voxels) from (to_device 1) or to (0) host memory -- the host-staged fallback of xb_comm_share_brick_masks */
 int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, int64_t count);
 int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that hold valid neighbour data */
 
@@ -218,7 +218,8 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
 int xb_comm_allreduce_i64(xb_ctx *c, int64_t *inout, int64_t n, int op);
 /* n int64 from every rank, out[size * n] in rank order: maxima tables (thread_handlers.py:59-65), seeds */
 int xb_comm_allgather_i64(xb_ctx *c, const int64_t *in, int64_t n, int64_t *out);
-/* every rank's chunk [first[r], first[r]+count[r]) of the brick move masks (xb_brick_masks) to every rank */
+/* every rank's chunk [first[r], first[r]+count[r]) of the brick move masks (xb_brick_masks) and of the bricks'
+ * single-maximum voxels to every rank */
 int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *count);
 
 #ifdef __cplusplus

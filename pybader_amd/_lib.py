@@ -380,11 +380,11 @@ class Context:
     def brick_masks_copy(self, host, first, count):
         """the chunk [first, first+count) of the per-brick move masks: host=None downloads it, else uploads `host`"""
         if host is None:
-            out = np.empty(int(count), np.int32)
+            out = np.empty(2 * int(count), np.int32)     # the masks, then the bricks' single-maximum voxels
             check(self.lib.xb_brick_masks_copy(self.h, 0, _ptr(out), int(first), int(count)))
             return out
         buf = np.ascontiguousarray(host, np.int32)
-        assert buf.size == int(count)
+        assert buf.size == 2 * int(count)
         check(self.lib.xb_brick_masks_copy(self.h, 1, _ptr(buf), int(first), int(count)))
 
     # -- multi-GPU transport (csrc/comm.h: RCCL through the C ABI) ---------------------------------

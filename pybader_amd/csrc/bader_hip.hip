@@ -85,6 +85,8 @@ struct xb_ctx {
     int table_stage = 0;           // windowed build: 1 = records + masks done, 2 = trapping regions done
     std::vector<int> window_seeds; // maxima found in the owned planes (windowed build)
     bool window_ties = true;       // the window holds a voxel whose record depends on the tie rule (windowed build)
+    bool slab_sparse = false;      // windowed build by passes A / B (k_masks.h): masks for the own bricks, records for the
+                                   // uncertain bricks of the window; false: round 1's full record per window voxel
     int ec_local_n = 0;            // xb_edge_check_local -> xb_edge_check_local_fetch
     long long stat_deferred = 0;   // retraces redone by the from-rho kernel (sparse table)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
@@ -823,7 +825,10 @@ static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks, bool ra
         int ncertain = 0;
         if (int rc = read_counter(c, 11, &ncertain)) return rc;
         c->box_voxels = (long long)ncertain * BRK * BRK * BRK;
-        c->blab = blab;
+        // the labels move out of `list` (the refinement's edge list overwrites it, and the slab retraces still read them)
+        if (int rc = ensure_brick_bytes(c, nbr)) return rc;
+        HIPCHK(hipMemcpyAsync(c->blab_buf, blab, (size_t)nbr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        c->blab = c->blab_buf;
         c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
     }
     HIPCHK(hipStreamSynchronize(c->stream));  // host vectors must outlive the copies
@@ -867,6 +872,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     NEED_GRID("xb_assign_trace");
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    const int *box_max = nullptr;   // region id - 1 -> its maximum (set once the regions of this call exist)
     HIPCHK(hipMemsetAsync(c->counters, 0, 16 * sizeof(int), c->stream));
     if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
         k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
@@ -884,6 +890,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
             if (int rc = ensure_grad(c, true, true, true)) return rc;
         }
         c->g.main_ties = 1;   // methods.neargrid's stepping rule for everything the assignment traces
+        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX;
         {
             ScopedTimer t(c, 0);
             const int opt = c->opt_trace;
@@ -892,19 +899,19 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
             if (c->blab && slab_bricks) {
                 // trapping regions known per brick: fill them in one sweep, trace only the rest
                 const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
-                int *walk = c->blab + nbr;  // next scratch slice of `list` (see ensure_grad)
+                int *walk = c->list + 4 * nbr;  // a free slice of `list` (seed, masks and the two growth buffers come first)
                 c->walk = walk;
                 HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
                 k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
                                                                          (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, c->counters + 13);
                 if (c->has_vacuum) {
                     k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],
-                                                                        c->boxbuf + BB_BOXMAX, c->labels, c->first, c->max_list,
+                                                                        box_max, c->labels, c->first, c->max_list,
                                                                         c->counters + 0, c->max_cap);
                 } else {
                     k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(
                         light(g), c->nbk[0], c->nbk[1], c->nbk[2], (g.x0 / 8) * c->nbk[1] * c->nbk[2],
-                        (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, c->boxbuf + BB_BOXMAX, c->first, c->max_list,
+                        (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, box_max, c->first, c->max_list,
                         c->counters + 0, c->max_cap);
                     c->regions_pending = true;
                 }
@@ -915,7 +922,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     const long long waves = 8LL * nwalk;
                     ScopedTimer tw(c, 6);
                     (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
-                        light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
+                        light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
                         c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
                         maxsteps, opt, c->rho, c->dist_dev);
                 }
@@ -924,7 +931,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
                     : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
                 (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
-                    light(g), c->grad, c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], nullptr, 0, c->labels,
+                    light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], nullptr, 0, c->labels,
                     c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
                     maxsteps, opt, c->rho, c->dist_dev);
             }
@@ -971,21 +978,22 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 if (int rc = table_regions(c, seeds, true, true)) return rc;
             }
         }
+        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX;
         if (c->blab) {
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
-            int *walk = c->blab + nbr;
+            int *walk = c->list + 4 * nbr;
             c->walk = walk;
             HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
             k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, c->counters + 13);
             k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(light(g), c->nbk[0], c->nbk[1], c->nbk[2], 0, nbr, c->blab,
-                                                                          c->boxbuf + BB_BOXMAX, c->first, c->max_list,
+                                                                          box_max, c->first, c->max_list,
                                                                           c->counters + 0, c->max_cap);
             int nwalk = 0;
             if (int rc = read_counter(c, 13, &nwalk)) return rc;
             c->n_walk = nwalk;
             if (nwalk) {
                 HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));
-                k_og_walk<<<8 * nwalk, XB_WAVE, 0, c->stream>>>(light(g), c->boxbuf + BB_BOXMAX, c->blab, c->nbk[1], c->nbk[2], walk,
+                k_og_walk<<<8 * nwalk, XB_WAVE, 0, c->stream>>>(light(g), box_max, c->blab, c->nbk[1], c->nbk[2], walk,
                                                                nwalk, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap,
                                                                1 << 22, c->counters + 8);
                 HIPCHK(hipGetLastError());
@@ -1126,8 +1134,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             const bool sym = sym_grid(g, gs);
             if (sparse) {
                 // the assignment's tie rule (methods.py:324) is the template argument
-                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES);
-                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES);
+                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0);
+                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0);
             } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);
@@ -1955,8 +1963,49 @@ int xb_set_table_window(xb_ctx *c, int64_t margin) {
     c->table_margin = m8;
     return XB_OK;
 }
+static bool slab_sparse_ok(const xb_ctx *c) {
+    const Grid &g = c->g;
+    return c->opt_sparse && c->opt_boxes && c->opt_bricks && table_windowed(c) && g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 &&
+           g.x0 % BRK == 0 && g.x1 % BRK == 0 && g.ny >= 16 && g.nz >= 16 && 7LL * (c->N / (BRK * BRK * BRK)) <= c->N;
+}
 int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
     NEED_GRID("xb_table_build");
+    c->slab_sparse = false;
+    if (slab_sparse_ok(c)) {
+        // pass A over the OWN planes: move masks, maxima count and the single maximum of every own brick (k_brick_masks);
+        // the scheduler shares both arrays, xb_table_finish grows the regions and builds the records of the window
+        Grid &g = c->g;
+        const int nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = (g.nx / BRK) * nb1 * nb2;
+        if (int rc = ensure_brick_bytes(c, nbr)) return rc;
+        int *fs = c->fs, *bmask = c->list + nbr, *bmaxv = c->list + 4 * nbr;
+        HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
+        g.main_ties = 1;
+        {
+            ScopedTimer t4(c, 4);
+            ScopedTimer t5(c, 5);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.x1 - g.x0) / GT_X);
+            GridS gs;
+            if (sym_grid(g, gs)) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0);
+            else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0);
+        }
+        HIPCHK(hipGetLastError());
+        int ties = 0;
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_TIES, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ties = c->host_ints[0];
+        c->window_ties = ties != 0;
+        c->window_seeds.clear();
+        c->grad_valid = true;     // (records follow in xb_table_finish)
+        c->grad_cover = 1;
+        c->grad_rule = 1;
+        c->blab = nullptr;
+        c->n_boxes = 0; c->box_voxels = 0;
+        c->table_stage = 1;
+        c->slab_sparse = true;
+        if (n_local_seeds) *n_local_seeds = 0;
+        return XB_OK;
+    }
     if (int rc = ensure_grad(c, true, true, true)) return rc;
     if (n_local_seeds) *n_local_seeds = table_windowed(c) ? (int64_t)c->window_seeds.size() : 0;
     return XB_OK;
@@ -1990,6 +2039,56 @@ int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t an
     // the records serve both tie rules (and the regions are closed for the refinement's retraces too) only when NO
     // rank's window holds a tie voxel
     c->grad_rule = any_ties ? 1 : 2;
+    if (c->slab_sparse) {
+        // every rank holds every brick's mask / maximum now: the same seeding + growth as on one GPU (replicated: the brick
+        // arrays are tiny), then the 32-byte records for the uncertain bricks of THIS rank's window
+        Grid &g = c->g;
+        const GridL gl = light(g);
+        const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+        int *fs = c->fs;
+        int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *bmaxv = c->list + 4 * nbr,
+            *reclist = c->list + 5 * nbr;
+        int *box_max = c->boxbuf + BB_REGMAX, *box_first = c->boxbuf + BB_REGFIRST;
+        c->box_max_tab = box_max;
+        ScopedTimer t4(c, 4);
+        k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
+        k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
+        const int launches = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
+        const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
+        for (int l = 0; l < launches; l++)
+            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
+        k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
+        c->blab = c->blab_buf;
+        c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
+        // the bricks of the window (it may wrap round the grid) that lie outside the regions get their records
+        const int per_plane = nb1 * nb2, w0 = g.wx0 / BRK, wn = g.wlen / BRK;
+        const int run1 = std::min(wn, nb0 - w0);
+        k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, w0 * per_plane, (w0 + run1) * per_plane, c->blab, reclist,
+                                                                                   fs + FS_N_WALK);
+        if (wn > run1)
+            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, (wn - run1) * per_plane, c->blab, reclist, fs + FS_N_WALK);
+        {
+            ScopedTimer t7(c, 7);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            g.main_ties = 1;
+            GridS gs;
+            if (sym_grid(g, gs))
+                k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, reclist, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
+            else
+                k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, reclist, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->n_boxes = c->host_ints[FS_N_BOXES];
+        c->box_voxels = (long long)c->host_ints[FS_N_CERTAIN] * BRK * BRK * BRK;
+        if (!c->host_ints[FS_GROW_CONVERGED] || c->n_boxes == 0) c->blab = nullptr;   // no regions: plain tracing of the slab
+        (void)gl;
+        c->table_stage = 2;
+        c->table_prebuilt = true;
+        return XB_OK;
+    }
     int rc = XB_OK;
     if (n_seeds >= 1 && n_seeds <= XB_BOX_SEEDS_MAX) {
         std::vector<int> sv(n_seeds);
@@ -2030,9 +2129,15 @@ int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, 
     NEED_GRID("xb_brick_masks_copy");
     const int64_t nbr = c->N / 512;
     if (!host || first < 0 || count < 0 || first + count > nbr) return fail(XB_E_ARG, "xb_brick_masks_copy: bad chunk");
-    int *masks = c->list + nbr;
-    if (to_device) HIPCHK(hipMemcpyAsync(masks + first, host, count * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    else HIPCHK(hipMemcpyAsync(host, masks + first, count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // host holds 2 * count ints: the move masks of the chunk, then the single-maximum voxels (k_brick_masks)
+    int *masks = c->list + nbr, *maxvox = c->list + 4 * nbr;
+    if (to_device) {
+        HIPCHK(hipMemcpyAsync(masks + first, host, count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(maxvox + first, host + count, count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(host, masks + first, count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(host + count, maxvox + first, count * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;
 }

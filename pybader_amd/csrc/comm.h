@@ -195,13 +195,15 @@ int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *co
     if (int rc = comm_need(c, "xb_comm_share_brick_masks")) return rc;
     if (!c->has_grid) return fail(XB_E_STATE, "xb_comm_share_brick_masks: no grid");
     const int64_t nbr = c->N / 512;
-    int *masks = c->list + nbr;
+    int *masks = c->list + nbr, *maxvox = c->list + 4 * nbr;   // move masks; the brick's single maximum (k_brick_masks)
     for (int r = 0; r < c->comm->size; r++)
         if (first[r] < 0 || count[r] < 0 || first[r] + count[r] > nbr) return fail(XB_E_ARG, "xb_comm_share_brick_masks: bad chunk of rank %d", r);
     NCCLCHK(xbcomm::g_api.GroupStart());
     for (int r = 0; r < c->comm->size; r++)
-        if (count[r])
+        if (count[r]) {
             NCCLCHK(xbcomm::g_api.Broadcast(masks + first[r], masks + first[r], (size_t)count[r], xbcomm::ncclInt32, r, c->comm->comm, c->stream));
+            NCCLCHK(xbcomm::g_api.Broadcast(maxvox + first[r], maxvox + first[r], (size_t)count[r], xbcomm::ncclInt32, r, c->comm->comm, c->stream));
+        }
     NCCLCHK(xbcomm::g_api.GroupEnd());
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;

@@ -181,10 +181,11 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
 
 template <typename GT, int MT>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
-                                                     int *__restrict__ bmaxv, int *tie_count) {
+                                                     int *__restrict__ bmaxv, int *tie_count, int xbase) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
     __shared__ int s_mask[GT_Z / 8], s_cnt[GT_Z / 8], s_mv[GT_Z / 8];
-    const int x0 = blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
+    // (xbase: the first plane; a slab runs the pass over its own planes only, brick aligned)
+    const int x0 = xbase + blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
     if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; }
     {   // row-wise staging, every load of a wave in flight before the first wait (see k_grad_field)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;

@@ -50,14 +50,15 @@ class ThreadComm:
 
     def share_brick_masks(self, backend, chunks):
         import torch
-        tensor = device_views(backend.ctx)[2]
-        self.sh.cur[self.rank] = tensor
-        self.sh.barrier.wait()
-        for r, (first, count) in enumerate(chunks):
-            if r != self.rank and count:
-                tensor[first:first + count].copy_(self.sh.cur[r][first:first + count])
-        torch.cuda.synchronize()
-        self.sh.barrier.wait()
+        views = device_views(backend.ctx)
+        for tensor in (views[2], views[3]):      # the move masks, then the bricks' single-maximum voxels
+            self.sh.cur[self.rank] = tensor
+            self.sh.barrier.wait()
+            for r, (first, count) in enumerate(chunks):
+                if r != self.rank and count:
+                    tensor[first:first + count].copy_(self.sh.cur[r][first:first + count])
+            torch.cuda.synchronize()
+            self.sh.barrier.wait()
 
     def barrier(self):
         self.sh.barrier.wait()
@@ -149,6 +150,33 @@ def test_ongrid_plus_refine_all_slabs_equal_oracle(n, name, halo):
     assert np.array_equal(post, v)
     if halo == 3:
         assert fb > 0, 'the narrow halo is meant to exercise the escape fallback'
+
+
+@pytest.mark.parametrize('n,name,tag,halo', [(2, 'r64_noise04', 'ng_all_inf', 8), (4, 'r64_noise04', 'ng_changed_2', 8),
+                                             (2, 'r40_noise04', 'ng_changed_inf', 6), (3, 'r48_sig5', 'ng_all_inf', 8),
+                                             (2, 'r48_sig5_noise', 'ng_changed_2', 8), (2, 'r40_vac_noise', 'ng_changed_2', 8),
+                                             (2, 'r32_quant8', 'ng_all_inf', 8), (4, 'r32_quant8', 'ng_changed_inf', 4),
+                                             (3, 'r48_sig5_noise', 'ng_all_inf', 6)])
+def test_rough_densities_slabs_equal_the_pipeline(n, name, tag, halo):
+    """Noisy / rounded / plateau densities: with tie voxels (5-digit rounding) the refinement really relabels voxels
+    after a neargrid assignment; without them it must change nothing, region stop or not.
+    r64: slabs of whole bricks (brick masks + shared maxima, records for the window); r32 with 2 / 4
+    slabs the same with tie voxels and thousands of relabelled voxels; r40 / r48 with 3 slabs: slab boundaries inside
+    bricks (the full-record window table)."""
+    from rough_common import MODES, load_rough, pipeline_maps, refined, vac_tol
+    g, rho = load_rough(name)
+    if tag not in g.files:
+        pytest.skip('mode not recorded for this case')
+    maps = pipeline_maps(g, rho)
+    want, olog = refined(g, rho, maps, tag)
+    if name in ('r48_sig5_noise', 'r32_quant8'):   # (without tie voxels the own-trajectory map is a fixed point of the retraces)
+        assert sum(c for _, c in olog) > 0, 'the rounded cases are meant to change labels during the refinement'
+    mode, iters = MODES[tag]
+    pre, post, log, maxima, ch, vo, fb = run_slabs(n, g, rho, 'neargrid', mode, iters, halo, vac_tol(g))
+    assert np.array_equal(maxima, maps['maxima'])
+    assert np.array_equal(pre, maps['assign'].astype(np.int32))
+    assert [tuple(x) for x in log] == [tuple(x) for x in olog]
+    assert np.array_equal(post, want)
 
 
 def test_windowed_table_is_used_and_exact():

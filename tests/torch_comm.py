@@ -56,4 +56,6 @@ def device_views(ctx, device_index=0):
     kn = torch.as_tensor(_DevArray(lib.xb_known_ptr(h), (nx, plane), '|i1'), device=dev)
     ptr, n, _, _ = ctx.brick_masks() if all(s % 8 == 0 for s in ctx.shape) else (0, 0, 0, 0)
     masks = torch.as_tensor(_DevArray(ptr, (n,), '<i4'), device=dev) if n else None
-    return lab, kn, masks
+    # the bricks' single-maximum voxels live three brick arrays behind the masks (csrc: list + nbr / list + 4 nbr)
+    maxvox = torch.as_tensor(_DevArray(ptr + 3 * n * 4, (n,), '<i4'), device=dev) if n else None
+    return lab, kn, masks, maxvox
