@@ -118,6 +118,21 @@ int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_vo
 int xb_escaped_paths_fetch(xb_ctx *c, int64_t *starts, int64_t *offsets, int64_t *voxels, int8_t *complete);
 int xb_gather_voxels(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *labels_out, int8_t *known_out);
 int xb_scatter_voxels(xb_ctx *c, const int64_t *idx, int64_t n, const int32_t *labels_in, const int8_t *known_in);
+/* slab scheduler, escaped retraces carried on by their next owner.  A retrace that leaves this rank's valid planes is
+ * parked (known == -6) and exported as a walker: XB_WALKER_WORDS int64 holding its start voxel and label, the voxel it
+ * arrived at, the carried remainder, the path window and the step count (refinement.py:137-154, 200-235: everything
+ * the loop carries).  The scheduler all-gathers the walkers; xb_walkers_continue carries on the ones that arrived on a
+ * plane this rank owns (its labels / known are the authoritative ones there: a retrace only reads labels at known == 2
+ * voxels and maxima, which no retrace rewrites) and yields results -- int64 pairs (start voxel | final label << 32) --
+ * and the walkers that left its valid planes again; xb_walkers_apply applies the pairs whose voxel this rank owns
+ * exactly as the retrace would have (refinement.py:288-291).  A walker that needs the exact slow path (path window
+ * overflow) comes back as `stuck` and stays parked for xb_escaped_paths.  The reference has no counterpart: its
+ * thread blocks read one shared array (thread_handlers.py:128-236). */
+#define XB_WALKER_WORDS 10
+int xb_walkers_count(xb_ctx *c, int64_t *n_walkers, int64_t *n_results);
+int xb_walkers_fetch(xb_ctx *c, int64_t *walkers, int64_t *results);
+int xb_walkers_continue(xb_ctx *c, const int64_t *walkers, int64_t n);
+int xb_walkers_apply(xb_ctx *c, const int64_t *results, int64_t n, int64_t *changed, int64_t *stuck);
 /* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels) */
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
 /* refinement.edge_check across slabs ('changed' refinement on N GPUs): the greedy scan of refinement.py:420-427 is
@@ -168,7 +183,8 @@ int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t an
 
 /* ---- slab halo planes (multi-GPU) -------------------------------------------------------- */
 /* Device pointers of the label / known arrays and the plane size in elements, so that the slab
- * scheduler can hand plane ranges to RCCL (ncclSend/ncclRecv) or any other transport. */
+ * scheduler can hand plane ranges to RCCL (ncclSend/ncclRecv) or any other transport.  On a slab, writes through
+ * the label pointer must stay within the planes [x0 - halo, x1 + halo): the library keeps the rest zero. */
 void *xb_labels_ptr(xb_ctx *c);
 void *xb_known_ptr(xb_ctx *c);
 void *xb_density_ptr(xb_ctx *c);

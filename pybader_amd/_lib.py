@@ -45,6 +45,10 @@ SYMBOLS = {
     'xb_escaped_paths_fetch': (_int, [_vp, _vp, _vp, _vp, _vp]),
     'xb_gather_voxels': (_int, [_vp, _vp, _i64, _vp, _vp]),
     'xb_scatter_voxels': (_int, [_vp, _vp, _i64, _vp, _vp]),
+    'xb_walkers_count': (_int, [_vp, _pi64, _pi64]),
+    'xb_walkers_fetch': (_int, [_vp, _vp, _vp]),
+    'xb_walkers_continue': (_int, [_vp, _vp, _i64]),
+    'xb_walkers_apply': (_int, [_vp, _vp, _i64, _pi64, _pi64]),
     'xb_edge_check': (_int, [_vp, _pi64, _pi64]),
     'xb_edge_check_local': (_int, [_vp, _pi64]),
     'xb_edge_check_local_fetch': (_int, [_vp, _vp, _vp]),
@@ -290,6 +294,30 @@ class Context:
         lab = np.ascontiguousarray(labels, np.int32)
         kn = np.ascontiguousarray(known, np.int8)
         check(self.lib.xb_scatter_voxels(self.h, _ptr(idx), idx.size, _ptr(lab), _ptr(kn)))
+
+    WALKER_WORDS = 10
+
+    def walkers(self):
+        """(walkers, results) left by the last refine_trace / walkers_continue: (n, 10) int64 records of the retraces
+        that left this rank's valid planes, and the (start voxel | label << 32) pairs of the ones it finished"""
+        n, m = C.c_int64(), C.c_int64()
+        check(self.lib.xb_walkers_count(self.h, C.byref(n), C.byref(m)))
+        w = np.zeros((n.value, self.WALKER_WORDS), np.int64)
+        r = np.zeros(m.value, np.int64)
+        check(self.lib.xb_walkers_fetch(self.h, _ptr(w), _ptr(r)))
+        return w, r
+
+    def walkers_continue(self, walkers):
+        w = np.ascontiguousarray(walkers, np.int64).reshape(-1, self.WALKER_WORDS)
+        check(self.lib.xb_walkers_continue(self.h, _ptr(w), w.shape[0]))
+        return self.walkers()
+
+    def walkers_apply(self, results):
+        """-> (changed, stuck)"""
+        r = np.ascontiguousarray(results, np.int64).reshape(-1)
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_walkers_apply(self.h, _ptr(r), r.size, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def edge_check(self):
         a, b = C.c_int64(), C.c_int64()

@@ -166,6 +166,11 @@ class HostComm:
     def barrier(self):
         self.store.barrier()
 
+    def gather_rows(self, rows):
+        """every rank's (n_r, w) int64 rows, concatenated in rank order"""
+        rows = np.ascontiguousarray(rows, np.int64)
+        return np.concatenate(self.allgather(rows)) if self.size > 1 else rows
+
     def _staged(self, sends, recvs, fetch, store_back):
         """planes through the store: every rank publishes what it sends, picks what is addressed to it"""
         out = {(peer, xa, xb): fetch(xa, xb) for peer, xa, xb in sends}
@@ -234,6 +239,20 @@ class RcclComm(HostComm):
         if self.device:
             return self.ctx.comm_allreduce([int(v) for v in vals])
         return super().sum(*vals)
+
+    def gather_rows(self, rows):
+        rows = np.ascontiguousarray(rows, np.int64)
+        if not self.device:
+            return super().gather_rows(rows)
+        w = rows.shape[1]
+        counts = self.ctx.comm_allgather([rows.shape[0]]).reshape(-1)
+        cap = int(counts.max())
+        if cap == 0:
+            return rows[:0]
+        padded = np.zeros((cap, w), np.int64)
+        padded[:rows.shape[0]] = rows
+        got = self.ctx.comm_allgather(padded.reshape(-1)).reshape(self.size, cap, w)
+        return np.concatenate([got[r, :int(counts[r])] for r in range(self.size)])
 
     def exchange_planes(self, backend, which, sends, recvs):
         if not sends and not recvs:

@@ -76,6 +76,8 @@ struct xb_ctx {
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
+    bool buni_halo_safe = false;   // ... and marks every brick outside the owned planes that is not of a trapping region as mixed:
+                                   // it stays right when the peers' halo planes arrive (slabs, xb_assign_finish)
     bool regions_labels = false;   // the resident labels are the last neargrid assignment's (+ refinement): every voxel of a
                                    // trapping-region brick (blab > 0) still carries the region's label
     int n_walk = 0;                // bricks on the walk list of the last assignment
@@ -88,6 +90,12 @@ struct xb_ctx {
     bool slab_sparse = false;      // windowed build by passes A / B (k_masks.h): masks for the own bricks, records for the
                                    // uncertain bricks of the window; false: round 1's full record per window voxel
     int ec_local_n = 0;            // xb_edge_check_local -> xb_edge_check_local_fetch
+    int walk_n_out = 0;            // walkers exported by the last xb_refine_trace / xb_walkers_continue ...
+    void *walk_out_dev = nullptr;  // ... and where they lie (device)
+    std::vector<int64_t> walk_host, res_host;   // ... fetched: walkers (10 int64 each), result pairs (voxel | label << 32)
+    int walk_n_res = 0;            // (start voxel, label) pairs of the last xb_walkers_continue
+    void *walk_in = nullptr, *walk_out2 = nullptr, *walk_res = nullptr;   // xb_walkers_continue: incoming walkers, re-exported ones, results
+    long long walk_cap = 0;
     long long stat_deferred = 0;   // retraces redone by the from-rho kernel (sparse table)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
@@ -116,6 +124,7 @@ struct xb_ctx {
     int *blab_buf = nullptr;   // brick labels of the trapping regions (fused path), nbr ints
     long long blab_alloc = 0;
     bool labels_zero_pending = false;   // volumes_init without vacuum: labels := 0 is owed (see xb_vacuum_assign)
+    int zero_outside[3] = {-1, -1, -1}; // slab (x0, x1, halo) for which every label outside the planes [x0-halo, x1+halo) is known to be 0
     int opt_fused = 1;         // 0: the host-driven round-1 orchestration (kept for slabs and odd grids)
     int opt_trace_grid = 8192; // one-wave workgroups of the persistent trace
     int opt_trace_chunk = 1;   // items (4x4x4 eighths of a brick) per pull: 1 keeps the waves of an XCD on ~128 neighbouring bricks (2 MB of table, L2 resident); 32 per pull ran 1.8x slower
@@ -124,6 +133,8 @@ struct xb_ctx {
     unsigned long long *counters64 = nullptr;
     double *dsum = nullptr;
     int *host_ints = nullptr;  // pinned
+    char *pin = nullptr;       // pinned staging for the small host arrays a step uploads (pageable copies pin pages on the fly)
+    size_t pin_bytes = 0;
     std::vector<int> maxima_sorted;  // global, label order
     std::vector<int> local_max, local_first;
     bool first_clean = false;
@@ -247,7 +258,9 @@ void xb_destroy(xb_ctx *c) {
         for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     free_grid(c);
     hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum); hipFree(c->dist_dev); hipFree(c->boxbuf);
+    hipFree(c->walk_in); hipFree(c->walk_out2); hipFree(c->walk_res);
     hipHostFree(c->host_ints);
+    hipHostFree(c->pin);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -299,6 +312,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
         c->n_alloc = N;
         c->first_clean = false;
     }
+    c->zero_outside[0] = -1;
     Grid &g = c->g;
     if (g.nx != (int)shape[0] || g.ny != (int)shape[1] || g.nz != (int)shape[2]) c->grad_valid = false;
     if (dist_mat && !T_grad) return fail(XB_E_ARG, "xb_set_grid: dist_mat without T_grad");
@@ -483,6 +497,7 @@ static size_t dtype_size(int dtype) { return (dtype == XB_I8 || dtype == XB_I16 
 int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     NEED_GRID_RAW("xb_upload_labels");
     c->labels_zero_pending = false;   // every label is overwritten
+    c->zero_outside[0] = -1;
     c->list_valid = false;
     c->has_vacuum = true;
     c->buni_valid = false; c->regions_labels = false;
@@ -545,13 +560,26 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
         // true, so the result is all-zero labels and zero vacuum charge/volume -- no need to read rho.
         // On one slab the 4 B/voxel memset is deferred (settle_labels): the assignment that follows
         // overwrites every label without reading any.
-        if (c->g.x1 - c->g.x0 == c->g.nx) c->labels_zero_pending = true;
-        else HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+        // A slab clears its own + halo planes only once the others are known to be zero (they were cleared by an earlier
+        // call and nothing has written there since).
+        const Grid &g = c->g;
+        if (g.x1 - g.x0 == g.nx) c->labels_zero_pending = true;
+        else if (c->halo < 2 || (g.x1 - g.x0) + 2 * c->halo >= g.nx || c->zero_outside[0] != g.x0 || c->zero_outside[1] != g.x1 ||
+                 c->zero_outside[2] != c->halo) {
+            HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+            c->zero_outside[0] = g.x0; c->zero_outside[1] = g.x1; c->zero_outside[2] = c->halo;   // (nothing but plane uploads writes out there)
+        } else {
+            const int len = (g.x1 - g.x0) + 2 * c->halo, first = ((g.x0 - c->halo) % g.nx + g.nx) % g.nx;
+            const int run1 = std::min(len, g.nx - first);
+            HIPCHK(hipMemsetAsync(c->labels + (size_t)first * g.nyz, 0, (size_t)run1 * g.nyz * sizeof(int), c->stream));
+            if (len > run1) HIPCHK(hipMemsetAsync(c->labels, 0, (size_t)(len - run1) * g.nyz * sizeof(int), c->stream));
+        }
         c->has_vacuum = false;
         if (vac_charge) *vac_charge = 0.;
         if (vac_volume) *vac_volume = 0.;
         return XB_OK;
     }
+    c->zero_outside[0] = -1;
     HIPCHK(hipMemsetAsync(c->dsum, 0, sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
     k_vacuum_assign<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, vac_tol, c->dsum, c->counters64);
@@ -623,7 +651,7 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         ScopedTimer t(c, 4);
         int *buni = reinterpret_cast<int *>(c->st);
-        if (!c->buni_valid) k_label_uniform<<<(unsigned)nbr, TPB, 0, c->stream>>>(light(g), c->labels, nb1, nb2, buni);
+        if (!c->buni_valid) k_label_uniform<<<(unsigned)nbr, TPB, 0, c->stream>>>(light(g), c->labels, nb1, nb2, buni, 0, nbr);
         c->buni_valid = true;
         k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
         k_flag_mixed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, buni + nbr, c->brick_rec);
@@ -836,6 +864,38 @@ static int table_regions(xb_ctx *c, std::vector<int> seeds, bool bricks, bool ra
     return XB_OK;
 }
 
+// host -> device through the pinned staging buffer; `slot` bytes into it (several uploads of one call use disjoint slots).
+// The caller synchronises the stream before the buffer is reused.
+static int upload_pinned(xb_ctx *c, void *dst, const void *src, size_t bytes, size_t slot = 0) {
+    if (!bytes) return XB_OK;
+    if (slot + bytes > c->pin_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const size_t want = std::max<size_t>(2 * (slot + bytes), 1 << 20);
+        char *p = nullptr;
+        HIPCHK(hipHostMalloc(&p, want));
+        if (c->pin && slot) memcpy(p, c->pin, slot);
+        hipHostFree(c->pin);
+        c->pin = p; c->pin_bytes = want;
+    }
+    memcpy(c->pin + slot, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, c->pin + slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return XB_OK;
+}
+// device -> host the same way (waits for the stream)
+static int download_pinned(xb_ctx *c, void *dst, const void *src_dev, size_t bytes) {
+    if (!bytes) return XB_OK;
+    if (bytes > c->pin_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0;
+        const size_t want = std::max<size_t>(2 * bytes, 1 << 20);
+        HIPCHK(hipHostMalloc(&c->pin, want));
+        c->pin_bytes = want;
+    }
+    HIPCHK(hipMemcpyAsync(c->pin, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(dst, c->pin, bytes);
+    return XB_OK;
+}
 static int read_counter(xb_ctx *c, int idx, int *out) {
     HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -921,10 +981,26 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 if (nwalk) {
                     const long long waves = 8LL * nwalk;
                     ScopedTimer tw(c, 6);
-                    (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
-                        light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
-                        c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                        maxsteps, opt, c->rho, c->dist_dev);
+                    const unsigned nblk = (unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE));
+                    if (table_windowed(c)) {
+                        // the lean kernel first: a trajectory that leaves the table window lands on a list (in `stage`, its
+                        // length stays on the device) and is redone by the kernel that derives missing records from rho
+                        int *redo = (int *)c->stage;
+                        const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
+                        HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
+                        k_ng_trace<2, false><<<nblk, tpb, 0, c->stream>>>(
+                            light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
+                            c->first, c->max_list, c->counters + 0, c->max_cap, redo, c->counters + 15, redo_cap,
+                            maxsteps, opt, c->rho, c->dist_dev);
+                        k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
+                            light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->counters + 15, c->labels,
+                            c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                            maxsteps, c->rho, c->dist_dev);
+                    } else
+                        k_ng_trace<2, false><<<nblk, tpb, 0, c->stream>>>(
+                            light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
+                            c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                            maxsteps, opt, c->rho, c->dist_dev);
                 }
             } else {
                 const long long waves = (opt & 1)
@@ -1048,7 +1124,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     if (n_global) {
-        HIPCHK(hipMemcpyAsync(c->max_aux, c->maxima_sorted.data(), n_global * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (int rc = upload_pinned(c, c->max_aux, c->maxima_sorted.data(), n_global * sizeof(int))) return rc;
         k_set_rank<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
         HIPCHK(hipGetLastError());
     }
@@ -1068,6 +1144,19 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
                                                                                 c->walk, c->n_walk, nullptr, nullptr, buni);
             c->buni_valid = true;
+            c->buni_halo_safe = false;
+        } else if (!c->has_vacuum && g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0 && g.x0 % 8 == 0 && g.x1 % 8 == 0) {
+            // a slab: the regions' bricks are uniform on every rank, the owned walk-list bricks are scanned, every other
+            // brick counts as mixed -- right whatever the peers' halo planes bring, and no pass over the labels
+            const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+            int *buni = reinterpret_cast<int *>(c->st);
+            k_fill<int><<<64, TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), c->first, buni, nullptr);
+            if (c->n_walk)
+                k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
+                                                                                c->walk, c->n_walk, nullptr, nullptr, buni);
+            c->buni_valid = true;
+            c->buni_halo_safe = true;
         }
     } else
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, nullptr);
@@ -1338,23 +1427,52 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
         int *buni = nullptr;
         if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {  // whole bricks: per-brick label uniformity first
             buni = reinterpret_cast<int *>(c->st);             // N bytes >= N/512 ints; edge_check reuses st later
-            if (!c->buni_valid)
-                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
-            const int nbr = (int)(c->N / 512);
+            const int nbr = (int)(c->N / 512), per_plane = (g.ny / 8) * (g.nz / 8);
+            if (!c->buni_valid) {
+                // a slab only scans the bricks its sweep can look at (the swept planes +- one brick)
+                int b_off = 0, count = nbr;
+                if (!all && np + 32 < g.nx) {
+                    const int p0 = ((xa - 8) % g.nx + g.nx) % g.nx;
+                    b_off = (p0 / 8) * per_plane;
+                    count = ((np + 8 + 7 + (p0 % 8)) / 8 + 1) * per_plane;
+                }
+                k_label_uniform<<<(unsigned)count, TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni, b_off, nbr);
+                c->buni_halo_safe = false;
+            }
             k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
             buni += nbr;   // the sweep reads the 27-brick version
         }
-        dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
-        k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
-                                                       c->counters + 5, small, buni, c->grad_valid ? c->grad : nullptr,
-                                                       c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr, c->has_vacuum ? 0 : 1);
-        if (!whole)
-            k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
+        const GradRec *G = c->grad_valid ? c->grad : nullptr;
+        const unsigned char *brec = c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr;
+        if (whole || all) {
+            dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
+                                                           c->counters + 5, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            if (!whole)
+                k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
+        } else {
+            // a slab: the owned planes (their edges make the list), then the halo planes each side -- their edges go to a
+            // second list (in `stage`, length on the device) that only serves the dilation (refinement.py:385-404)
+            const int own = g.x1 - g.x0, side = c->halo - 1;
+            int *halo_list = (int *)c->stage;
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            GridL ga = gl;
+            ga.x0 = 0; ga.x1 = g.nx;    // (lists every edge of the planes it sweeps)
+            dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (own + ET_X - 1) / ET_X);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, g.x0, own, c->list,
+                                                           c->counters + 5, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            grid.z = (side + ET_X - 1) / ET_X;
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, xa, side, halo_list,
+                                                           c->counters + 6, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, g.x1 % g.nx, side, halo_list,
+                                                           c->counters + 6, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            k_edge_dilate_list<<<2048, TPB, 0, c->stream>>>(gl, c->known, halo_list, 0, c->counters + 6);
+        }
     }
     HIPCHK(hipGetLastError());
     int n = 0;
     if (int rc = read_counter(c, 5, &n)) return rc;
-    if (whole && n) {  // one slab: the list holds every edge, dilate from it
+    if ((whole || !all) && n) {  // the list holds every owned edge: dilate from it
         ScopedTimer t(c, 2);
         k_edge_dilate_list<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->known, c->list, n, nullptr);
         HIPCHK(hipGetLastError());
@@ -1466,6 +1584,7 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         if (e == hipSuccess) k_scatter_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, dlab, dkn, c->labels, c->known);
         c->list_valid = false;
         c->buni_valid = false; c->regions_labels = false;
+        c->zero_outside[0] = -1;
     } else {
         if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
         if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -1494,6 +1613,8 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     else if (int rc = compact(c, flag, &n)) return rc;
     c->list_valid = false;  // the retrace rewrites known
     c->buni_valid = false;  // ... and may relabel edge voxels; st is also edge_check's scratch
+    c->walk_n_out = 0; c->walk_n_res = 0; c->walk_out_dev = nullptr;
+    c->walk_host.clear(); c->res_host.clear();
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
@@ -1504,24 +1625,40 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
             const int regions_ok = brec && c->regions_labels && !c->has_vacuum ? 1 : 0;
             // slabs: the regions' brick labels stop a retrace when the labels are this assignment's, there is no vacuum and
             // the density has no tie voxel (the windowed masks are built under the assignment's tie rule only)
-            const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && c->grad_rule == 2 &&
+            const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && (c->grad_rule == 2 || c->slab_sparse) &&
                                        g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
-            if (table_windowed(c))   // slabs: the kernel with the from-rho fallback for voxels outside the table window
-                k_refine_trace<2, true><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
-                                                                           c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
-                                                                           c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0, slab_regions);
-            else {
-                // the lean kernel; the few retraces whose walk goes on through a brick without records are redone by
-                // the from-rho kernel (their count stays on the device: its grid strides over it)
-                HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
-                k_refine_trace<2, false><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
-                                                                            c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
-                                                                            c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, (int *)c->stage,
-                                                                            c->counters + 15, regions_ok, nullptr);
-                if (brec)
-                    k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, (int *)c->stage, 0, c->counters + 15,
+            // the lean kernel; the retraces whose walk goes on through a voxel without a record (a brick without records,
+            // a voxel outside the table window of a slab) or out of the valid planes of a slab are redone by the from-rho
+            // kernel (their count stays on the device: its grid strides over it).  On a slab that kernel parks the
+            // retraces that leave the valid planes AND exports them as walkers (xb_walkers_*).
+            const bool slab = g.vlen < g.nx;
+            int *defer = (int *)c->stage;
+            WalkerIO wio{};
+            if (flag == -2 && slab) {
+                const size_t off = (((size_t)n * sizeof(int)) + 255) & ~(size_t)255;
+                if (off + sizeof(Walker) <= c->stage_bytes) {
+                    HIPCHK(hipMemsetAsync(c->counters + 16, 0, sizeof(int), c->stream));
+                    wio.out = (Walker *)((char *)c->stage + off); wio.out_count = c->counters + 16;
+                    wio.out_cap = (int)std::min<size_t>((c->stage_bytes - off) / sizeof(Walker), 1u << 30);
+                    c->walk_out_dev = wio.out;
+                }
+            }
+            HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
+            k_refine_trace<2, false><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
                                                                         c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
-                                                                        c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0, nullptr);
+                                                                        c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, defer,
+                                                                        c->counters + 15, regions_ok, slab_regions, WalkerIO{});
+            if (brec || slab || table_windowed(c))
+                k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, defer, 0, c->counters + 15,
+                                                                    c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                    c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0,
+                                                                    slab_regions, wio);
+            if (wio.out) {
+                int k = 0;
+                if (int rc = read_counter(c, 16, &k)) return rc;
+                c->walk_n_out = std::min(k, wio.out_cap);
+                c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
+                if (int rc = download_pinned(c, c->walk_host.data(), wio.out, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
             }
         }
         HIPCHK(hipGetLastError());
@@ -1536,6 +1673,107 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     HIPCHK(hipStreamSynchronize(c->stream));
     if (changed) *changed = c->host_ints[0];
     if (escaped) *escaped = c->host_ints[1];
+    return XB_OK;
+}
+
+// ---- walkers: retraces that left this rank's valid planes, carried on by the rank that owns the plane they entered ----
+static int ensure_walker_bufs(xb_ctx *c, int64_t n) {
+    if (c->walk_cap >= n) return XB_OK;
+    (void)hipFree(c->walk_in); (void)hipFree(c->walk_out2); (void)hipFree(c->walk_res);
+    c->walk_in = c->walk_out2 = c->walk_res = nullptr; c->walk_cap = 0;
+    const size_t cap = (size_t)n + n / 2 + 4096;
+    HIPCHK(hipMalloc(&c->walk_in, cap * sizeof(Walker)));
+    HIPCHK(hipMalloc(&c->walk_out2, cap * sizeof(Walker)));
+    HIPCHK(hipMalloc(&c->walk_res, cap * 2 * sizeof(int)));
+    c->walk_cap = (long long)cap;
+    return XB_OK;
+}
+int xb_walkers_count(xb_ctx *c, int64_t *n_walkers, int64_t *n_results) {
+    NEED_GRID("xb_walkers_count");
+    if (n_walkers) *n_walkers = c->walk_n_out;
+    if (n_results) *n_results = c->walk_n_res;
+    return XB_OK;
+}
+int xb_walkers_fetch(xb_ctx *c, int64_t *walkers, int64_t *results) {
+    NEED_GRID("xb_walkers_fetch");
+    if (walkers && c->walk_n_out) memcpy(walkers, c->walk_host.data(), (size_t)c->walk_n_out * sizeof(Walker));
+    if (results && c->walk_n_res) memcpy(results, c->res_host.data(), (size_t)c->walk_n_res * sizeof(int64_t));
+    return XB_OK;
+}
+// `walkers`: n records of XB_WALKER_WORDS int64 (every rank's exports, any order).  The ones that arrive on a plane this
+// rank owns are carried on with this rank's labels / known: results = (start voxel, final label) pairs, the others
+// that leave the valid planes again are exported anew (xb_walkers_count / xb_walkers_fetch).
+int xb_walkers_continue(xb_ctx *c, const int64_t *walkers, int64_t n) {
+    NEED_GRID("xb_walkers_continue");
+    if (n < 0 || (n && !walkers)) return fail(XB_E_ARG, "xb_walkers_continue: bad arguments");
+    if (c->g.vlen >= c->g.nx) return fail(XB_E_STATE, "xb_walkers_continue: every plane is valid on this rank (no slab halo)");
+    const Grid &g = c->g;
+    c->walk_n_out = 0; c->walk_n_res = 0;
+    c->walk_host.clear(); c->res_host.clear();
+    if (!n) return XB_OK;
+    if (n > (1 << 28)) return fail(XB_E_LIMIT, "xb_walkers_continue: too many walkers");
+    c->g.main_ties = 0;
+    if (int rc = ensure_grad(c, false, false, false)) return rc;
+    const size_t bytes = (size_t)n * sizeof(Walker);
+    if (int rc = ensure_walker_bufs(c, n)) return rc;
+    if (int rc = upload_pinned(c, c->walk_in, walkers, bytes)) return rc;
+    HIPCHK(hipMemsetAsync(c->counters + 16, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters + 1, 0, 3 * sizeof(int), c->stream));
+    WalkerIO wio{};
+    wio.in = (const Walker *)c->walk_in;
+    wio.out = (Walker *)c->walk_out2; wio.out_count = c->counters + 16; wio.out_cap = (int)n;
+    wio.res = (int *)c->walk_res; wio.res_count = c->counters + 17;
+    wio.own0 = g.x0; wio.own1 = g.x1;
+    const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
+    const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && (c->grad_rule == 2 || c->slab_sparse) &&
+                               g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
+    const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+    k_refine_trace<2, true, true><<<nblocks((int)n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, nullptr, (int)n, nullptr,
+                                                                         c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                         c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0,
+                                                                         slab_regions, wio);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 16, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->walk_n_out = c->host_ints[0]; c->walk_n_res = c->host_ints[1];
+    c->walk_out_dev = wio.out;
+    c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
+    std::vector<int> pairs(2 * (size_t)c->walk_n_res);
+    if (int rc = download_pinned(c, c->walk_host.data(), wio.out, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
+    if (int rc = download_pinned(c, pairs.data(), wio.res, pairs.size() * sizeof(int))) return rc;
+    c->res_host.resize(c->walk_n_res);
+    for (int i = 0; i < c->walk_n_res; i++)
+        c->res_host[i] = (int64_t)(uint32_t)pairs[2 * i] | ((int64_t)pairs[2 * i + 1] << 32);
+    return XB_OK;
+}
+// `results`: n pairs (voxel | label << 32), every rank's.  The pairs whose voxel this rank owns are applied as the retrace
+// would have (refinement.py:288-291); stuck ones (the exact slow path is needed) stay parked for xb_escaped_paths.
+int xb_walkers_apply(xb_ctx *c, const int64_t *results, int64_t n, int64_t *changed, int64_t *stuck) {
+    NEED_GRID("xb_walkers_apply");
+    if (changed) *changed = 0;
+    if (stuck) *stuck = 0;
+    if (n < 0 || (n && !results)) return fail(XB_E_ARG, "xb_walkers_apply: bad arguments");
+    if (!n) return XB_OK;
+    if (n > (1 << 28)) return fail(XB_E_LIMIT, "xb_walkers_apply: too many results");
+    const Grid &g = c->g;
+    std::vector<int> pairs(2 * (size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t v = results[i] & 0xffffffffLL;
+        if (v >= c->N) return fail(XB_E_ARG, "xb_walkers_apply: voxel out of range");
+        pairs[2 * i] = (int)v; pairs[2 * i + 1] = (int)(results[i] >> 32);
+    }
+    if (int rc = ensure_walker_bufs(c, n)) return rc;
+    int *d = (int *)c->walk_res;    // (the results of the last xb_walkers_continue were fetched to the host already)
+    if (int rc = upload_pinned(c, d, pairs.data(), pairs.size() * sizeof(int))) return rc;
+    HIPCHK(hipMemsetAsync(c->counters + 18, 0, 2 * sizeof(int), c->stream));
+    k_walkers_apply<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(light(g), d, (int)n, g.x0, g.x1, c->labels, c->known,
+                                                                      c->counters + 18, c->counters + 19);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 18, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->list_valid = false; c->buni_valid = false;
+    if (changed) *changed = c->host_ints[0];
+    if (stuck) *stuck = c->host_ints[1];
     return XB_OK;
 }
 
@@ -1680,8 +1918,8 @@ int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64
     }
     int8_t *dcls = c->st + (c->N - n);   // the tail of `st` (its head receives the decisions of k_ec_collect)
     if (2 * n > c->N) return fail(XB_E_LIMIT, "xb_edge_check_global: list longer than half the grid");
-    HIPCHK(hipMemcpyAsync(c->list, i32.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dcls, cls, n, hipMemcpyHostToDevice, c->stream));
+    if (int rc = upload_pinned(c, c->list, i32.data(), n * sizeof(int))) return rc;
+    if (int rc = upload_pinned(c, dcls, cls, n, (n * sizeof(int) + 255) & ~(size_t)255)) return rc;
     k_scatter_byte<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->known, c->list, (int)n, (int8_t)-2);
     HIPCHK(hipGetLastError());
     // a processed voxel re-classifies its box (one plane each side) and a new edge among those rings its own box
@@ -1715,7 +1953,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {
             buni = reinterpret_cast<int *>(c->st);
             if (!c->buni_valid)
-                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni);
+                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni, 0, (int)(c->N / 512));
             const int nbr = (int)(c->N / 512);
             k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
             buni += nbr;
@@ -1746,11 +1984,11 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev,
                                                               c->grad_cover == 1 ? c->brick_rec : nullptr, (int *)c->stage, fs + FS_R_DEFER,
-                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0, nullptr);
+                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0, nullptr, WalkerIO{});
         if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
             k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
                                                                fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
-                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr);
+                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, WalkerIO{});
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1854,6 +2092,7 @@ int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *char
 
 int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap) {
     NEED_GRID("xb_volume_assign");
+    c->zero_outside[0] = -1;
     c->buni_valid = false; c->regions_labels = false;
     if (n_swap <= 0) return XB_OK;
     if (n_swap > c->max_cap) return fail(XB_E_LIMIT, "xb_volume_assign: swap table too long");
@@ -2117,7 +2356,9 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
     // (a slab's halo planes come from peers that ran the same assignment: the regions' labels stay what they are)
-    if (to_device) { c->list_valid = false; c->has_vacuum = c->has_vacuum || c->g.x1 - c->g.x0 == c->g.nx; c->buni_valid = false;
+    if (to_device && which == 0) c->zero_outside[0] = -1;
+    if (to_device) { c->list_valid = false; c->has_vacuum = c->has_vacuum || c->g.x1 - c->g.x0 == c->g.nx;
+                     c->buni_valid = c->buni_valid && c->buni_halo_safe && c->g.x1 - c->g.x0 < c->g.nx;
                      if (c->g.x1 - c->g.x0 == c->g.nx) c->regions_labels = false; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));

@@ -146,7 +146,7 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
     auto bad = [&](int peer, int64_t xa, int64_t xb) { return peer < 0 || peer >= c->comm->size || peer == c->comm->rank || xa < 0 || xb > g.nx || xa >= xb; };
     for (int i = 0; i < n_send; i++) if (bad(send_peer[i], send_xa[i], send_xb[i])) return fail(XB_E_ARG, "xb_comm_exchange_planes: bad send %d", i);
     for (int i = 0; i < n_recv; i++) if (bad(recv_peer[i], recv_xa[i], recv_xb[i])) return fail(XB_E_ARG, "xb_comm_exchange_planes: bad recv %d", i);
-    if (n_recv) { c->list_valid = false; c->buni_valid = false; }   // halo planes of peers that ran the same assignment
+    if (n_recv) { c->list_valid = false; c->buni_valid = c->buni_valid && c->buni_halo_safe; }   // halo planes of peers that ran the same assignment
     NCCLCHK(xbcomm::g_api.GroupStart());
     for (int i = 0; i < n_recv; i++)
         NCCLCHK(xbcomm::g_api.Recv(base + (size_t)recv_xa[i] * g.nyz * es, (size_t)(recv_xb[i] - recv_xa[i]) * g.nyz, dt, recv_peer[i],

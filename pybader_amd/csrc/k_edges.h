@@ -47,12 +47,14 @@ __device__ __forceinline__ void classify27(const Grid &g, const double *__restri
 // buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
 // Lets the edge sweep skip tiles whose whole 3x3x3 surroundings carry one label (no edge possible).
 #define XB_MIXED (-2147483647 - 1)
+// (b_off, nbr: the launch covers the bricks b_off, b_off + 1, ... modulo nbr -- slabs only scan the bricks of their planes)
 __global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__restrict__ labels, int nb1, int nb2,
-                                                       int *__restrict__ buni) {
+                                                       int *__restrict__ buni, int b_off, int nbr) {
     __shared__ int s_min, s_max;
     if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
     __syncthreads();
-    const int b = blockIdx.x;
+    int b = blockIdx.x + b_off;
+    if (b >= nbr) b -= nbr;
     const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
     int lo = 2147483647, hi = XB_MIXED;
     for (int t = threadIdx.x; t < 512; t += TPB) {
@@ -496,20 +498,49 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate(Grid g, int8_t *known, int 
 //  * otherwise the retrace goes to `defer_list` (redone by the RHO instantiation), but only if its walk has to go ON
 //    through the missing record: the path-membership test only needs a value <= the key q would have been pushed
 //    with (key_floor).
-template <int K, bool RHO>
+//
+// Slabs (WalkerIO): a retrace that leaves the valid planes before it ends is parked (known == -6) and its state at
+// the moment of arrival on the first invalid voxel is written to `wio.out` (Walker).  The scheduler hands the walkers
+// to the rank that owns that plane, which carries them on with the RESUME instantiation (its labels / known are the
+// authoritative ones there), writes (start voxel, final label) pairs for those that end and exports the others
+// again; the owner of the start voxel applies the pair (k_walkers_apply).  A retrace only reads labels at
+// known == 2 voxels / maxima, which no retrace rewrites, so where it is finished does not matter.
+struct Walker {          // 80 bytes, no padding; travels as 10 int64
+    int v, vol_num;      // start voxel and its label when the retrace started
+    int lp, lq;          // last voxel of the path, voxel just arrived at (not yet tested / pushed)
+    double dr0, dr1, dr2;
+    int widx[2];         // PathWindow<2>
+    double wval[2];
+    double m_old;
+    int steps, og_move;
+};
+struct WalkerIO {
+    const Walker *in;    // RESUME: the walkers of every rank; the ones arriving in [own0, own1) are carried on
+    Walker *out;         // exported walkers (null: escaped retraces are only parked)
+    int *out_count;
+    int out_cap;
+    int *res;            // RESUME: pairs (start voxel, final label; XB_WALKER_STUCK: needs the exact slow path)
+    int *res_count;
+    int own0, own1;
+};
+#define XB_WALKER_STUCK (-2147483647 - 1)
+
+template <int K, bool RHO, bool RESUME = false>
 __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n_host,
                                                       const int *n_dev, int *changed, int *escaped, int *ovf_list,
                                                       int *ovf_count, int ovf_cap, int maxsteps,
                                                       const double *__restrict__ rho, const double *__restrict__ gc,
                                                       const unsigned char *__restrict__ brick_rec, int *defer_list,
-                                                      int *defer_count, int regions_ok, const int *__restrict__ region_blab) {
+                                                      int *defer_count, int regions_ok, const int *__restrict__ region_blab,
+                                                      WalkerIO wio) {
+    static_assert(!RESUME || (RHO && K == 2), "walkers are carried on by the from-rho kernel");
     const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
     int n_ch = 0, n_es = 0;
   for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
     const int t = base + threadIdx.x;
-    const bool valid = t < n;
-    const int v = valid ? list[t] : 0;
+    bool valid = t < n;
+    int v = (valid && !RESUME) ? list[t] : 0;
     bool moving = false;
     int result = -3;  // terminal voxel index; -2 overflow; -4 escaped; -5 deferred to the from-rho kernel
     int px = 0, py = 0, pz = 0, lp = 0, steps = 0, vol_num = 0;
@@ -517,6 +548,28 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     GradRec rec = {0., 0., 0., 0.};
     PathWindow<K> w;
     w.init(0, 0.);
+    bool arrive = false, og_in = false;   // RESUME: the first pass of the loop only tests the voxel arrived at
+    int lq_in = 0;
+    if (RESUME) {
+        if (valid) {
+            const Walker wk = wio.in[t];
+            const int qx = wk.lq / g.nyz;
+            valid = qx >= wio.own0 && qx < wio.own1;
+            if (valid) {
+                v = wk.v; vol_num = wk.vol_num; lp = wk.lp; lq_in = wk.lq;
+                px = lp / g.nyz;
+                const int r = lp - px * g.nyz;
+                py = r / g.nz;
+                pz = r - py * g.nz;
+                dr0 = wk.dr0; dr1 = wk.dr1; dr2 = wk.dr2;
+                w.idx[0] = wk.widx[0]; w.idx[K - 1] = wk.widx[1];
+                w.val[0] = wk.wval[0]; w.val[K - 1] = wk.wval[1];
+                w.m_old = wk.m_old;
+                steps = wk.steps; og_in = wk.og_move != 0;
+                arrive = true; moving = true;
+            }
+        }
+    } else
     if (valid) {
         px = v / g.nyz;
         const int r = v - px * g.nyz;
@@ -537,10 +590,19 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     }
     while (__any(moving)) {
         if (moving) {
+            int qx = 0, qy = 0, qz = 0, lq = 0;
+            bool og_move = false;
+            if (RESUME && arrive) {   // the move was made by the rank the walker comes from
+                arrive = false;
+                lq = lq_in; og_move = og_in;
+                qx = lq / g.nyz;
+                const int r = lq - qx * g.nyz;
+                qy = r / g.nz;
+                qz = r - qy * g.nz;
+            } else {
             const int bits = key_bits(rec.key);
             const int code = bits & 63;
-            int qx, qy, qz, lq = 0;
-            bool og_move = (code == XB_STAY_CODE);
+            og_move = (code == XB_STAY_CODE);
             if (!og_move) {
                 ng_move_t(g, px, py, pz, rec, code, dr0, dr1, dr2, qx, qy, qz);
                 lq = lin3f(g, qx, qy, qz);
@@ -557,6 +619,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                     lq = lin3f(g, qx, qy, qz);
                 }
             }
+            }
             if (moving) {
                 const bool in_win = plane_in_window(g, qx);
                 const bool ok_plane = plane_valid(g, qx);
@@ -570,7 +633,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                 // enters a region ends in it with the region's label -- it no longer glides along a dividing surface for
                 // tens of planes, so a narrow label halo is enough and the remote path queries become rare
                 const bool in_region = region_blab && ok_plane && region_blab[((qx >> 3) * (g.ny >> 3) + (qy >> 3)) * (g.nz >> 3) + (qz >> 3)] > 0;
-                if (in_region || (!RHO && regions_ok && missing && ok_plane)) {
+                if (in_region || (!RHO && regions_ok && in_win && missing && ok_plane)) {
                     // q lies in a trapping region (closed, one label): the retrace ends in it whatever happens next --
                     // no record, no density, no membership test needed (q cannot be an old path voxel: the path would
                     // not have left the region)
@@ -581,7 +644,22 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                         if (RHO) nr = make_rec_rho(g, rho, gc, qx, qy, qz);
                         else nr.key = key_floor(rho[lq]);
                     }
-                    if (!ok_plane) { result = -4; moving = false; }
+                    if (!ok_plane) {
+                        result = (RHO || !defer_list) ? -4 : -5;   // (lean kernel on a slab: the from-rho pass redoes and exports it)
+                        moving = false;
+                        if (RHO && K == 2 && wio.out) {   // hand the walker over as it arrives at q
+                            const int k = atomicAdd(wio.out_count, 1);
+                            if (k < wio.out_cap) {
+                                Walker wk;
+                                wk.v = v; wk.vol_num = vol_num; wk.lp = lp; wk.lq = lq;
+                                wk.dr0 = dr0; wk.dr1 = dr1; wk.dr2 = dr2;
+                                wk.widx[0] = w.idx[0]; wk.widx[1] = w.idx[K - 1];
+                                wk.wval[0] = w.val[0]; wk.wval[1] = w.val[K - 1];
+                                wk.m_old = w.m_old; wk.steps = steps; wk.og_move = og_move ? 1 : 0;
+                                wio.out[k] = wk;
+                            }
+                        }
+                    }
                     else if ((!og_move && nr.key <= w.m_old) || ++steps > maxsteps) { result = -2; moving = false; }
                     else if (kq == 2) { result = lq; moving = false; }  // refinement.py:294-303
                     else if (!RHO && missing) { result = -5; moving = false; }
@@ -594,6 +672,16 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         }
     }
     int ch = 0, es = 0;
+    if (RESUME) {
+        if (valid) {
+            if (result == -4) es = 1;    // exported again: it left this rank's valid planes too
+            else {
+                const int k = atomicAdd(wio.res_count, 1);
+                wio.res[2 * k] = v;
+                wio.res[2 * k + 1] = result >= 0 ? labels[result] : XB_WALKER_STUCK;
+            }
+        }
+    } else
     if (valid) {
         if (result >= 0) {
             const int nv = labels[result];
@@ -612,6 +700,20 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         if (n_ch) atomicAdd(changed, n_ch);
         if (n_es) atomicAdd(escaped, n_es);
     }
+}
+
+// the (start voxel, final label) pairs of carried-on walkers, applied by the owner of the start voxel exactly as the
+// retrace itself would have (refinement.py:288-291); a stuck walker stays parked (known == -6)
+__global__ void k_walkers_apply(GridL g, const int *__restrict__ res, int n, int own0, int own1, int *labels, int8_t *known,
+                                int *changed, int *stuck) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int v = res[2 * t], nv = res[2 * t + 1];
+    const int x = v / g.nyz;
+    if (x < own0 || x >= own1) return;
+    if (nv == XB_WALKER_STUCK) { atomicAdd(stuck, 1); return; }
+    if (nv != labels[v]) { labels[v] = nv; known[v] = -2; atomicAdd(changed, 1); }
+    else known[v] = -1;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -335,6 +335,30 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     ng_walk_wave<K, WIN>(g, G, box_max, blab, nb1, nb2, walk != nullptr, sx, sy, sz, labels, first, max_list, max_count,
                          max_cap, ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc);
 }
+// Slabs: the start voxels the lean kernel could not finish (their trajectory leaves the table window) once more, with
+// the from-rho fallback.  The list and its length live on the device; the grid strides over it.
+template <int K>
+__global__ __launch_bounds__(TPB) void k_ng_trace_list(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+                                                       const int *__restrict__ blab, int nb1, int nb2,
+                                                       const int *__restrict__ vox, const int *n_dev, int *labels, int *first,
+                                                       int *max_list, int *max_count, int max_cap, int *ovf_list,
+                                                       int *ovf_count, int ovf_cap, int maxsteps,
+                                                       const double *__restrict__ rho, const double *__restrict__ gc) {
+    const int n = *n_dev;
+    for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
+        const int t = base + threadIdx.x;
+        int sx = g.x1, sy = 0, sz = 0;     // (a lane without work: not valid)
+        if (t < n) {
+            const int v = vox[t];
+            sx = v / g.nyz;
+            const int r = v - sx * g.nyz;
+            sy = r / g.nz;
+            sz = r - sy * g.nz;
+        }
+        ng_walk_wave<K, true>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, max_count, max_cap,
+                              ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc);
+    }
+}
 // Persistent form (single GPU, device-side control flow, k_fused.h): a fixed grid of one-wave workgroups pulls
 // 4x4x4 eighths of the walk-list bricks until none is left; the list length stays on the device.  One cursor per
 // XCD (each XCD takes the k-th contiguous eighth of the list first -- spatial neighbours read the same table

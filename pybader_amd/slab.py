@@ -206,18 +206,52 @@ class SlabRunner:
         if self.comm.size == 1:
             assert escaped == 0
             return changed
+        local_escaped = escaped
         with _Phase(self, 'sums'):
             changed, escaped = self.comm.sum(changed, escaped)
         if escaped:
-            # Some retraces walked out of [x0-halo+2, x1+halo-2) before meeting a known==2 voxel (they slide
-            # along a dividing surface for tens of planes).  They were parked (known == -6) untouched.
+            # Some retraces walked out of the valid planes before meeting a known==2 voxel (they slide along a
+            # dividing surface for tens of planes: about 1 % of them with a 16-plane halo at 512^3).  They were parked
+            # (known == -6) untouched and exported as walkers: the rank that owns the plane they entered carries them on.
             self.n_fallbacks += 1
-            with _Phase(self, 'escaped_path_queries'):
-                ch2 = self._resolve_escaped()
+            ch2, left = 0, local_escaped
+            if hasattr(self.be, 'walkers_continue') and hasattr(self.comm, 'gather_rows'):
+                with _Phase(self, 'walkers'):
+                    ch2, left = self._migrate_walkers(local_escaped)
             with _Phase(self, 'sums'):
-                ch2, = self.comm.sum(ch2)
+                ch2, left = self.comm.sum(ch2, left)
             changed += ch2
+            if left:      # no walker transport (host backend), or walkers that need the exact slow path
+                with _Phase(self, 'escaped_path_queries'):
+                    ch3 = self._resolve_escaped()
+                with _Phase(self, 'sums'):
+                    ch3, = self.comm.sum(ch3)
+                changed += ch3
         return changed
+
+    def _migrate_walkers(self, local_escaped):
+        """Rounds of: all-gather the open walkers together with the results of the round before; apply the results
+        that concern the owned voxels; carry on the walkers that arrived on an owned plane.  Every rank sees the same
+        gathered rows, so all of them leave the loop in the same round (no walker row left).  Returns (voxels
+        relabelled here, voxels still parked here)."""
+        words = self.be.WALKER_WORDS
+        rows, _ = self.be.walkers()
+        left = local_escaped - rows.shape[0]          # (an export buffer that ran full: those stay parked)
+        changed = 0
+        for _ in range(4 * self.comm.size + 16):
+            allrows = self.comm.gather_rows(rows)
+            is_res = allrows[:, 1] == -1               # result rows: word 0 = voxel | label << 32, word 1 = -1
+            if is_res.any():
+                ch, stuck = self.be.walkers_apply(allrows[is_res, 0])
+                changed += ch
+                left += stuck
+            if is_res.all():
+                return changed, left
+            w, res = self.be.walkers_continue(allrows[~is_res])
+            rrows = np.full((res.size, words), -1, np.int64)
+            rrows[:, 0] = res
+            rows = np.concatenate([w, rrows])
+        raise RuntimeError('walkers still travelling after a full tour of the ranks')
 
     def _resolve_escaped(self):
         """Finish the parked retraces without moving planes: a retrace's path depends on rho only (replicated),

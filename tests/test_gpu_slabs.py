@@ -60,6 +60,9 @@ class ThreadComm:
             torch.cuda.synchronize()
             self.sh.barrier.wait()
 
+    def gather_rows(self, rows):
+        return np.concatenate(self.allgather(np.ascontiguousarray(rows, np.int64)))
+
     def barrier(self):
         self.sh.barrier.wait()
 
