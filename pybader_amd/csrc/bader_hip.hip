@@ -1616,8 +1616,11 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     c->walk_n_out = 0; c->walk_n_res = 0; c->walk_out_dev = nullptr;
     c->walk_host.clear(); c->res_host.clear();
     HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
+    int n_changed = 0, n_escaped = 0;
     if (n) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        Walker *wio_out = nullptr;
+        int wio_cap = 0;
         if (int rc = ensure_grad(c, false, false, false)) return rc;
         {
             ScopedTimer t(c, 3);
@@ -1653,26 +1656,30 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
                                                                     c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
                                                                     c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0,
                                                                     slab_regions, wio);
-            if (wio.out) {
-                int k = 0;
-                if (int rc = read_counter(c, 16, &k)) return rc;
-                c->walk_n_out = std::min(k, wio.out_cap);
-                c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
-                if (int rc = download_pinned(c, c->walk_host.data(), wio.out, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
-            }
+            wio_out = wio.out; wio_cap = wio.out_cap;
         }
         HIPCHK(hipGetLastError());
-        int novf = 0;
-        if (int rc = read_counter(c, 1, &novf)) return rc;
+        // one wait for everything the kernels counted: overflows [1], changed [2], escaped [3], exported walkers [16]
+        HIPCHK(hipMemcpyAsync(c->host_ints, c->counters, 17 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const int novf = c->host_ints[1];
+        n_changed = c->host_ints[2]; n_escaped = c->host_ints[3];
+        if (wio_out) {
+            c->walk_n_out = std::min(c->host_ints[16], wio_cap);
+            c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
+            if (int rc = download_pinned(c, c->walk_host.data(), wio_out, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
+        }
         if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
         c->stat_ovf_refine += novf;
-        if (novf > 0)
+        if (novf > 0) {
             if (int rc = run_slow(c, novf, 1)) return rc;
+            HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            n_changed = c->host_ints[0]; n_escaped = c->host_ints[1];
+        }
     }
-    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (changed) *changed = c->host_ints[0];
-    if (escaped) *escaped = c->host_ints[1];
+    if (changed) *changed = n_changed;
+    if (escaped) *escaped = n_escaped;
     return XB_OK;
 }
 

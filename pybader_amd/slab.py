@@ -170,9 +170,11 @@ class SlabRunner:
             with _Phase(self, 'table_build'):
                 local = self.be.table_build()
             with _Phase(self, 'seeds_allgather'):
-                parts = self.comm.allgather((np.asarray(local).tolist(), bool(self.be.table_ties())))
-                seeds = sorted(set(int(v) for part, _ in parts for v in part))
-                any_ties = any(t for _, t in parts)
+                # (rows of one int64: the owned maxima the cube seeding wants, -1 - ties flag last; brick seeding sends the flag only)
+                mine = np.array(list(np.asarray(local).tolist()) + [-1 - int(bool(self.be.table_ties()))], np.int64).reshape(-1, 1)
+                got = self._gather_rows(mine).reshape(-1)
+                seeds = sorted(set(int(v) for v in got if v >= 0))
+                any_ties = bool((got == -2).any())
             with _Phase(self, 'mask_exchange'):
                 self.be.sync()
                 if getattr(self, '_chunks', None) is None:      # static for a given decomposition
@@ -187,12 +189,20 @@ class SlabRunner:
                 order = np.argsort(f, kind='stable')
                 maxima = np.asarray(m)[order]
             else:
-                maxima = merge_maxima_tables(self.comm.allgather((np.asarray(m), np.asarray(f))))
+                rows = self._gather_rows(np.stack([np.asarray(m, np.int64), np.asarray(f, np.int64)], axis=1).reshape(-1, 2))
+                maxima = merge_maxima_tables([(rows[:, 0], rows[:, 1])])
         with _Phase(self, 'assign_finish'):
             self.be.assign_finish(maxima)
         self.n_maxima = int(maxima.shape[0])
         self.maxima = maxima
         return self.n_maxima
+
+    def _gather_rows(self, rows):
+        """every rank's int64 rows in rank order: through the device transport when the communicator has one"""
+        rows = np.ascontiguousarray(rows, np.int64)
+        if hasattr(self.comm, 'gather_rows'):
+            return self.comm.gather_rows(rows)
+        return np.concatenate(self.comm.allgather(rows))
 
     def exchange_label_halo(self):
         if self.comm.size > 1:
