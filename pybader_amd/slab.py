@@ -245,6 +245,8 @@ class SlabRunner:
         gathered rows, so all of them leave the loop in the same round (no walker row left).  Returns (voxels
         relabelled here, voxels still parked here)."""
         words = self.be.WALKER_WORDS
+        nyz = self.shape[1] * self.shape[2]
+        x0, x1 = self.x_range
         rows, _ = self.be.walkers()
         left = local_escaped - rows.shape[0]          # (an export buffer that ran full: those stay parked)
         changed = 0
@@ -252,12 +254,16 @@ class SlabRunner:
             allrows = self.comm.gather_rows(rows)
             is_res = allrows[:, 1] == -1               # result rows: word 0 = voxel | label << 32, word 1 = -1
             if is_res.any():
-                ch, stuck = self.be.walkers_apply(allrows[is_res, 0])
+                res = allrows[is_res, 0]
+                plane = (res & 0xffffffff) // nyz      # only the pairs of owned voxels go to the card
+                ch, stuck = self.be.walkers_apply(res[(plane >= x0) & (plane < x1)])
                 changed += ch
                 left += stuck
             if is_res.all():
                 return changed, left
-            w, res = self.be.walkers_continue(allrows[~is_res])
+            wk = allrows[~is_res]
+            plane = ((wk[:, 1] >> 32) & 0xffffffff) // nyz     # word 1 = last voxel | voxel arrived at << 32
+            w, res = self.be.walkers_continue(wk[(plane >= x0) & (plane < x1)])
             rrows = np.full((res.size, words), -1, np.int64)
             rrows[:, 0] = res
             rows = np.concatenate([w, rrows])
