@@ -1021,6 +1021,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
             if (int rc = run_slow(c, novf, 0)) return rc;
         c->g.main_ties = 0;
     } else if (method == XB_METHOD_ONGRID) {
+        c->zero_outside[0] = -1;   // (the pointer pass writes the labels of every plane, on a slab too)
         const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
         // trapping regions of the pointer field (whole 8^3 bricks, one slab, no vacuum), else plain pointer jumping
         const bool regions = c->opt_boxes && c->opt_bricks && !c->has_vacuum && g.x1 - g.x0 == g.nx && g.nx % BRK == 0 &&

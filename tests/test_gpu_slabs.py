@@ -182,6 +182,55 @@ def test_rough_densities_slabs_equal_the_pipeline(n, name, tag, halo):
     assert np.array_equal(post, want)
 
 
+def test_slab_contexts_reused_across_assignments():
+    """The same N contexts run neargrid, ongrid and neargrid again (a pipeline that keeps its contexts): every piece of
+    state a step leaves behind -- table window, region labels, brick uniformity, which label planes are known to be
+    zero -- must be rebuilt or invalidated by the next one."""
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    n = 4
+    sh = Shared(n)
+    out = [None] * n
+
+    def work(rank):
+        try:
+            ctx = _lib.Context(0)
+            runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), ThreadComm(sh, rank), rho.shape, g['dist_mat'], g['T_grad'], halo=8)
+            runner.enable_table_window(8)
+            ctx.upload_density(rho)
+            x0, x1 = runner.x_range
+            got = []
+            for method in ('neargrid', 'ongrid', 'neargrid', 'neargrid'):
+                ctx.vacuum_assign(None, 1.0)
+                runner.assign(method)
+                pre = ctx.download_labels(np.int32)[x0:x1].copy()
+                log = runner.refine('changed', 2)
+                got.append((pre, ctx.download_labels(np.int32)[x0:x1].copy(), log))
+            out[rank] = (x0, got)
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            sh.errors.append(repr(e))
+            sh.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not sh.errors, sh.errors
+    out.sort(key=lambda r: r[0])
+    for k, method in enumerate(('neargrid', 'ongrid', 'neargrid', 'neargrid')):
+        pre = np.concatenate([r[1][k][0] for r in out])
+        post = np.concatenate([r[1][k][1] for r in out])
+        if method == 'neargrid':
+            assert np.array_equal(pre, g['ng_F'].astype(np.int32)), k
+            assert np.array_equal(post, g['ng_changed_2'].astype(np.int32)), k
+        else:
+            assert np.array_equal(pre, g['og_main'].astype(np.int32)), k
+            assert np.array_equal(post, g['og_ngrefine_changed_2'].astype(np.int32)), k
+            assert np.array_equal(np.array(out[0][1][k][2], np.int64).reshape(-1, 2), g['og_ngrefine_changed_2_log']), k
+
+
 def test_windowed_table_is_used_and_exact():
     """8 slabs of 8 planes on a 64^3 grid with a 8-plane table margin: every rank builds 24 of 64 planes of
     the table; walkers that leave the window fall back to the exact slow kernel."""
