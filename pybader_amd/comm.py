@@ -240,17 +240,23 @@ class RcclComm(HostComm):
             return self.ctx.comm_allreduce([int(v) for v in vals])
         return super().sum(*vals)
 
+    FAST_ROWS = 32     # contributions up to this many rows travel in ONE collective (count + rows, padded)
+
     def gather_rows(self, rows):
         rows = np.ascontiguousarray(rows, np.int64)
         if not self.device:
             return super().gather_rows(rows)
-        w = rows.shape[1]
-        counts = self.ctx.comm_allgather([rows.shape[0]]).reshape(-1)
+        n, w = rows.shape
+        first = np.zeros((self.FAST_ROWS + 1, w), np.int64)
+        first[0, 0] = n
+        first[1:1 + min(n, self.FAST_ROWS)] = rows[:self.FAST_ROWS]
+        got = self.ctx.comm_allgather(first.reshape(-1)).reshape(self.size, self.FAST_ROWS + 1, w)
+        counts = got[:, 0, 0]
         cap = int(counts.max())
-        if cap == 0:
-            return rows[:0]
+        if cap <= self.FAST_ROWS:       # the tie flags, the maxima rows, the last walker rounds
+            return np.concatenate([got[r, 1:1 + int(counts[r])] for r in range(self.size)])
         padded = np.zeros((cap, w), np.int64)
-        padded[:rows.shape[0]] = rows
+        padded[:n] = rows
         got = self.ctx.comm_allgather(padded.reshape(-1)).reshape(self.size, cap, w)
         return np.concatenate([got[r, :int(counts[r])] for r in range(self.size)])
 

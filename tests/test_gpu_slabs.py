@@ -266,6 +266,14 @@ def test_rccl_transport_through_the_c_abi_single_rank():
     assert n == 8 and np.array_equal(ctx.download_labels(np.int32), before)
     with pytest.raises(_lib.BaderHipError):
         ctx.comm_exchange_planes(0, [(0, 0, 1)], [])       # a send to myself is refused
+    # RcclComm.gather_rows through the device collectives (one rank: what comes back is what went in): the single
+    # collective for short contributions, the second one for long ones
+    from pybader_amd import comm as pcomm
+    rc = pcomm.RcclComm.__new__(pcomm.RcclComm)
+    rc.ctx, rc.size, rc.rank, rc.device = ctx, 1, 0, True
+    for nrows in (0, 1, pcomm.RcclComm.FAST_ROWS, pcomm.RcclComm.FAST_ROWS + 1, 1000):
+        rows = np.arange(nrows * 10, dtype=np.int64).reshape(nrows, 10) - 7
+        assert np.array_equal(rc.gather_rows(rows), rows)
     ctx.close()
 
 
