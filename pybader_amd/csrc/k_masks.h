@@ -31,6 +31,9 @@
 // tile row, wave 1 the purely high-side ones (y == 7 or z == 7), waves 2-3 (and the last lanes of 0-1) interior
 // columns.  An interior column needs the 27-point ongrid scan on the two x-faces of the brick only, and a field
 // that points the same way across the tile leaves one of the two border waves without any face to test.
+#ifndef BM_ROW
+#define BM_ROW 38   // row length of the LDS tile in doubles (34 are used): with the column order below the 9 reads per voxel
+#endif              // meet fewer bank conflicts at a stride of 38 or 39 -- worth 2 % of the kernel (0.918 -> 0.90 ms): LDS time hides behind the VALU work
 __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
     int bz, yy, zz;
     if (t < 60) {            // wave 0: per brick 13 low-side columns + 2 mixed corners
@@ -182,7 +185,7 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
 template <typename GT, int MT>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
                                                      int *__restrict__ bmaxv, int *tie_count, int xbase) {
-    __shared__ double tile[GT_X + 2][GT_Y + 2][GT_Z + 2];
+    __shared__ double tile[GT_X + 2][GT_Y + 2][BM_ROW];
     __shared__ int s_mask[GT_Z / 8], s_cnt[GT_Z / 8], s_mv[GT_Z / 8];
     // (xbase: the first plane; a slab runs the pass over its own planes only, brick aligned)
     const int x0 = xbase + blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
