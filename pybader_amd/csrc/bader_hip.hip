@@ -71,7 +71,7 @@ struct xb_ctx {
     int opt_ec_groups = 256;    // workgroups of k_ec_chase (at most one per CU)
     int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
     std::vector<int64_t> esc_starts, esc_offsets, esc_vox;  // xb_escaped_paths -> xb_escaped_paths_fetch
-    unsigned int *ec_pend = nullptr;  // edge_check's 16 bits per voxel (2 N bytes, allocated on first use)
+    unsigned long long *ec_pend = nullptr;  // edge_check's counter word per voxel (8 N bytes, allocated on first use)
     std::vector<int8_t> esc_complete;
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
@@ -1803,11 +1803,11 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
         // 'changed' refinement needs them).
         const int cap = (int)std::min<long long>(c->N, 1LL << 30);
         int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
-        if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 2 * (size_t)c->N + 16));
-        unsigned int *pend_w = c->ec_pend;
+        if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 8 * (size_t)c->N + 16));
+        ec_word *pend_w = c->ec_pend;
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-        if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, reinterpret_cast<uint16_t *>(pend_w));
-        else k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, reinterpret_cast<uint16_t *>(pend_w));
+        if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, pend_w);
+        else k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, pend_w);
         k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
                                                                                          c->counters + 6, cap);
         HIPCHK(hipGetLastError());

@@ -751,9 +751,17 @@ __global__ void k_walkers_apply(GridL g, const int *__restrict__ res, int n, int
 // The code below is written branch-free on purpose: with a branch per neighbour the compiler waits for every
 // load / atomic before it issues the next one (measured: ~20 serial round trips, 10 us per chain step).
 // ---------------------------------------------------------------------------------------------
+// Round 2: the word is 64 bits wide and also holds, in bits 32-58, WHICH box positions of the voxel are later listed
+// neighbours.  The atomicAdd that wakes a voxel returns that mask with the counters, the queue entry carries it, and
+// the consumer needs no load of its own before it notifies its neighbours: a chain step inside the chase is ONE
+// device-scope round trip (the notifications) instead of two (status claim + box loads, then the notifications).
+// A queue entry is unique by construction (exactly one notifier sees the first processed neighbour arrive / the
+// counter reach zero), so its status is published without waiting for the claim; only the blanket scan of round 1 and
+// the seeds it leaves (a voxel may be decided by its scan thread AND queued by a notifier) still claim first.
 #define EC_CNT 0x00FFu
 #define EC_NPROC 0x7F00u
 #define EC_CLS1 0x8000u
+typedef unsigned long long ec_word;
 __device__ __forceinline__ bool ec_listed(int8_t k) { return k == -2 || k == EC_PROC || k == EC_SKIP; }
 // status bytes of the 27-box of (x,y,z) as 9 words: byte (iz+1) of word (ix+1)*3+(iy+1); all loads in flight
 __device__ __forceinline__ void ec_box(const Grid &g, const int8_t *__restrict__ known, int x, int y, int z, int rows[9],
@@ -785,7 +793,7 @@ __device__ __forceinline__ int ec_box_voxel(const Grid &g, const int rows[9], in
 // pend[v] := (listed earlier neighbours) | (edge&max ? bit 15); every listed voxel once, nothing decided yet
 __global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
                                                  const int8_t *__restrict__ known, const int *__restrict__ list, int n,
-                                                 uint16_t *pend) {
+                                                 ec_word *pend) {
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= n) return;
     const int v = list[t];
@@ -796,10 +804,13 @@ __global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restric
     unsigned int w[9];
     ec_box(g, known, x, y, z, rows, w);
     int cnt = 0;
+    unsigned int later = 0;
 #pragma unroll
     for (int j = 0; j < 27; j++) {
         const int8_t k = (int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff);
-        cnt += (ec_box_voxel(g, rows, z, j) < v) & (k == -2);
+        const int u = ec_box_voxel(g, rows, z, j);
+        cnt += (u < v) & (k == -2);
+        later |= (unsigned int)((u > v) & (k == -2)) << j;
     }
     // class: edge & maximum.  A denser non-vacuum FACE neighbour already rules the maximum out (13 loads
     // instead of the 54 of the full classification)
@@ -817,7 +828,7 @@ __global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restric
         classify27(g, rho, labels, x, y, z, v, is_edge, is_max);
         cls1 = is_edge && is_max;
     }
-    pend[v] = (uint16_t)(cnt | (cls1 ? EC_CLS1 : 0u));
+    pend[v] = (ec_word)(cnt | (cls1 ? EC_CLS1 : 0u)) | ((ec_word)later << 32);
 }
 // Slabs: the class bit alone, for the owned listed voxels (their 27-boxes lie in label-valid planes) ...
 __global__ __launch_bounds__(TPB) void k_ec_class(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(TPB) void k_ec_class(Grid g, const double *__restri
 }
 // ... and the 16 bits of every voxel of the GLOBAL list from the classes their owners computed
 __global__ __launch_bounds__(TPB) void k_ec_init_cls(Grid g, const int8_t *__restrict__ known, const int *__restrict__ list, int n,
-                                                     const int8_t *__restrict__ cls, uint16_t *pend) {
+                                                     const int8_t *__restrict__ cls, ec_word *pend) {
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= n) return;
     const int v = list[t];
@@ -844,12 +855,15 @@ __global__ __launch_bounds__(TPB) void k_ec_init_cls(Grid g, const int8_t *__res
     unsigned int w[9];
     ec_box(g, known, x, y, z, rows, w);
     int cnt = 0;
+    unsigned int later = 0;
 #pragma unroll
     for (int j = 0; j < 27; j++) {
         const int8_t k = (int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff);
-        cnt += (ec_box_voxel(g, rows, z, j) < v) & (k == -2);
+        const int u = ec_box_voxel(g, rows, z, j);
+        cnt += (u < v) & (k == -2);
+        later |= (unsigned int)((u > v) & (k == -2)) << j;
     }
-    pend[v] = (uint16_t)(cnt | (cls[t] ? EC_CLS1 : 0u));
+    pend[v] = (ec_word)(cnt | (cls[t] ? EC_CLS1 : 0u)) | ((ec_word)later << 32);
 }
 __global__ void k_scatter_byte(int8_t *a, const int *__restrict__ idx, int n, int8_t value) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -863,50 +877,58 @@ __global__ void k_ec_keep_near(Grid g, const int *__restrict__ list, int n, int8
     if (d < 0) d += g.nx;
     if (d >= np) st[t] = 0;
 }
-// Decide v if its 16 bits allow it and tell the later listed neighbours; push(u) receives every voxel that became
-// decidable through this decision.  A voxel from the blanket scan of round 1 may not be decidable yet; one from
-// a queue always is.
-// `entry`: the voxel, with bit 31 set when the notifier already knows the decision is "skipped" and bit 30 when it
-// knows "processed" (queue entries carry it: the notifier has the neighbour's 16 bits from its atomic, which
-// saves the consumer a dependent load); neither bit: read the 16 bits (blanket scan of round 1).
+// Decide v if its word allows it and tell the later listed neighbours; push(e) receives, for every voxel that became
+// decidable through this decision, its queue entry.
+// `entry` (64 bits): bits 0-29 the voxel; bit 31 set when the notifier already knows the decision is "skipped", bit 30
+// when it knows "processed" (the notifier has the neighbour's word from its atomic); bits 32-58 the voxel's later
+// listed neighbours (from the same word).  Neither flag: read the word (blanket scan of round 1, where a voxel may not be
+// decidable yet).  CLAIM: wait for the status claim and give way to whoever decided the voxel first (blanket scan and
+// its seeds); without it the entry is known to be the only one for its voxel and the status is published on the side.
 #define EC_E_SKIP 0x80000000u
 #define EC_E_PROC 0x40000000u
-template <typename Push>
-__device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigned int *pend_w, unsigned int entry, Push push) {
+template <bool CLAIM, typename Push>
+__device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word *pend, ec_word entry, Push push) {
     const int v = (int)(entry & 0x3FFFFFFFu);
     int d;
-    if (entry & EC_E_SKIP) d = 2;
-    else if (entry & EC_E_PROC) d = 1;
-    else {
-        const unsigned int b = (__hip_atomic_load(pend_w + (v >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> ((v & 1) * 16)) & 0xffffu;
-        if (b & EC_CLS1) d = 1;
+    unsigned int later;
+    if ((entry & (EC_E_SKIP | EC_E_PROC)) && !CLAIM) {
+        d = (entry & EC_E_SKIP) ? 2 : 1;
+        later = (unsigned int)(entry >> 32);
+    } else {
+        const ec_word b = __hip_atomic_load(pend + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        later = (unsigned int)(b >> 32);
+        if (entry & EC_E_SKIP) d = 2;
+        else if (entry & EC_E_PROC) d = 1;
+        else if (b & EC_CLS1) d = 1;
         else if (b & EC_NPROC) d = 2;
         else if ((b & EC_CNT) == 0) d = 1;
         else return;  // still waiting for an earlier neighbour (blanket scan only)
+    }
+    {   // publish (and, CLAIM, claim): one atomicAnd clears the decision's bit of 0xFE; the returned word names the winner
+        const int sh = (v & 3) * 8;
+        unsigned int *word = reinterpret_cast<unsigned int *>(known + (v & ~3));
+        const unsigned int clr = ~((d == 1 ? 0x02u : 0x08u) << sh);
+        if (CLAIM) {
+            const unsigned int old = atomicAnd(word, clr);
+            if (((old >> sh) & 0xffu) != 0xFEu) return;
+        } else
+            __hip_atomic_fetch_and(word, clr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no wait
     }
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
     const int y = r / g.nz, z = r - y * g.nz;
     int rows[9];
-    unsigned int w[9];
-    ec_box(g, known, x, y, z, rows, w);  // issued before the claim below: the loads and the atomic travel together
-    {   // claim + publish: one atomicAnd clears the decision's bit of 0xFE; the returned word names the winner
-        const int sh = (v & 3) * 8;
-        const unsigned int old = atomicAnd(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh));
-        if (((old >> sh) & 0xffu) != 0xFEu) return;
-    }
-    // the later listed neighbours as a bit set over the box positions
-    unsigned int later = 0;
 #pragma unroll
-    for (int j = 0; j < 27; j++) {
-        const int u = ec_box_voxel(g, rows, z, j);
-        if ((u > v) & ec_listed((int8_t)((w[j / 3] >> (8 * (j % 3))) & 0xff))) later |= 1u << j;
+    for (int ix = -1; ix < 2; ix++) {
+        const int tx = wrapi(x + ix, g.nx);
+#pragma unroll
+        for (int iy = -1; iy < 2; iy++) rows[(ix + 1) * 3 + iy + 1] = (tx * g.ny + wrapi(y + iy, g.ny)) * g.nz;
     }
-    // One atomicAdd per neighbour, issued together in 10 slots (a voxel rarely has more later listed neighbours;
-    // the rest is handled one by one below; an empty slot adds 0 to v's own word, harmless and on the same cache
-    // line).  The atomics of a workgroup share one CU's address unit, so 10 instead of one per box position matters.
-    const unsigned int delta = d == 1 ? 0xFFu : 0xFFFFFFFFu;  // +0x100 - 1  |  -1   (shifted into the voxel's half)
-    unsigned int o[10];
+    // One atomicAdd per later listed neighbour, issued together in 10 slots (a voxel rarely has more; the rest is handled
+    // one by one below; an empty slot adds 0 to v's own word, harmless).  The atomics of a workgroup share one CU's
+    // address unit, so 10 instead of one per box position matters.
+    const ec_word delta = d == 1 ? 0xFFull : ~0ull;  // +0x100 - 1  |  -1  (the count never borrows: it counts this very neighbour)
+    ec_word o[10];
     int uu[10];
 #pragma unroll
     for (int s = 0; s < 10; s++) {
@@ -915,30 +937,33 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, unsigne
         later &= later - 1;
         const int u = hit ? ec_box_voxel(g, rows, z, j) : v;
         uu[s] = hit ? u : -1;
-        o[s] = atomicAdd(pend_w + (u >> 1), hit ? delta << ((u & 1) * 16) : 0u) >> ((u & 1) * 16);
+        o[s] = atomicAdd(pend + u, hit ? delta : 0ull);
     }
 #pragma unroll
     for (int s = 0; s < 10; s++) {
-        const unsigned int ob = o[s] & 0xffffu;
+        const unsigned int ob = (unsigned int)o[s] & 0xffffu;
         const bool wake = (uu[s] >= 0) & !(ob & (EC_NPROC | EC_CLS1)) & ((d == 1) | ((ob & EC_CNT) == 1));
         // first processed earlier neighbour: u gets skipped / the last one u waited for, none processed: processed
-        if (wake) push((unsigned int)uu[s] | (d == 1 ? EC_E_SKIP : EC_E_PROC));
+        if (wake) push((ec_word)((unsigned int)uu[s] | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o[s] & 0xFFFFFFFF00000000ull));
     }
     while (later) {  // the later neighbours beyond the slots
         const int u = ec_box_voxel(g, rows, z, __ffs(later) - 1);
         later &= later - 1;
-        const unsigned int ob = (atomicAdd(pend_w + (u >> 1), delta << ((u & 1) * 16)) >> ((u & 1) * 16)) & 0xffffu;
-        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1)) push((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC));
+        const ec_word ow = atomicAdd(pend + u, delta);
+        const unsigned int ob = (unsigned int)ow & 0xffffu;
+        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1))
+            push((ec_word)((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (ow & 0xFFFFFFFF00000000ull));
     }
 }
 // Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
-// decided, the voxels that become decidable through these decisions seed the chase.
-__global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, unsigned int *pend_w, const int *__restrict__ in,
+// decided, the voxels that become decidable through these decisions seed the chase (32-bit entries: the seeds read
+// their word again).
+__global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word *pend, const int *__restrict__ in,
                                                   int n, int *out, int *n_out, int out_cap) {
     for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
-        ec_resolve(g, known, pend_w, (unsigned int)in[e], [&](unsigned int u) {
+        ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)in[e], [&](ec_word u) {
             const int at = atomicAdd(n_out, 1);
-            if (at < out_cap) out[at] = (int)u;
+            if (at < out_cap) out[at] = (int)(unsigned int)u;
         });
 }
 // The rest: the dependency chains are ~1000 voxels long while only a few thousand voxels are decidable at any
@@ -950,11 +975,11 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, unsigne
 // 8-XCD gfx950 an agent-scope fence writes back and invalidates the XCD's L2 (~2 us each).
 // Queue overflows go to `ovf` and seed the next launch.
 #define EC_CHASE_THREADS 1024
-#define EC_Q 6000   // queue entries per buffer (2 buffers, 47 KB of LDS)
-__global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *known, unsigned int *pend_w,
+#define EC_Q 6000   // queue entries per buffer (2 buffers of 64-bit entries, 94 KB of LDS)
+__global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *known, ec_word *pend,
                                                                const int *__restrict__ seeds, int n_seeds, int *ovf,
                                                                int *n_ovf, int ovf_cap, int qcap) {
-    __shared__ int q[2][EC_Q];
+    __shared__ ec_word q[2][EC_Q];
     __shared__ int s_n[2];
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
@@ -967,17 +992,19 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
         if (n + take == 0) break;
         __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
         if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
-        int *nq = q[cur ^ 1], *n_next = &s_n[cur ^ 1];
+        ec_word *nq = q[cur ^ 1];
+        int *n_next = &s_n[cur ^ 1];
+        auto push = [&](ec_word u) {
+            const int at = atomicAdd(n_next, 1);
+            if (at < qcap) nq[at] = u;
+            else {  // queue full: hand over to the next launch (as a seed: it reads its word again)
+                const int o = atomicAdd(n_ovf, 1);
+                if (o < ovf_cap) ovf[o] = (int)(unsigned int)u;
+            }
+        };
         for (int e = threadIdx.x; e < n + take; e += EC_CHASE_THREADS) {
-            const unsigned int v = (unsigned int)(e < n ? q[cur][e] : seeds[seed_cur + e - n]);
-            ec_resolve(g, known, pend_w, v, [&](unsigned int u) {
-                const int at = atomicAdd(n_next, 1);
-                if (at < qcap) nq[at] = (int)u;
-                else {  // queue full: hand over to the next launch
-                    const int o = atomicAdd(n_ovf, 1);
-                    if (o < ovf_cap) ovf[o] = (int)u;
-                }
-            });
+            if (e < n) ec_resolve<false>(g, known, pend, q[cur][e], push);
+            else ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)seeds[seed_cur + e - n], push);
         }
         seed_cur += take;
         __syncthreads();  // the next round's queue is complete (every atomic's result was used: they have returned)
