@@ -933,6 +933,8 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     const int *box_max = nullptr;   // region id - 1 -> its maximum (set once the regions of this call exist)
+    int *max_count_dev = c->counters + 0;   // where the kernels of this call count the maxima they note
+    bool fast_slab = false;                 // windowed slab on passes A/B: the persistent trace, counts on the device
     HIPCHK(hipMemsetAsync(c->counters, 0, 16 * sizeof(int), c->stream));
     if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
         k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
@@ -961,23 +963,47 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
                 int *walk = c->list + 4 * nbr;  // a free slice of `list` (seed, masks and the two growth buffers come first)
                 c->walk = walk;
-                HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
+                fast_slab = table_windowed(c) && c->slab_sparse && c->opt_fused;
+                int *walk_count = c->counters + 13;
+                if (fast_slab) {   // the state block of the device-side control flow: list length, cursors, maxima and redo counts
+                    HIPCHK(hipMemsetAsync(c->fs, 0, FS_TOTAL * sizeof(int), c->stream));
+                    walk_count = c->fs + FS_N_WALK;
+                    max_count_dev = c->fs + FS_N_MAX;
+                } else
+                    HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
                 k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
-                                                                         (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, c->counters + 13);
+                                                                         (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, walk_count);
                 if (c->has_vacuum) {
                     k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],
                                                                         box_max, c->labels, c->first, c->max_list,
-                                                                        c->counters + 0, c->max_cap);
+                                                                        max_count_dev, c->max_cap);
                 } else {
                     k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(
                         light(g), c->nbk[0], c->nbk[1], c->nbk[2], (g.x0 / 8) * c->nbk[1] * c->nbk[2],
                         (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, box_max, c->first, c->max_list,
-                        c->counters + 0, c->max_cap);
+                        max_count_dev, c->max_cap);
                     c->regions_pending = true;
                 }
                 int nwalk = 0;
+                if (fast_slab) {
+                    // the persistent trace of the one-GPU path (per-XCD cursors over the list, its length on the device): no
+                    // host wait before it.  A trajectory that leaves the table window lands on a list (in `stage`) and is
+                    // redone by the kernel that derives missing records from rho.
+                    ScopedTimer tw(c, 6);
+                    int *redo = (int *)c->stage;
+                    const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
+                    k_ng_trace_p<2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                                                                                  c->fs, c->labels, c->first, c->max_list, c->max_cap, redo,
+                                                                                  redo_cap, maxsteps, c->has_vacuum ? 1 : 0,
+                                                                                  c->opt_trace_chunk, c->opt_trace_xcd);
+                    k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
+                        light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->fs + FS_N_OVF, c->labels,
+                        c->first, c->max_list, max_count_dev, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                        maxsteps, c->rho, c->dist_dev);
+                } else {
                 if (int rc = read_counter(c, 13, &nwalk)) return rc;
                 c->n_walk = nwalk;
+                }
                 if (nwalk) {
                     const long long waves = 8LL * nwalk;
                     ScopedTimer tw(c, 6);
@@ -1014,11 +1040,22 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         }
         HIPCHK(hipGetLastError());
         int novf = 0;
-        if (int rc = read_counter(c, 1, &novf)) return rc;
+        if (fast_slab) {   // one wait: overflows, the list length (xb_assign_finish scans those bricks)
+            HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(c->host_ints + 1, c->fs + FS_N_WALK, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            novf = c->host_ints[0];
+            c->n_walk = c->host_ints[1];
+        } else if (int rc = read_counter(c, 1, &novf)) return rc;
         if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
         c->stat_ovf_assign += novf;
-        if (novf > 0)
+        if (novf > 0) {
+            if (fast_slab) {   // the exact slow kernel counts its maxima in counters[0]: carry the count over
+                HIPCHK(hipMemcpyAsync(c->counters + 0, max_count_dev, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                max_count_dev = c->counters + 0;
+            }
             if (int rc = run_slow(c, novf, 0)) return rc;
+        }
         c->g.main_ties = 0;
     } else if (method == XB_METHOD_ONGRID) {
         c->zero_outside[0] = -1;   // (the pointer pass writes the labels of every plane, on a slab too)
@@ -1095,16 +1132,17 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     } else
         return fail(XB_E_ARG, "xb_assign: unknown method %d", method);
     int nmax = 0;
-    if (int rc = read_counter(c, 0, &nmax)) return rc;
+    HIPCHK(hipMemcpyAsync(c->host_ints, max_count_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    nmax = c->host_ints[0];
     if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
     c->local_max.resize(nmax);
     c->local_first.resize(nmax);
     if (nmax) {
         k_gather_first<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, c->max_aux);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->local_max.data(), c->max_list, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(c->local_first.data(), c->max_aux, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (int rc = download_pinned(c, c->local_max.data(), c->max_list, nmax * sizeof(int))) return rc;
+        if (int rc = download_pinned(c, c->local_first.data(), c->max_aux, nmax * sizeof(int))) return rc;
     }
     if (n_local) *n_local = nmax;
     return XB_OK;

@@ -210,15 +210,23 @@ class SlabRunner:
                 self.be.sync()
                 self.comm.exchange_planes(self.be, 0, self.sends, self.recvs)
 
-    def _trace(self):
+    def _trace(self, edges=None):
+        """one retrace pass over the flagged edge voxels; `edges`: this rank's edge count of the sweep before, summed
+        in the same collective as the pass's own counters.  Returns changed, or (changed, edges summed) when given."""
+        if edges is not None:
+            changed, total = self._trace_counted(edges)
+            return changed, total
+        return self._trace_counted(0)[0]
+
+    def _trace_counted(self, edges):
         with _Phase(self, 'refine_trace'):
             changed, escaped = self.be.refine_trace()
         if self.comm.size == 1:
             assert escaped == 0
-            return changed
+            return changed, edges
         local_escaped = escaped
         with _Phase(self, 'sums'):
-            changed, escaped = self.comm.sum(changed, escaped)
+            changed, escaped, edges = self.comm.sum(changed, escaped, edges)
         if escaped:
             # Some retraces walked out of the valid planes before meeting a known==2 voxel (they slide along a
             # dividing surface for tens of planes: about 1 % of them with a 16-plane halo at 512^3).  They were parked
@@ -237,7 +245,7 @@ class SlabRunner:
                 with _Phase(self, 'sums'):
                     ch3, = self.comm.sum(ch3)
                 changed += ch3
-        return changed
+        return changed, edges
 
     def _migrate_walkers(self, local_escaped):
         """Rounds of: all-gather the open walkers together with the results of the round before; apply the results
@@ -362,27 +370,25 @@ class SlabRunner:
                 self.be.prepare_refine()     # the retraces need the table anyway; edge_find profits from it
         with _Phase(self, 'edge_find'):
             edges = self.be.edge_find()
-        if self.comm.size > 1:
-            with _Phase(self, 'sums'):
-                edges, = self.comm.sum(edges)
+        # (the edge count travels with the retrace counters: one collective; without an edge anywhere the pass is empty)
+        changed, edges = self._trace(edges)
         if edges == 0:
             return log
-        changed = self._trace()
         log.append((edges, changed))
         it = 2
         while iters < 0 or it <= iters:
             if mode.lower() == 'all':
                 self.exchange_label_halo()
                 edges = self.be.edge_find()
-                if self.comm.size > 1:
-                    edges, = self.comm.sum(edges)
-            elif self.comm.size == 1:
-                _, edges = self.be.edge_check()
-            elif changed == 0:
-                edges = 0                      # no voxel is flagged -2: edge_check is the identity
+                changed, edges = self._trace(edges)
             else:
-                edges = self._edge_check_slabs()
-            changed = self._trace()
+                if self.comm.size == 1:
+                    _, edges = self.be.edge_check()
+                elif changed == 0:
+                    edges = 0                      # no voxel is flagged -2: edge_check is the identity
+                else:
+                    edges = self._edge_check_slabs()
+                changed = self._trace()
             log.append((edges, changed))
             if changed == 0:
                 break
