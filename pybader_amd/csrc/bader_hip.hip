@@ -1172,7 +1172,11 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     }
     c->buni_valid = false; c->regions_labels = false;
     if (c->regions_pending && c->blab) {
-        if (g.nz % 4 == 0)
+        if (g.nz % 4 == 0 && g.ny % 8 == 0 && g.x0 % 8 == 0 && g.x1 % 8 == 0 && c->nbk[1] == g.ny / 8)   // whole bricks: one brick-label lookup per 8 rows
+            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
+                light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX),
+                nullptr, nullptr, c->n_boxes);
+        else if (g.nz % 4 == 0)
             k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
                                                                     c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
         else
@@ -1492,6 +1496,36 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
                                                            c->counters + 5, small, buni, G, brec, c->has_vacuum ? 0 : 1);
             if (!whole)
                 k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
+        } else if (buni && g.x0 % ET_X == 0 && g.x1 % ET_X == 0 && g.ny % ET_Y == 0 &&
+                   (g.x1 - g.x0) + 2 * ((c->halo - 1 + ET_X - 1) / ET_X * ET_X) <= g.nx) {
+            // a slab of whole bricks: as on one GPU only the tiles that are not of one label with their surroundings are swept
+            // (`known` preset to 2 on the swept planes).  The owned planes' edges make the list; the halo planes each side
+            // (rounded out to whole tiles: the extra planes lie beyond the ones whose flags anything reads) give a second
+            // list (in `stage`, length on the device) that only serves the dilation (refinement.py:385-404)
+            const int own = g.x1 - g.x0, side4 = (c->halo - 1 + ET_X - 1) / ET_X * ET_X;
+            const int nty = g.ny / ET_Y, ntz = (g.nz + ET_Z - 1) / ET_Z;
+            const int left0 = ((g.x0 - side4) % g.nx + g.nx) % g.nx, right0 = g.x1 % g.nx;
+            auto preset = [&](int p0, int np_) -> int {
+                const int run1 = std::min(np_, g.nx - p0);
+                HIPCHK(hipMemsetAsync(c->known + (size_t)p0 * g.nyz, 2, (size_t)run1 * g.nyz, c->stream));
+                if (np_ > run1) HIPCHK(hipMemsetAsync(c->known, 2, (size_t)(np_ - run1) * g.nyz, c->stream));
+                return XB_OK;
+            };
+            if (int rc = preset(left0, side4 + own + side4)) return rc;
+            const int n_own = (own / ET_X) * nty * ntz, n_halo = 2 * (side4 / ET_X) * nty * ntz;
+            int *tiles_own = (int *)c->stage, *tiles_halo = tiles_own + n_own, *halo_list = tiles_halo + n_halo;
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            HIPCHK(hipMemsetAsync(c->counters + 22, 0, 2 * sizeof(int), c->stream));
+            GridL ga = gl;
+            ga.x0 = 0; ga.x1 = g.nx;    // (lists every edge of the planes it sweeps)
+            k_edge_tile_list<<<(n_own + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_own, c->counters + 22, g.x0 / ET_X, own / ET_X);
+            k_edge_tile_list<<<(n_halo / 2 + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_halo, c->counters + 23, left0 / ET_X, side4 / ET_X);
+            k_edge_tile_list<<<(n_halo / 2 + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_halo, c->counters + 23, right0 / ET_X, side4 / ET_X);
+            k_edge_flag_listed<<<n_own, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, c->counters + 5, small, G, brec,
+                                                            c->has_vacuum ? 0 : 1, tiles_own, c->counters + 22);
+            k_edge_flag_listed<<<n_halo, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, halo_list, c->counters + 6, small, G, brec,
+                                                             c->has_vacuum ? 0 : 1, tiles_halo, c->counters + 23);
+            k_edge_dilate_list<<<2048, TPB, 0, c->stream>>>(gl, c->known, halo_list, 0, c->counters + 6);
         } else {
             // a slab: the owned planes (their edges make the list), then the halo planes each side -- their edges go to a
             // second list (in `stage`, length on the device) that only serves the dilation (refinement.py:385-404)
@@ -2014,7 +2048,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
             int *tiles = (int *)c->stage;
             HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
             HIPCHK(hipMemsetAsync(fs + FS_N_TILES, 0, sizeof(int), c->stream));
-            k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES);
+            k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES, 0, g.nx / ET_X);
             k_edge_flag_listed<<<ntiles, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
                                                            c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1, tiles, fs + FS_N_TILES);
         } else {

@@ -369,13 +369,19 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
 // surroundings are swept -- a sixth of the 65 536 tiles at 512^3, whose early-exit workgroups cost a third of the sweep.
 // k_edge_tile_list: one thread per tile, the buni3 test of edge_tile; entry = tile index, bit 31 set for a tile of
 // uniform VACUUM (its flags are 0, refinement.py:342-343).
-__global__ __launch_bounds__(TPB) void k_edge_tile_list(GridL g, const int *__restrict__ buni3, int *tiles, int *n_tiles) {
+// (tx_lo, tx_n: the tile planes tx_lo, tx_lo + 1, ... modulo nx / ET_X -- a slab lists the tiles of its own planes and of
+// its halo planes separately)
+__global__ __launch_bounds__(TPB) void k_edge_tile_list(GridL g, const int *__restrict__ buni3, int *tiles, int *n_tiles, int tx_lo,
+                                                        int tx_n) {
     const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = g.ny / ET_Y, ntx = g.nx / ET_X;
-    const int t = blockIdx.x * TPB + threadIdx.x;
+    const int i = blockIdx.x * TPB + threadIdx.x;
     bool hit = false;
     unsigned entry = 0;
-    if (t < ntx * nty * ntz) {
-        const int tz = t % ntz, ty = (t / ntz) % nty, tx = t / (ntz * nty);
+    if (i < tx_n * nty * ntz) {
+        int tx = tx_lo + i / (ntz * nty);
+        if (tx >= ntx) tx -= ntx;
+        const int tz = i % ntz, ty = (i / ntz) % nty;
+        const int t = (tx * nty + ty) * ntz + tz;
         const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
         const int bxa = (tx * ET_X) >> 3, bxb = (tx * ET_X + ET_X - 1) >> 3, nbz = min(ET_Z / 8, nb2 - ((tz * ET_Z) >> 3));
         int lab = XB_MIXED;

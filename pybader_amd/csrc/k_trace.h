@@ -113,13 +113,14 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions4_3d(GridL g, int *label
 __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *labels, const int *__restrict__ rank,
                                                                const int *__restrict__ blab, int nb1, int nb2,
                                                                const int *__restrict__ box_max, const int *__restrict__ fs,
-                                                               const int *gate) {
+                                                               const int *gate, int n_boxes = -1) {
     __shared__ int s_rank[XB_BOXES_MAX];
     if (gate && !*gate) return;
-    for (int i = threadIdx.x; i < min(fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
+    // (n_boxes: the number of regions when the caller knows it -- a slab, whose planes x0..x1 the launch covers)
+    for (int i = threadIdx.x; i < min(n_boxes >= 0 ? n_boxes : fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
     __syncthreads();
-    const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = blockIdx.z * 4 + (threadIdx.x >> 6);
-    if (z >= g.nz || x >= g.nx) return;
+    const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = g.x0 + blockIdx.z * 4 + (threadIdx.x >> 6);
+    if (z >= g.nz || x >= g.x1) return;
     const int b = blab[((x >> 3) * nb1 + by) * nb2 + (z >> 3)];
     int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + by * 8) * g.nz + z));
     const int stride = g.nz >> 2;   // int4 per row
