@@ -178,8 +178,8 @@ def main():
     ap.add_argument('--halo', type=int, default=None,
                     help='label planes valid each side of a slab (default 16 for N > 1: a retrace stops when it enters a '
                          'trapping region; whatever still leaves the valid planes is finished by remote path queries)')
-    ap.add_argument('--table-margin', type=int, default=32,
-                    help='planes of gradient-field table each side of a slab (N > 1)')
+    ap.add_argument('--table-margin', type=int, default=None,
+                    help='planes of gradient-field table each side of a slab (N > 1; default max(32, nx / 16))')
     args = ap.parse_args()
     mode, iters = args.refine.split(':')
     iters = int(iters)
@@ -222,6 +222,8 @@ def main():
 
     halo = args.halo if args.halo is not None else (16 if world > 1 else 8)
     runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=halo)
+    if args.table_margin is None:
+        args.table_margin = max(32, shape[0] // 16)
     windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
     ctx.enable_timing(True)

@@ -144,10 +144,13 @@ class SlabRunner:
             self.be.sync()
             comm.selftest_planes(self.be, self.ranges)
 
-    def enable_table_window(self, margin=32):
+    def enable_table_window(self, margin=None):
         """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks
-        everywhere).  Returns whether the window is active."""
+        everywhere; default margin: 32 planes, nx / 16 on larger grids -- trajectories that leave the window are redone
+        from rho, 1.4 ms of an 8.8 ms trace at 1024^3 with 32 planes, 0.8 with 64).  Returns whether the window is active."""
         nx, ny, nz = self.shape
+        if margin is None:
+            margin = max(32, nx // 16)
         ok = (self.comm.size > 1 and hasattr(self.be, 'set_table_window') and nx % 8 == 0 and ny % 8 == 0 and nz % 8 == 0
               and all(a % 8 == 0 and b % 8 == 0 for a, b in self.ranges)
               and (self.x_range[1] - self.x_range[0]) + 2 * (margin + 7) // 8 * 8 < nx)

@@ -110,7 +110,7 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--ranks', type=int, nargs='+', default=[1, 2, 4, 8])
     ap.add_argument('--halo', type=int, default=16)
-    ap.add_argument('--margin', type=int, default=32)
+    ap.add_argument('--margin', type=int, default=None)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--mode', default='changed')
