@@ -90,3 +90,91 @@ def test_slabs_over_the_products_own_host_transport(tmp_path):
     r2 = run_world(2, ['c12_cubic', 'neargrid', 'changed', '2'], tmp_path, 29622, 4, transport='tcp')
     g2 = load_golden('c12_cubic')
     assert np.array_equal(r2['post'], g2['ng_changed_2'].astype(np.int32))
+
+
+def test_walker_rounds_bookkeeping_with_a_mock_backend():
+    """SlabRunner._migrate_walkers on CPU: four ranks (threads) with a mock backend whose walkers need a given number of
+    hops.  Every walker's result must reach the owner of its start voxel exactly once, walkers must only be handed to
+    the rank that owns the plane they arrived on, and all ranks must leave the loop in the same round."""
+    import threading
+
+    shape, n = (32, 4, 4), 4
+    nyz = shape[1] * shape[2]
+    ranges = slab.slab_ranges(shape[0], n)
+    barrier = threading.Barrier(n)
+    slots = [None] * n
+
+    class Comm:
+        def __init__(self, rank):
+            self.rank, self.size = rank, n
+
+        def gather_rows(self, rows):
+            slots[self.rank] = np.ascontiguousarray(rows, np.int64)
+            barrier.wait()
+            out = np.concatenate(list(slots))
+            barrier.wait()
+            return out
+
+    def owner_of(voxel):
+        return next(r for r, (a, b) in enumerate(ranges) if a <= voxel // nyz < b)
+
+    class Backend:
+        WALKER_WORDS = 10
+
+        def __init__(self, rank):
+            self.rank, self.applied, self.continued, self.rounds = rank, [], 0, 0
+            x0, x1 = ranges[rank]
+            # three walkers per rank, needing 0, 1 and 2 more hops; they arrive on the next slab's first plane
+            rows = np.zeros((3, 10), np.int64)
+            for k in range(3):
+                v = (x0 * nyz + k) | ((100 + rank) << 32)                  # start voxel | label
+                arrive = (x1 % shape[0]) * nyz
+                rows[k] = [v, (x1 - 1) * nyz | (arrive << 32), 0, 0, 0, 0, 0, 0, 0, k]
+            self.rows = rows
+
+        def walkers(self):
+            return self.rows, np.zeros(0, np.int64)
+
+        def walkers_continue(self, rows):
+            x0, x1 = ranges[self.rank]
+            out, res = [], []
+            for row in np.asarray(rows).reshape(-1, 10):
+                plane = ((row[1] >> 32) & 0xffffffff) // nyz
+                assert x0 <= plane < x1, 'a walker was handed to a rank that does not own its plane'
+                self.continued += 1
+                if row[9] > 0:                                             # walks on into the next slab
+                    nxt = row.copy()
+                    nxt[9] -= 1
+                    nxt[1] = (x1 - 1) * nyz | (((x1 % shape[0]) * nyz) << 32)
+                    out.append(nxt)
+                else:                                                      # ends here: label 7 for everybody
+                    res.append((row[0] & 0xffffffff) | (7 << 32))
+            return (np.array(out, np.int64).reshape(-1, 10), np.array(res, np.int64))
+
+        def walkers_apply(self, res):
+            self.rounds += 1
+            for r in np.asarray(res).reshape(-1):
+                v = int(r & 0xffffffff)
+                assert owner_of(v) == self.rank, 'a result pair reached a rank that does not own the voxel'
+                self.applied.append(v)
+            return len(res), 0
+
+    backends = [Backend(r) for r in range(n)]
+    got = [None] * n
+
+    def work(rank):
+        runner = slab.SlabRunner.__new__(slab.SlabRunner)
+        runner.be, runner.comm, runner.shape = backends[rank], Comm(rank), shape
+        runner.x_range = ranges[rank]
+        got[rank] = runner._migrate_walkers(3)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r, be in enumerate(backends):
+        x0 = ranges[r][0]
+        assert sorted(be.applied) == [x0 * nyz + k for k in range(3)]      # each of its walkers came back exactly once
+        assert got[r] == (3, 0)                                            # (changed here, still parked here)
+    assert sum(be.continued for be in backends) == n * (1 + 2 + 3)         # a walker is carried on once per hop + once to end
