@@ -178,3 +178,48 @@ def test_walker_rounds_bookkeeping_with_a_mock_backend():
         assert sorted(be.applied) == [x0 * nyz + k for k in range(3)]      # each of its walkers came back exactly once
         assert got[r] == (3, 0)                                            # (changed here, still parked here)
     assert sum(be.continued for be in backends) == n * (1 + 2 + 3)         # a walker is carried on once per hop + once to end
+
+
+@pytest.mark.parametrize('counts', [(0, 0, 0, 0), (1, 0, 3, 2), (32, 32, 1, 0), (0, 33, 0, 5), (1000, 7, 0, 250)])
+def test_rccl_gather_rows_padding_logic_with_a_mock_context(counts):
+    """RcclComm.gather_rows (the only per-step gather on a multi-GPU node) against a context whose comm_allgather is played
+    by threads: the one-collective path for short contributions, the second collective for long ones, ragged and empty
+    ranks, rank order of the result."""
+    import threading
+    from pybader_amd import comm as pcomm
+
+    n, w = len(counts), 10
+    barrier = threading.Barrier(n)
+    slots = [None] * n
+    calls = [0] * n
+
+    class Ctx:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def comm_allgather(self, vals):
+            slots[self.rank] = np.ascontiguousarray(vals, np.int64).reshape(-1).copy()
+            calls[self.rank] += 1
+            barrier.wait()
+            assert len({a.size for a in slots}) == 1, 'ncclAllGather needs equal contributions'
+            out = np.concatenate(slots)
+            barrier.wait()
+            return out
+
+    rows = [np.arange(c * w, dtype=np.int64).reshape(c, w) + 1000000 * (r + 1) for r, c in enumerate(counts)]
+    got = [None] * n
+
+    def work(rank):
+        rc = pcomm.RcclComm.__new__(pcomm.RcclComm)
+        rc.ctx, rc.size, rc.rank, rc.device = Ctx(rank), n, rank, True
+        got[rank] = rc.gather_rows(rows[rank])
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    want = np.concatenate(rows)
+    for r in range(n):
+        assert got[r].shape == want.shape and np.array_equal(got[r], want)
+    assert len(set(calls)) == 1 and calls[0] == (1 if max(counts) <= pcomm.RcclComm.FAST_ROWS else 2)
