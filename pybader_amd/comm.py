@@ -203,12 +203,21 @@ class RcclComm(HostComm):
         try:
             with _stdout_to_stderr():
                 ctx.comm_init(self.rank, self.size, uid)
-            n = self.size
-            ok = ctx.comm_allreduce([self.rank + 1, 1]) == [n * (n + 1) // 2, n]
-            ok = ok and ctx.comm_allgather([self.rank, 7 * self.rank]).reshape(n, 2).tolist() == [[r, 7 * r] for r in range(n)]
         except _lib.BaderHipError as err:
             ok = False
             self.init_error = str(err)
+        # first vote (over the store): a rank without a communicator must keep the others out of the device collectives,
+        # which would wait for it for ever
+        if all(self.allgather(bool(ok))):
+            try:
+                n = self.size
+                ok = ctx.comm_allreduce([self.rank + 1, 1]) == [n * (n + 1) // 2, n]
+                ok = ok and ctx.comm_allgather([self.rank, 7 * self.rank]).reshape(n, 2).tolist() == [[r, 7 * r] for r in range(n)]
+            except _lib.BaderHipError as err:
+                ok = False
+                self.init_error = str(err)
+        else:
+            ok = False
         self.device = all(self.allgather(bool(ok)))     # unanimous: every rank takes the same transport
         if self.device:
             self.transport = 'rccl'

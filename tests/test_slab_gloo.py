@@ -223,3 +223,71 @@ def test_rccl_gather_rows_padding_logic_with_a_mock_context(counts):
     for r in range(n):
         assert got[r].shape == want.shape and np.array_equal(got[r], want)
     assert len(set(calls)) == 1 and calls[0] == (1 if max(counts) <= pcomm.RcclComm.FAST_ROWS else 2)
+
+
+@pytest.mark.parametrize('broken_rank', [None, 1])
+def test_rccl_comm_start_up_is_unanimous_with_a_mock_context(broken_rank):
+    """RcclComm.__init__ over the product's own SocketStore (threads as ranks) with a mock context: the unique id travels
+    from rank 0, the collective self-test decides the transport, and ONE rank whose communicator fails takes every rank to
+    the host-staged transport."""
+    import threading
+    import uuid
+    from pybader_amd import _lib, comm as pcomm
+
+    n = 3
+    key = 'test_' + uuid.uuid4().hex
+    barrier = threading.Barrier(n)
+    slots = [None] * n
+    seen_uid = [None] * n
+
+    class Ctx:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def comm_unique_id(self):
+            return bytes(range(128))
+
+        def comm_init(self, rank, size, uid):
+            seen_uid[rank] = bytes(uid)
+            if rank == broken_rank:
+                raise _lib.BaderHipError('mock: no communicator on this rank')
+
+        def _gather(self, vals):
+            slots[self.rank] = np.ascontiguousarray(vals, np.int64).reshape(-1).copy()
+            barrier.wait()
+            out = [a.copy() for a in slots]
+            barrier.wait()
+            return out
+
+        def comm_allreduce(self, vals, op='sum'):
+            return np.sum(self._gather(vals), axis=0).tolist()
+
+        def comm_allgather(self, vals):
+            return np.concatenate(self._gather(vals))
+
+    out = [None] * n
+    errors = []
+
+    def work(rank):
+        try:
+            store = pcomm.SocketStore(rank, n, key=key, timeout=60.0)
+            ctx = Ctx(rank)
+            rc = pcomm.RcclComm(ctx, store)
+            out[rank] = (rc.device, rc.transport, rc.sum(rank + 1, 10))
+            store.barrier()
+            store.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert all(u == bytes(range(128)) for u in seen_uid)
+    if broken_rank is None:
+        assert out == [(True, 'rccl', [6, 30])] * n
+    else:   # nobody entered a device collective (the mock's would have waited for the broken rank for ever); sums go over the store
+        assert out == [(False, 'host-staged-tcp', [6, 30])] * n
