@@ -291,3 +291,22 @@ def test_rccl_comm_start_up_is_unanimous_with_a_mock_context(broken_rank):
         assert out == [(True, 'rccl', [6, 30])] * n
     else:   # nobody entered a device collective (the mock's would have waited for the broken rank for ever); sums go over the store
         assert out == [(False, 'host-staged-tcp', [6, 30])] * n
+
+
+@pytest.mark.parametrize('n,nx,halo', [(2, 64, 8), (2, 64, 24), (3, 96, 8), (4, 40, 3), (8, 512, 16), (8, 64, 2), (5, 100, 16)])
+def test_halo_plan_pairs_sends_with_receives_in_order(n, nx, halo):
+    """ncclSend / ncclRecv between two ranks are matched in posting order: what rank r sends to p must be, run by run and
+    in the same order, what p expects from r (two slabs exchange BOTH halos with the same peer)."""
+    ranges = slab.slab_ranges(nx, n)
+    plans = [slab.halo_plan(ranges, r, halo, nx) for r in range(n)]
+    for r in range(n):
+        sends, recvs = plans[r]
+        assert all(p != r for p, _, _ in sends + recvs)
+        for p in range(n):
+            if p != r:
+                assert [(a, b) for q, a, b in sends if q == p] == [(a, b) for q, a, b in plans[p][1] if q == r]
+        got = sorted(x for _, a, b in recvs for x in range(a, b))
+        a0, b0 = ranges[r]
+        want = sorted(set((a0 - halo + k) % nx for k in range(halo)) | set((b0 + k) % nx for k in range(halo))) \
+            if (b0 - a0) + 2 * halo < nx else [x for x in range(nx) if not a0 <= x < b0]
+        assert got == [x for x in want if not a0 <= x < b0]
