@@ -159,7 +159,10 @@ def test_ongrid_plus_refine_all_slabs_equal_oracle(n, name, halo):
                                              (2, 'r40_noise04', 'ng_changed_inf', 6), (3, 'r48_sig5', 'ng_all_inf', 8),
                                              (2, 'r48_sig5_noise', 'ng_changed_2', 8), (2, 'r40_vac_noise', 'ng_changed_2', 8),
                                              (2, 'r32_quant8', 'ng_all_inf', 8), (4, 'r32_quant8', 'ng_changed_inf', 4),
-                                             (3, 'r48_sig5_noise', 'ng_all_inf', 6)])
+                                             (3, 'r48_sig5_noise', 'ng_all_inf', 6),
+                                             # narrow halos: nearly every retrace that moves travels as a walker, for several hops
+                                             (4, 'r32_quant8', 'ng_all_inf', 2), (8, 'r32_quant8', 'ng_changed_inf', 3),
+                                             (6, 'r48_sig5_noise', 'ng_changed_inf', 3)])
 def test_rough_densities_slabs_equal_the_pipeline(n, name, tag, halo):
     """Noisy / rounded / plateau densities: with tie voxels (5-digit rounding) the refinement really relabels voxels
     after a neargrid assignment; without them it must change nothing, region stop or not.
