@@ -354,10 +354,19 @@ int xb_set_halo(xb_ctx *c, int64_t halo) {
 // volumes_init without vacuum owes `labels := 0` (xb_vacuum_assign defers the 4 B/voxel memset because the
 // neargrid / ongrid assignment that normally follows overwrites every label without reading any); every other
 // entry point pays the debt first, so the deferral is not observable.
+static int zero_slab_labels(xb_ctx *c) {   // the owned + halo planes of a slab (the others are known to be zero)
+    const Grid &g = c->g;
+    const int len = (g.x1 - g.x0) + 2 * c->halo, first = ((g.x0 - c->halo) % g.nx + g.nx) % g.nx;
+    const int run1 = std::min(len, g.nx - first);
+    HIPCHK(hipMemsetAsync(c->labels + (size_t)first * g.nyz, 0, (size_t)run1 * g.nyz * sizeof(int), c->stream));
+    if (len > run1) HIPCHK(hipMemsetAsync(c->labels, 0, (size_t)(len - run1) * g.nyz * sizeof(int), c->stream));
+    return XB_OK;
+}
 static int settle_labels(xb_ctx *c) {
     if (c->labels_zero_pending) {
         c->labels_zero_pending = false;
-        HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+        if (c->g.x1 - c->g.x0 == c->g.nx) HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
+        else return zero_slab_labels(c);
     }
     return XB_OK;
 }
@@ -568,12 +577,8 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
                  c->zero_outside[2] != c->halo) {
             HIPCHK(hipMemsetAsync(c->labels, 0, c->N * sizeof(int), c->stream));
             c->zero_outside[0] = g.x0; c->zero_outside[1] = g.x1; c->zero_outside[2] = c->halo;   // (nothing but plane uploads writes out there)
-        } else {
-            const int len = (g.x1 - g.x0) + 2 * c->halo, first = ((g.x0 - c->halo) % g.nx + g.nx) % g.nx;
-            const int run1 = std::min(len, g.nx - first);
-            HIPCHK(hipMemsetAsync(c->labels + (size_t)first * g.nyz, 0, (size_t)run1 * g.nyz * sizeof(int), c->stream));
-            if (len > run1) HIPCHK(hipMemsetAsync(c->labels, 0, (size_t)(len - run1) * g.nyz * sizeof(int), c->stream));
-        }
+        } else
+            c->labels_zero_pending = true;   // (owed for the owned + halo planes; a neargrid assignment on regions writes every owned label itself)
         c->has_vacuum = false;
         if (vac_charge) *vac_charge = 0.;
         if (vac_volume) *vac_volume = 0.;
@@ -929,9 +934,15 @@ static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int 
 }
 
 int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
-    NEED_GRID("xb_assign_trace");
+    NEED_GRID_RAW("xb_assign_trace");
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    // a deferred labels := 0 is dropped when this call writes every owned label without reading any: a neargrid assignment
+    // over trapping regions without vacuum (the halo planes are the peers' to fill before anything reads them)
+    if (c->labels_zero_pending && method == XB_METHOD_NEARGRID && !c->has_vacuum && c->table_prebuilt && c->blab &&
+        g.x0 % 8 == 0 && g.x1 % 8 == 0 && g.x1 - g.x0 < g.nx)
+        c->labels_zero_pending = false;
+    else if (int rc_ = settle_labels(c)) return rc_;
     const int *box_max = nullptr;   // region id - 1 -> its maximum (set once the regions of this call exist)
     int *max_count_dev = c->counters + 0;   // where the kernels of this call count the maxima they note
     bool fast_slab = false;                 // windowed slab on passes A/B: the persistent trace, counts on the device
@@ -1002,7 +1013,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
                         light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->fs + FS_N_OVF, c->labels,
                         c->first, c->max_list, max_count_dev, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                        maxsteps, c->rho, c->dist_dev);
+                        maxsteps, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
                 } else {
                 if (int rc = read_counter(c, 13, &nwalk)) return rc;
                 c->n_walk = nwalk;
@@ -1020,16 +1031,16 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                         k_ng_trace<2, false><<<nblk, tpb, 0, c->stream>>>(
                             light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
                             c->first, c->max_list, c->counters + 0, c->max_cap, redo, c->counters + 15, redo_cap,
-                            maxsteps, opt, c->rho, c->dist_dev);
+                            maxsteps, opt, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
                         k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
                             light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->counters + 15, c->labels,
                             c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                            maxsteps, c->rho, c->dist_dev);
+                            maxsteps, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
                     } else
                         k_ng_trace<2, false><<<nblk, tpb, 0, c->stream>>>(
                             light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
                             c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                            maxsteps, opt, c->rho, c->dist_dev);
+                            maxsteps, opt, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
                 }
             } else {
                 const long long waves = (opt & 1)
@@ -1038,7 +1049,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
                     light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], nullptr, 0, c->labels,
                     c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
-                    maxsteps, opt, c->rho, c->dist_dev);
+                    maxsteps, opt, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
             }
         }
         HIPCHK(hipGetLastError());
@@ -2291,7 +2302,7 @@ static bool slab_sparse_ok(const xb_ctx *c) {
            g.x0 % BRK == 0 && g.x1 % BRK == 0 && g.ny >= 16 && g.nz >= 16 && 7LL * (c->N / (BRK * BRK * BRK)) <= c->N;
 }
 int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
-    NEED_GRID("xb_table_build");
+    NEED_GRID_RAW("xb_table_build");   // (no label is read here: a deferred labels := 0 stays deferred)
     c->slab_sparse = false;
     if (slab_sparse_ok(c)) {
         // pass A over the OWN planes: move masks, maxima count and the single maximum of every own brick (k_brick_masks);
@@ -2333,13 +2344,13 @@ int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
     return XB_OK;
 }
 int xb_table_local_seeds(xb_ctx *c, int64_t *out, int64_t capacity) {
-    NEED_GRID("xb_table_local_seeds");
+    NEED_GRID_RAW("xb_table_local_seeds");   // (no label is read here: a deferred labels := 0 stays deferred)
     if ((int64_t)c->window_seeds.size() > capacity) return fail(XB_E_ARG, "xb_table_local_seeds: capacity too small");
     for (size_t i = 0; i < c->window_seeds.size(); i++) out[i] = c->window_seeds[i];
     return XB_OK;
 }
 int xb_brick_masks(xb_ctx *c, void **dev_ptr, int64_t *n_bricks, int64_t *own_first, int64_t *own_count) {
-    NEED_GRID("xb_brick_masks");
+    NEED_GRID_RAW("xb_brick_masks");   // (no label is read here: a deferred labels := 0 stays deferred)
     const Grid &g = c->g;
     if (g.nx % 8 || g.ny % 8 || g.nz % 8) return fail(XB_E_STATE, "xb_brick_masks: grid is not made of whole bricks");
     const int64_t nbr = c->N / 512, per_plane = (int64_t)(g.ny / 8) * (g.nz / 8);
@@ -2350,13 +2361,13 @@ int xb_brick_masks(xb_ctx *c, void **dev_ptr, int64_t *n_bricks, int64_t *own_fi
     return XB_OK;
 }
 int xb_table_ties(xb_ctx *c, int64_t *has_ties) {
-    NEED_GRID("xb_table_ties");
+    NEED_GRID_RAW("xb_table_ties");   // (no label is read here: a deferred labels := 0 stays deferred)
     if (c->table_stage < 1 || !c->grad_valid) return fail(XB_E_STATE, "xb_table_ties: call xb_table_build first");
     if (has_ties) *has_ties = c->window_ties ? 1 : 0;
     return XB_OK;
 }
 int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t any_ties) {
-    NEED_GRID("xb_table_finish");
+    NEED_GRID_RAW("xb_table_finish");   // (no label is read here: a deferred labels := 0 stays deferred)
     if (c->table_stage < 1 || !c->grad_valid) return fail(XB_E_STATE, "xb_table_finish: call xb_table_build first");
     // the records serve both tie rules (and the regions are closed for the refinement's retraces too) only when NO
     // rank's window holds a tie voxel
@@ -2450,7 +2461,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
 }
 
 int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, int64_t count) {
-    NEED_GRID("xb_brick_masks_copy");
+    NEED_GRID_RAW("xb_brick_masks_copy");   // (no label is read here: a deferred labels := 0 stays deferred)
     const int64_t nbr = c->N / 512;
     if (!host || first < 0 || count < 0 || first + count > nbr) return fail(XB_E_ARG, "xb_brick_masks_copy: bad chunk");
     // host holds 2 * count ints: the move masks of the chunk, then the single-maximum voxels (k_brick_masks)

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
                                                   int *labels, int *first,
                                                   int *max_list, int *max_count, int max_cap, int *ovf_list,
                                                   int *ovf_count, int ovf_cap, int maxsteps, int opt,
-                                                  const double *__restrict__ rho, const double *__restrict__ gc) {
+                                                  const double *__restrict__ rho, const double *__restrict__ gc, int has_vacuum) {
     // XCD-aware block order (opt bit 1): blocks are dealt round-robin over the 8 XCDs, each with
     // its own L2; give XCD k the k-th contiguous eighth of the work so that spatial neighbours --
     // whose trajectories read the same table lines -- share one L2.
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
         sy = row - (row / g.ny) * g.ny;
     }
     ng_walk_wave<K, WIN>(g, G, box_max, blab, nb1, nb2, walk != nullptr, sx, sy, sz, labels, first, max_list, max_count,
-                         max_cap, ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc);
+                         max_cap, ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc, has_vacuum != 0);
 }
 // Slabs: the start voxels the lean kernel could not finish (their trajectory leaves the table window) once more, with
 // the from-rho fallback.  The list and its length live on the device; the grid strides over it.
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace_list(GridL g, const GradRec *_
                                                        const int *__restrict__ vox, const int *n_dev, int *labels, int *first,
                                                        int *max_list, int *max_count, int max_cap, int *ovf_list,
                                                        int *ovf_count, int ovf_cap, int maxsteps,
-                                                       const double *__restrict__ rho, const double *__restrict__ gc) {
+                                                       const double *__restrict__ rho, const double *__restrict__ gc, int has_vacuum) {
     const int n = *n_dev;
     for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
         const int t = base + threadIdx.x;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace_list(GridL g, const GradRec *_
             sz = r - sy * g.nz;
         }
         ng_walk_wave<K, true>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, max_count, max_cap,
-                              ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc);
+                              ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc, has_vacuum != 0);
     }
 }
 // Persistent form (single GPU, device-side control flow, k_fused.h): a fixed grid of one-wave workgroups pulls
