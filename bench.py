@@ -350,7 +350,7 @@ def main():
 
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
     out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
-    out['config']['refine_escape_fallbacks'] = runner.n_fallbacks
+    out['config']['retrace_passes_with_walkers'] = runner.n_fallbacks   # passes in which some retrace left a slab's valid planes (0 on one GPU)
     if runner.timing is not None:   # XB_SLAB_TIMING=1: wall-clock per scheduler phase (adds a device sync around each)
         out['config']['slab_phase_ms_avg'] = {k: v / args.steps * 1e3 for k, v in runner.timing.items()}
     if rank == 0 and world == 1 and not args.no_cpu:
