@@ -117,10 +117,10 @@ def test_trapping_regions_do_not_change_the_map(size, lattice):
     ctx.close()
 
 
-def test_config4_1024_one_gpu_and_two_slabs():
+def test_config4_1024_one_gpu_two_and_four_slabs():
     """BASELINE config 4 (1024^3, axis-0 slabs) as far as one GPU carries it: the whole grid in one context (66.6 GB),
-    then two logical slabs of 512 planes on the same device (2 x 66.6 GB: eight do not fit 288 GB, every rank keeps
-    full-size arrays) -- properties of the map, and N-slab == 1-slab bit for bit (int8 labels, hashed)."""
+    then two and FOUR logical slabs on the same device (4 x 66.6 GB = 266 of the 288 GB: every rank keeps full-size
+    arrays, eight do not fit) -- properties of the map, and N-slab == 1-slab bit for bit (int8 labels, hashed)."""
     import hashlib
     from test_gpu_slabs import run_slabs
     size = 1024
@@ -145,13 +145,15 @@ def test_config4_1024_one_gpu_and_two_slabs():
     del lab
     ctx.close()
     g = {'dist_mat': dm, 'T_grad': tg}
-    pre, post, slog, mx, ch2, vo2, fb = run_slabs(2, g, None, 'neargrid', 'changed', 2, 16, None, shape=shape,
-                                                  synth_args=(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND),
-                                                  label_dtype=np.int8, keep_pre=False, margin=32)
-    assert hashlib.sha256(np.ascontiguousarray(post)).hexdigest() == sha
-    assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
-    assert np.array_equal(vo2, vo) and np.allclose(ch2, ch, rtol=1e-12)
-    assert [tuple(x) for x in slog] == [tuple(x) for x in log]
+    for n_slabs, margin in ((2, 32), (4, 64)):
+        pre, post, slog, mx, ch2, vo2, fb = run_slabs(n_slabs, g, None, 'neargrid', 'changed', 2, 16, None, shape=shape,
+                                                      synth_args=(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND),
+                                                      label_dtype=np.int8, keep_pre=False, margin=margin)
+        assert hashlib.sha256(np.ascontiguousarray(post)).hexdigest() == sha, n_slabs
+        del pre, post
+        assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
+        assert np.array_equal(vo2, vo) and np.allclose(ch2, ch, rtol=1e-12)
+        assert [tuple(x) for x in slog] == [tuple(x) for x in log]
 
 
 def test_many_atoms_keep_their_trapping_regions():
