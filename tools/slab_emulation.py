@@ -19,6 +19,7 @@ import time
 import numpy as np
 
 os.environ.setdefault('HSA_ENABLE_INTERRUPT', '0')   # N host threads wait on one card: completion signals by polling, not by interrupt
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')    # one hardware queue per logical rank's stream (the default of 4 makes streams share queues)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
