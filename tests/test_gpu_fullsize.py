@@ -95,6 +95,38 @@ def test_slabs_equal_one_gpu_256():
     assert fb <= 2, fb
 
 
+def test_768_eight_slabs_equal_one_gpu():
+    """Eight logical slabs (the slab count of BASELINE config 4) on the largest grid whose eight full-size contexts fit one
+    card: 768^3 (8 x 28 GB).  96 planes per rank, halo 16, table window +-48: the map, the maxima and the sums equal the
+    one-context run's (int8 labels, hashed)."""
+    import hashlib
+    from test_gpu_slabs import run_slabs
+    size = 768
+    shape = (size,) * 3
+    dm, tg = matrices(shape, synth.CUBIC6)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    ctx.vacuum_assign(None, 1.0)
+    n = ctx.assign('neargrid')
+    maxima = ctx.maxima()
+    log = ctx.refine('changed', 2)
+    ch, vo = ctx.charge_sum(1.0, n)
+    sha = hashlib.sha256(ctx.download_labels(np.int8)).hexdigest()
+    ctx.close()
+    assert n == 8 and vo.sum() == float(size) ** 3
+    g = {'dist_mat': dm, 'T_grad': tg}
+    pre, post, slog, mx, ch2, vo2, fb = run_slabs(8, g, None, 'neargrid', 'changed', 2, 16, None, shape=shape,
+                                                  synth_args=(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND),
+                                                  label_dtype=np.int8, keep_pre=False, margin=48)
+    assert all(run_slabs.last_windowed)
+    assert hashlib.sha256(np.ascontiguousarray(post)).hexdigest() == sha
+    assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
+    assert np.array_equal(vo2, vo) and np.allclose(ch2, ch, rtol=1e-12)
+    assert [tuple(x) for x in slog] == [tuple(x) for x in log]
+    assert fb > 0      # with a 16-plane halo some retraces travel as walkers
+
+
 @pytest.mark.parametrize('size,lattice', [(256, synth.CUBIC6), (192, synth.TRICLINIC), (512, synth.CUBIC6)])
 def test_trapping_regions_do_not_change_the_map(size, lattice):
     """The trapping-region early exit (closed cubes + brick growth) is exact by construction; check it
