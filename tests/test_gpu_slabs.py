@@ -162,7 +162,9 @@ def test_ongrid_plus_refine_all_slabs_equal_oracle(n, name, halo):
                                              (3, 'r48_sig5_noise', 'ng_all_inf', 6),
                                              # narrow halos: nearly every retrace that moves travels as a walker, for several hops
                                              (4, 'r32_quant8', 'ng_all_inf', 2), (8, 'r32_quant8', 'ng_changed_inf', 3),
-                                             (6, 'r48_sig5_noise', 'ng_changed_inf', 3)])
+                                             (6, 'r48_sig5_noise', 'ng_changed_inf', 3),
+                                             # noisy vacuum (thousands of maxima, -1 labels) with a narrow halo
+                                             (4, 'r40_vac_noise', 'ng_changed_2', 3), (5, 'r40_vac_noise', 'ng_all_inf', 2)])
 def test_rough_densities_slabs_equal_the_pipeline(n, name, tag, halo):
     """Noisy / rounded / plateau densities: with tie voxels (5-digit rounding) the refinement really relabels voxels
     after a neargrid assignment; without them it must change nothing, region stop or not.
