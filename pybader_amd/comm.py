@@ -116,6 +116,24 @@ class SocketStore:
     def barrier(self):
         self.allgather(None)
 
+    def route(self, out):
+        """point-to-point through rank 0: `out` maps a destination rank to an object; returns {source rank: object} of
+        what the others addressed to this rank (every rank calls it, possibly with an empty dict)"""
+        if self.size == 1:
+            return {}
+        if self.rank == 0:
+            boxes = [dict() for _ in range(self.size)]
+            for dst, obj in out.items():
+                boxes[dst][0] = obj
+            for src in range(1, self.size):
+                for dst, obj in pickle.loads(_recv_msg(self.peers[src])).items():
+                    boxes[dst][src] = obj
+            for dst in range(1, self.size):
+                _send_msg(self.peers[dst], pickle.dumps(boxes[dst], protocol=pickle.HIGHEST_PROTOCOL))
+            return boxes[0]
+        _send_msg(self.sock, pickle.dumps(out, protocol=pickle.HIGHEST_PROTOCOL))
+        return pickle.loads(_recv_msg(self.sock))
+
     def close(self):
         for c in self.peers[1:] if self.peers else []:
             c.close()
@@ -172,11 +190,17 @@ class HostComm:
         return np.concatenate(self.allgather(rows)) if self.size > 1 else rows
 
     def _staged(self, sends, recvs, fetch, store_back):
-        """planes through the store: every rank publishes what it sends, picks what is addressed to it"""
-        out = {(peer, xa, xb): fetch(xa, xb) for peer, xa, xb in sends}
-        everything = self.allgather(out)
+        """planes through the store: every rank hands rank 0 what it sends, addressed; rank 0 forwards each rank its share"""
+        out = {}
+        for peer, xa, xb in sends:
+            out.setdefault(peer, {})[(xa, xb)] = fetch(xa, xb)
+        if hasattr(self.store, 'route'):
+            inbox = self.store.route(out)
+        else:       # (a store without routing: everybody gets everything)
+            everything = self.allgather(out)
+            inbox = {src: everything[src].get(self.rank, {}) for src in range(self.size)}
         for peer, xa, xb in recvs:
-            store_back(xa, xb, everything[peer][(self.rank, xa, xb)])
+            store_back(xa, xb, inbox[peer][(xa, xb)])
 
     def exchange_planes(self, backend, which, sends, recvs):
         arr = backend.planes(which)

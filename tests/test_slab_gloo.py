@@ -310,3 +310,37 @@ def test_halo_plan_pairs_sends_with_receives_in_order(n, nx, halo):
         want = sorted(set((a0 - halo + k) % nx for k in range(halo)) | set((b0 + k) % nx for k in range(halo))) \
             if (b0 - a0) + 2 * halo < nx else [x for x in range(nx) if not a0 <= x < b0]
         assert got == [x for x in want if not a0 <= x < b0]
+
+
+def test_socket_store_route_delivers_point_to_point():
+    """SocketStore.route (the host-staged plane exchange): every rank addresses objects to some ranks, rank 0 forwards; each
+    rank gets exactly what was addressed to it, keyed by source."""
+    import threading
+    import uuid
+    from pybader_amd import comm as pcomm
+
+    n = 4
+    key = 'route_' + uuid.uuid4().hex
+    got, errors = [None] * n, []
+
+    def work(rank):
+        try:
+            store = pcomm.SocketStore(rank, n, key=key, timeout=60.0)
+            out = {dst: np.full(3, 10 * rank + dst) for dst in range(n) if dst != rank and (rank + dst) % 2 == 1}
+            got[rank] = store.route(out)
+            assert store.route({}) == {}
+            store.barrier()
+            store.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for r in range(n):
+        want = {src: 10 * src + r for src in range(n) if src != r and (src + r) % 2 == 1}
+        assert sorted(got[r]) == sorted(want)
+        assert all(np.array_equal(got[r][src], np.full(3, v)) for src, v in want.items())
