@@ -352,9 +352,11 @@ class SlabRunner:
             self.comm.exchange_planes(self.be, 1, self.sends, self.recvs)     # the flags the retraces rewrote
         with _Phase(self, 'edge_check'):
             idx, cls = self.be.edge_check_local()
-            parts = self.comm.allgather((idx, cls))
-            gidx = np.concatenate([p[0] for p in parts])
-            gcls = np.concatenate([p[1] for p in parts])
+            # (one int64 per changed voxel: index | class << 32 -- through the device transport when there is one)
+            packed = np.asarray(idx, np.int64) | (np.asarray(cls, np.int64) << 32)
+            allp = self._gather_rows(packed.reshape(-1, 1)).reshape(-1)
+            gidx = allp & 0xffffffff
+            gcls = (allp >> 32).astype(np.int8)
             _, edges = self.be.edge_check_global(gidx, gcls)
         with _Phase(self, 'sums'):
             edges, = self.comm.sum(edges)
