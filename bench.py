@@ -264,6 +264,14 @@ def main():
     dt = comm.max_float(time.perf_counter() - t0)       # max over ranks
 
     nvox = float(np.prod(shape))
+    # outside the timed region: every voxel carries exactly one basin of the merged numbering, over all ranks together (a wrong
+    # multi-rank map must be loud, not fast)
+    _, vols = ctx.charge_sum(1.0, n_basins)
+    vols = [int(v) for v in vols]
+    if world > 1:
+        vols = comm.sum(*vols)
+    if sum(vols) != int(nvox) or (vols and min(vols) <= 0):
+        raise SystemExit(f'map check failed: basin volumes {vols[:16]}... sum {sum(vols)} of {int(nvox)} voxels')
     ms_per_step = dt / args.steps * 1e3
     # HIP-event timings on the library's own stream (xb_kernel_time)
     tm = {name: ctx.kernel_time(i) for i, name in enumerate(
@@ -348,6 +356,7 @@ def main():
     if world == 1 and args.method == 'neargrid' and not args.no_dropin:
         out['dropin_many_atoms'] = dropin_leg(ctx)
 
+    out['config']['map_check'] = {'voxels_labelled': int(sum(vols)), 'smallest_basin': int(min(vols)) if vols else 0, 'largest_basin': int(max(vols)) if vols else 0}
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
     out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
     out['config']['retrace_passes_with_walkers'] = runner.n_fallbacks   # passes in which some retrace left a slab's valid planes (0 on one GPU)
