@@ -104,6 +104,9 @@ struct xb_ctx {
     bool grad_valid = false;
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
+    int opt_trace_group = 8;   // persistent trace: waves per workgroup (the eighths of a brick on one compute unit, k_ng_trace_g)
+    int opt_lean = 1;          // persistent trace: the lean walker (k_trace.h, ng_walk_lean); 0: ng_walk_wave (tests compare)
+    int opt_mirror = 1;        // pass A: mirror prefilter of the ongrid face test (k_masks.h, bm_mirror)
     int opt_sparse = 1;        // single-GPU neargrid assignment: brick masks for every voxel + records for the walk-list bricks only
     int grad_rule = 0;         // which tie rule the resident table obeys: 0 refinement.py:111, 1 methods.py:324, 2 both
                                // (the density has no voxel where they differ)
@@ -184,6 +187,32 @@ static bool sym_grid(const Grid &g, GridS &s) {
         s.dsym[idx] = a;
     }
     return true;
+}
+
+// Mirror prefilter of pass A (k_masks.h, bm_mirror): which axes of dist_mat are mirror symmetric (bit j: d(+1 on axis j) ==
+// d(-1 on axis j) for all nine pairs -- that lattice vector is orthogonal to the other two) and the margin scale
+// 2^-48 (1 + 1/d_min).  dist_mat is indexed 0, +1, -1 (index 2 == -1).
+static void mirror_prefilter(const Grid &g, int &mirror, double &mu_scale) {
+    mirror = 0;
+    double dmin = 0.;
+    bool first = true;
+    for (int i = 0; i < 27; i++)
+        if (i != 0) { dmin = first ? g.dist[i] : std::min(dmin, g.dist[i]); first = false; }
+    if (!(dmin > 0.) || !std::isfinite(dmin)) { mu_scale = 0.; return; }
+    for (int ax = 0; ax < 3; ax++) {
+        bool ok = true;
+        for (int u = 0; u < 3 && ok; u++)
+            for (int v = 0; v < 3 && ok; v++) {
+                int ip[3], im[3];
+                ip[ax] = 1; im[ax] = 2;
+                ip[(ax + 1) % 3] = im[(ax + 1) % 3] = u;
+                ip[(ax + 2) % 3] = im[(ax + 2) % 3] = v;
+                const double a = g.dist[ip[0] * 9 + ip[1] * 3 + ip[2]], b = g.dist[im[0] * 9 + im[1] * 3 + im[2]];
+                ok = std::memcmp(&a, &b, sizeof a) == 0;
+            }
+        if (ok) mirror |= 1 << ax;
+    }
+    mu_scale = std::ldexp(1. + 1. / dmin, -48);
 }
 
 struct ScopedTimer {
@@ -1006,7 +1035,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     ScopedTimer tw(c, 6);
                     int *redo = (int *)c->stage;
                     const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
-                    k_ng_trace_p<2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                    k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
                                                                                   c->fs, c->labels, c->first, c->max_list, c->max_cap, redo,
                                                                                   redo_cap, maxsteps, c->has_vacuum ? 1 : 0,
                                                                                   c->opt_trace_chunk, c->opt_trace_xcd);
@@ -1280,8 +1309,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             const bool sym = sym_grid(g, gs);
             if (sparse) {
                 // the assignment's tie rule (methods.py:324) is the template argument
-                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0);
-                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0);
+                int mirror = 0;
+                double mu_scale = 0.;
+                if (sym && c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
+                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror);
+                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0);
             } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);
@@ -1347,9 +1379,24 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         {
             ScopedTimer t6(c, 6);
             const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
-            k_ng_trace_p<2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels,
-                                                                          c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap,
-                                                                          maxsteps, c->has_vacuum ? 1 : 0, c->opt_trace_chunk, c->opt_trace_xcd);
+            // the lean walker needs 24-bit index products and nothing else the fused path does not already guarantee (whole-grid
+            // table window, brick-label regions); 32-bit table offsets up to 2^27 voxels
+            const int lean = (gl.use24 && c->opt_lean) ? (c->N <= (1LL << 27) ? 2 : 1) : 0;
+            const int gw = c->opt_trace_group;   // waves per workgroup (1: one-wave workgroups, every wave pulls for itself)
+#define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
+                      maxsteps, c->has_vacuum ? 1 : 0
+            if (gw > 1) {
+                const int groups = std::max(1, c->opt_trace_grid / gw), ch = std::max(8, c->opt_trace_chunk);
+                if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                else if (lean == 1) k_ng_trace_g<2, 1><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                else k_ng_trace_g<2, 0><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+            } else if (lean == 2)
+                k_ng_trace_p<2, 2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+            else if (lean == 1)
+                k_ng_trace_p<2, 1><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+            else
+                k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+#undef XB_TRACE_ARGS
         }
         HIPCHK(hipGetLastError());
     }
@@ -2319,8 +2366,11 @@ int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
             const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
             dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.x1 - g.x0) / GT_X);
             GridS gs;
-            if (sym_grid(g, gs)) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0);
-            else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0);
+            int mirror = 0;
+            double mu_scale = 0.;
+            if (c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
+            if (sym_grid(g, gs)) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, mu_scale, mirror);
+            else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, 0., 0);
         }
         HIPCHK(hipGetLastError());
         int ties = 0;
@@ -2492,6 +2542,9 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 10) c->opt_trace_xcd = value != 0;
     else if (key == 11) c->opt_morton = value != 0;
     else if (key == 12) c->opt_sparse = value != 0;   // 0: the round-1 route (a 32-byte record for every voxel)
+    else if (key == 14) c->opt_lean = value != 0;
+    else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
+    else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
 }
@@ -2512,6 +2565,17 @@ int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels) {
     if (box_voxels) *box_voxels = c->box_voxels;
     return XB_OK;
 }
+#ifdef XB_DEBUG_COUNT
+int xb_debug_counts(unsigned long long *out, int reset) {
+    hipDeviceSynchronize();
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(xb_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return XB_E_HIP;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(xb_dbg), z, sizeof z) != hipSuccess) return XB_E_HIP;
+    }
+    return XB_OK;
+}
+#endif
 int xb_enable_timing(xb_ctx *c, int on) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     c->timing = on != 0;

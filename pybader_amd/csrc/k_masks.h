@@ -25,6 +25,9 @@
 // and mirrored for negative d.  The thresholds below are 2e-12: a superset of the exact intervals in the two slivers
 // of width 1e-12, equal everywhere else (soundness only needs a superset).
 #define BM_EPS 2e-12
+#ifdef XB_DEBUG_COUNT
+__device__ unsigned long long xb_dbg[16];
+#endif
 
 // thread -> (y, z) column of the 8 x 32 tile face.  The columns on a y- or z-face of their brick (28 of 64 per brick)
 // come first, sorted by side: wave 0 holds the low-side columns (y == 0 or z == 0) and the four mixed corners per
@@ -66,6 +69,45 @@ __device__ __forceinline__ double max_raw(double a, double b) {
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ double min_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// Mirror prefilter of the ongrid face test.  The ongrid pick (methods.py:87-117) maximises w_n = fl(fl((rho_n - c) d_n) + c)
+// over the 26 neighbours, strict '>'.  When the distance matrix is mirror symmetric along an axis (d(-1,j,k) == d(+1,j,k):
+// that lattice vector is orthogonal to the other two) every neighbour n0 of the low plane has a mirror image n2 in the
+// high plane with the same weight, and fl(.) is monotone: if rho(n2) - rho(n0) > mu for all nine pairs, with
+//     mu = 2^-48 (1 + 1/d_min) max|rho| over the tile  >  2^-52 B (6 + 1/d)   (three roundings per w, |rho_n - c| <= 2B),
+// then w(n2) > w(n0) STRICTLY for every pair, the largest w of the low plane is smaller than that of the high plane, and
+// the pick cannot lie in the low plane: the ongrid step of this voxel does not cross the low face.  A smooth field that
+// points away from a face satisfies this almost everywhere (rho(+1,j,k) - rho(-1,j,k) = 2 g_x to first order for every
+// j,k), so the 115-instruction plane-maximum test below only runs for the waves that hold a voxel where it does not.
+// D: +1 tests the low plane against the high one, -1 the high plane against the low one.
+template <int AX>
+__device__ __forceinline__ double bm_pair(const double (&a)[3][3][3], int u, int v) {
+    return AX == 0 ? a[2][u][v] - a[0][u][v] : (AX == 1 ? a[u][2][v] - a[u][0][v] : a[u][v][2] - a[u][v][0]);
+}
+template <int AX>
+__device__ __forceinline__ void bm_mirror(const double (&a)[3][3][3], bool want_lo, bool want_hi, double mu, bool &nlo, bool &nhi) {
+    double e[9];
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int v = 0; v < 3; v++) e[u * 3 + v] = bm_pair<AX>(a, u, v);
+    if (want_lo) {   // wave uniform
+        double m = min_raw(e[0], e[1]);
+#pragma unroll
+        for (int k = 2; k < 9; k++) m = min_raw(m, e[k]);
+        nlo = nlo && !(m > mu);
+    }
+    if (want_hi) {
+        double m = max_raw(e[0], e[1]);
+#pragma unroll
+        for (int k = 2; k < 9; k++) m = max_raw(m, e[k]);
+        nhi = nhi && !(m < -mu);
+    }
+}
 // One tie rule's contribution to the face-crossing booleans of a voxel at (k, ty, zz) of its brick.  MT: methods.py:324
 // (1) or refinement.py:111 (0), compile time -- with the rule in a register both variants were evaluated and blended.
 template <int MT, int K, typename GT>
@@ -97,7 +139,7 @@ __device__ __forceinline__ void bm_cross(const GT &g, double c, double hx, doubl
 // one x-position K of the column: everything below the window update
 template <int MT, int K, typename GT>
 __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3], double dface, bool in, int v, int ty, int zz,
-                                         int &mine, bool &any_tie, int *s_cnt, int *s_mv) {
+                                         int &mine, bool &any_tie, int *s_cnt, int *s_mv, double mu, int mirror) {
     const double c = a[1][1][1];
     const double hx = a[2][1][1], lx = a[0][1][1], hy = a[1][2][1], ly = a[1][0][1], hz = a[1][1][2], lz = a[1][1][0];
     const bool tie = axis_tie(hx, c, lx) || axis_tie(hy, c, ly) || axis_tie(hz, c, lz);
@@ -119,9 +161,36 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
     double wq = (r6 - c) * dface;
     wq += c;
     const bool not_max = wq > c;
-    const bool need = (K == 0 && !xl) || (K == GT_X - 1 && !xh) || (ty == 0 && !yl) || (ty == 7 && !yh) ||
-                      (zz == 0 && !zl) || (zz == 7 && !zh) || !not_max;
+    // the faces whose crossing is still open, minus those the mirror prefilter closes (wave-uniform branches)
+    bool nxl = in && K == 0 && !xl, nxh = in && K == GT_X - 1 && !xh;
+    bool nyl = in && ty == 0 && !yl, nyh = in && ty == 7 && !yh, nzl = in && zz == 0 && !zl, nzh = in && zz == 7 && !zh;
+    if ((K == 0 || K == GT_X - 1) && (mirror & 1)) {
+        const bool wl = K == 0 && __any(nxl), wh = K == GT_X - 1 && __any(nxh);
+        if (wl || wh) bm_mirror<0>(a, wl, wh, mu, nxl, nxh);
+    }
+    if (mirror & 2) {
+        const bool wl = __any(nyl), wh = __any(nyh);
+        if (wl || wh) bm_mirror<1>(a, wl, wh, mu, nyl, nyh);
+    }
+    if (mirror & 4) {
+        const bool wl = __any(nzl), wh = __any(nzh);
+        if (wl || wh) bm_mirror<2>(a, wl, wh, mu, nzl, nzh);
+    }
+    const bool need = nxl || nxh || nyl || nyh || nzl || nzh || !not_max;
     bool is_max = false;
+#ifdef XB_DEBUG_COUNT   // diagnostic build only (tools/debug_counts.py): why does a wave-iteration run the exact test?
+    {
+        const bool ax = __any(nxl || nxh), ay = __any(nyl || nyh), az = __any(nzl || nzh), am = __any(in && !not_max), an = __any(need && in);
+        if (threadIdx.x % XB_WAVE == 0) {
+            atomicAdd(&xb_dbg[0], 1ull);
+            if (ax) atomicAdd(&xb_dbg[1], 1ull);
+            if (ay) atomicAdd(&xb_dbg[2], 1ull);
+            if (az) atomicAdd(&xb_dbg[3], 1ull);
+            if (am) atomicAdd(&xb_dbg[4], 1ull);
+            if (an) atomicAdd(&xb_dbg[5], 1ull);
+        }
+    }
+#endif
     if (__any(need && in)) {
         // methods.py:87-117 picks the FIRST neighbour (ix,iy,iz ascending) whose weighted value w = fl(fl((rho_n - c) d_n) + c)
         // is the largest and > c.  Only two things are needed of it here: whether any w exceeds c (else the voxel is a
@@ -184,12 +253,15 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
 
 template <typename GT, int MT>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
-                                                     int *__restrict__ bmaxv, int *tie_count, int xbase) {
+                                                     int *__restrict__ bmaxv, int *tie_count, int xbase, double mu_scale, int mirror) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][BM_ROW];
     __shared__ int s_mask[GT_Z / 8], s_cnt[GT_Z / 8], s_mv[GT_Z / 8];
+    __shared__ unsigned s_bmax;   // the largest |rho| of the haloed tile, as the high word of its double (mirror prefilter)
     // (xbase: the first plane; a slab runs the pass over its own planes only, brick aligned)
     const int x0 = xbase + blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
     if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; }
+    if (threadIdx.x == 0) s_bmax = 0;
+    __syncthreads();
     {   // row-wise staging, every load of a wave in flight before the first wait (see k_grad_field)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
         int Z = z0 + lane - 1;
@@ -215,8 +287,18 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
             const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
             if (lane < GT_Z + 2) tile[ex][ey][lane] = val[k];
         }
+        if (mirror) {
+            unsigned hi = 0;
+#pragma unroll
+            for (int k = 0; k < ROWS; k++) hi = max(hi, (unsigned)__double2hiint(val[k]) & 0x7fffffffu);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) hi = max(hi, (unsigned)__shfl_xor((int)hi, o));
+            if (lane == 0) atomicMax(&s_bmax, hi);
+        }
     }
     __syncthreads();
+    // mu: see bm_mirror; the double whose high word is s_bmax + 1 bounds every |rho| of the tile from above
+    const double mu = mirror ? __hiloint2double((int)min(s_bmax + 1u, 0x7ff00000u), 0) * mu_scale : 0.;
     int ty, tz;
     bm_column(threadIdx.x, ty, tz);
     const int zz = tz & 7;
@@ -245,7 +327,7 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
         }                                                                                                            \
         const int x = x0 + K;                                                                                        \
         bm_voxel<MT, K>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie,           \
-                        &s_cnt[tz >> 3], &s_mv[tz >> 3]);                                                            \
+                        &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror);                                                \
     }
     BM_STEP(0) BM_STEP(1) BM_STEP(2) BM_STEP(3) BM_STEP(4) BM_STEP(5) BM_STEP(6) BM_STEP(7)
 #undef BM_STEP

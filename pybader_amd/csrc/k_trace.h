@@ -289,6 +289,109 @@ __device__ __forceinline__ void ng_walk_wave(const GridL &g, const GradRec *__re
         if (k < ovf_cap) ovf_list[k] = v;
     }
 }
+// ---------------------------------------------------------------------------------------------
+// The lean walker of the single-GPU persistent trace.  Same trajectory, same exits and the same results as
+// ng_walk_wave<2, false> -- tests/test_gpu_parity.py runs both -- for the case that kernel is launched in: the table
+// window is the whole grid, trapping regions are brick labels (no box ids in the keys), nx * ny and nz below 2^24.
+// What differs is the instruction stream of a step (round 2: ~100 VALU + 48 SALU per wave-step, 87 % of the kernel's
+// time in VALU issue):
+//   * the gradient move is computed for every moving lane, straight-line; the rare ongrid step (a voxel without a
+//     gradient step, or the move lands on the last two path voxels: methods.py:411) sits behind ONE wave-uniform
+//     branch and un-does the move from the move's own offsets instead of keeping the old coordinates alive;
+//   * the coordinates are updated in place, the new record is loaded into the registers of the old one (no copies
+//     at the back-edge), linear and brick indices by 24-bit multiply-adds (the generic form compiles to the
+//     quarter-rate v_mad_u64_u32), the periodic wrap is one v_min3_u32 of (q, q + n, q - n);
+//   * no window / table-cover tests.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap3(int q, int n) {   // q in [-n, 2n) -> [0, n)
+    return (int)min(min((unsigned)q, (unsigned)(q + n)), (unsigned)(q - n));
+}
+__device__ __forceinline__ int mad24(int a, int b, int c) {   // a * b + c, a and b below 2^24 (one full-rate instruction)
+    int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int lin24(const GridL &g, int x, int y, int z) { return mad24(mad24(x, g.ny, y), g.nz, z); }
+// OFF32: every byte offset into the table (32 B per voxel) fits 32 bits (N <= 2^27): scalar base + 32-bit lane offset
+template <bool OFF32>
+__device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, int l) {
+    if (OFF32) return *reinterpret_cast<const GradRec *>(reinterpret_cast<const char *>(G) + ((unsigned)l << 5));
+    return fetch_rec(G, l);
+}
+template <bool OFF32>
+__device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+                                             const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
+                                             int *labels, int *first, int *max_list, int *max_count, int max_cap,
+                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum) {
+    // every start voxel is valid: the walk list holds whole bricks of a grid made of whole bricks
+    const int v = lin24(g, sx, sy, sz);
+    const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
+    GradRec rec = fetch_rec_o<OFF32>(G, v);
+    bool moving = lab0 != -1;
+    int result = -1;
+    int px = sx, py = sy, pz = sz, steps = 0;
+    double dr0 = 0., dr1 = 0., dr2 = 0.;
+    // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key
+    int i0 = v, i1 = -1;
+    double k0 = rec.key, k1 = -1.7976931348623157e308, m_old = -1.7976931348623157e308;
+    while (__builtin_amdgcn_ballot_w64(moving) != 0) {
+        if (moving) {
+            const int bits = key_bits(rec.key);
+            // methods.py:345-363: dr += r; corr = rha(dr); q = p + int_grad + corr; dr -= corr (a voxel without a gradient
+            // step has code 63 and r = 0: the move below is garbage for it and replaced by the ongrid step)
+            const double t0 = dr0 + rec.r0, t1 = dr1 + rec.r1, t2 = dr2 + rec.r2;
+            const int id0 = rha_cs(t0), id1 = rha_cs(t1), id2 = rha_cs(t2);
+            const int m0 = (bits & 3) + id0 - 1, m1 = ((bits >> 2) & 3) + id1 - 1, m2 = ((bits >> 4) & 3) + id2 - 1;
+            px += m0; py += m1; pz += m2;
+            dr0 = t0 - (double)id0; dr1 = t1 - (double)id1; dr2 = t2 - (double)id2;
+            // the periodic wrap only for the waves that touch the faces of the grid
+            if (__builtin_amdgcn_ballot_w64((unsigned)px >= (unsigned)g.nx || (unsigned)py >= (unsigned)g.ny || (unsigned)pz >= (unsigned)g.nz) != 0) {
+                px = wrap3(px, g.nx); py = wrap3(py, g.ny); pz = wrap3(pz, g.nz);
+            }
+            int lq = lin24(g, px, py, pz);
+            const bool og_move = (bits & 63) == XB_STAY_CODE || lq == i0 || lq == i1;   // methods.py:411: already on this path
+            bool at_max = false;
+            if (__builtin_amdgcn_ballot_w64(og_move) != 0) {   // rare: dr = 0 and one ongrid step from p (methods.py:412-447, tabulated)
+                if (og_move) {
+                    const int og = (bits >> 6) & 31;
+                    int ox, oy, oz;
+                    og_offsets(og, ox, oy, oz);
+                    at_max = og == XB_OG_SELF;   // break_flag: p is the maximum
+                    dr0 = dr1 = dr2 = 0.;
+                    px = wrap3(wrap3(px - m0, g.nx) + ox, g.nx);
+                    py = wrap3(wrap3(py - m1, g.ny) + oy, g.ny);
+                    pz = wrap3(wrap3(pz - m2, g.nz) + oz, g.nz);
+                    lq = lin24(g, px, py, pz);   // (== i0 at a maximum)
+                }
+            }
+            // both loads in flight together; a lane at its maximum reloads its own record (harmless)
+            rec = fetch_rec_o<OFF32>(G, lq);
+            const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
+            const int bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
+            steps++;
+            // arrived inside a trapping region (q cannot be an old path voxel: the trajectory would have stopped there
+            // already); membership undecidable from the window: exact slow kernel (ongrid moves are appended without a
+            // membership test, methods.py:513-521)
+            const bool arrived = bl > 0 && !at_max;
+            const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps;
+            if (arrived) result = box_max[bl - 1];
+            else if (at_max) result = i0;
+            else if (undecided) result = -2;
+            moving = !(arrived || at_max || undecided);
+            m_old = max_raw(m_old, k1);
+            i1 = i0; k1 = k0;
+            i0 = lq; k0 = rec.key;
+        }
+    }
+    // a maximum that is itself vacuum hands its -1 to the start voxel (methods.py:449-452)
+    if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
+    labels[v] = result;
+    note_maximum_wave(result >= 0, result, v, first, max_list, max_count, max_cap);
+    if (result == -2) {
+        const int k = atomicAdd(ovf_count, 1);
+        if (k < ovf_cap) ovf_list[k] = v;
+    }
+}
 // lane -> voxel of the 4x4x4 eighth `sub` of brick b (z fastest: 4 lanes per 128-B table line)
 __device__ __forceinline__ void brick_sub_voxel(int b, int sub, int lane, int nb1, int nb2, int &sx, int &sy, int &sz) {
     const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
@@ -369,7 +472,7 @@ __device__ __forceinline__ int xcc_id() {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     return x & 7;
 }
-template <int K>
+template <int K, int LEAN>   // LEAN: 0 ng_walk_wave, 1 ng_walk_lean, 2 ng_walk_lean with 32-bit table offsets
 __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                         const int *__restrict__ blab, int nb1, int nb2,
                                                         const int *__restrict__ walk, int *fs, int *labels, int *first,
@@ -392,8 +495,60 @@ __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *
             for (int item = base; item < stop; item++) {
                 int sx, sy, sz;
                 brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
-                ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
-                                       max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
+                if (LEAN)
+                    ng_walk_lean<LEAN == 2>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX], max_cap, ovf_list,
+                                 &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
+                else
+                    ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                                           max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
+            }
+        }
+    }
+}
+
+// Group form of the persistent trace: a workgroup of W waves pulls CH consecutive items (CH / 8 whole bricks of the Morton
+// ordered walk list) and its waves take them one by one from a counter in LDS, so that the eight 4x4x4 eighths of a brick --
+// whose walkers converge onto the same voxels within a few steps -- run on ONE compute unit at the same time: their record
+// loads meet in that unit's L1 (hit, or merged with the miss in flight) instead of each occupying a miss slot of a
+// different unit.  The trace is bound by exactly that: L2 requests x L2 latency / misses in flight per compute unit
+// (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
+template <int K, int LEAN>
+__global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+                                                       const int *__restrict__ blab, int nb1, int nb2,
+                                                       const int *__restrict__ walk, int *fs, int *labels, int *first,
+                                                       int *max_list, int max_cap, int *ovf_list, int ovf_cap, int maxsteps,
+                                                       int has_vacuum, int CH, int xcd_split) {
+    __shared__ int s_base, s_next;
+    const int n_items = fs[FS_N_WALK] * 8;
+    const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
+    const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
+    const int lane = threadIdx.x & (XB_WAVE - 1);
+    for (int r = 0; r < 8; r++) {
+        const int q = (home + r) & 7;
+        const int beg = q * per, end = min(beg + per, n_items);
+        for (;;) {
+            __syncthreads();   // the previous chunk's readers are done with s_base / s_next
+            if (threadIdx.x == 0) {
+                s_base = beg + atomicAdd(&fs[FS_CURSOR0 + q * FS_CURSOR_STRIDE], CH);
+                s_next = 0;
+            }
+            __syncthreads();
+            const int base = s_base;
+            if (base >= end) break;   // uniform over the workgroup
+            const int stop = min(base + CH, end);
+            for (;;) {
+                int i = 0;
+                if (lane == 0) i = atomicAdd(&s_next, 1);
+                const int item = base + __builtin_amdgcn_readfirstlane(i);
+                if (item >= stop) break;
+                int sx, sy, sz;
+                brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
+                if (LEAN)
+                    ng_walk_lean<LEAN == 2>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX], max_cap, ovf_list,
+                                            &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
+                else
+                    ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                                           max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
             }
         }
     }

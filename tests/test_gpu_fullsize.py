@@ -274,3 +274,43 @@ def test_noisy_vacuum_keeps_the_atoms_regions():
     assert np.array_equal(m0, m1) and np.array_equal(l0, l1)
     assert s1[0] > 1023 and s1[1] > 0.25 * 256 ** 3, s1     # regions survive (round 1: none beyond 64 maxima)
     ctx.close()
+
+
+HEXAGONAL = np.array([[5.2, 0.0, 0.0], [-2.6, 4.503332099679081, 0.0], [0.0, 0.0, 6.4]])   # only the third axis is a mirror axis
+ORTHO = np.array([[5.0, 0.0, 0.0], [0.0, 6.5, 0.0], [0.0, 0.0, 7.25]])
+
+
+@pytest.mark.parametrize('shape,lattice,noise', [((256, 256, 256), synth.CUBIC6, 0.0), ((128, 160, 192), ORTHO, 0.0),
+                                                 ((160, 160, 128), HEXAGONAL, 0.0), ((128, 128, 128), synth.TRICLINIC, 0.0),
+                                                 ((128, 128, 128), synth.CUBIC6, 1e-3)])
+def test_mirror_prefilter_and_lean_walker_do_not_change_the_map(shape, lattice, noise):
+    """Round 3's two instruction diets are exact by construction -- pass A's mirror prefilter (k_masks.h, bm_mirror) only
+    closes faces the exact ongrid test would close too, the lean walker (k_trace.h, ng_walk_lean) follows the same
+    trajectory -- but check them anyway: each switched off against both on, on lattices with three, one and no mirror
+    axis, smooth and with noise (thousands of maxima: ongrid steps, plateaus), map + maxima + refinement log."""
+    ctx = _lib.Context(0)
+    dm, tg = matrices(shape, lattice)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(lattice, synth.ATOMS8, synth.BACKGROUND)
+    if noise:
+        rho = ctx.download_density()
+        rho = np.ascontiguousarray(rho + noise * np.random.default_rng(3).random(shape))
+        ctx.upload_density(rho)
+    res = []
+    for mirror, lean in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        ctx.set_option(13, mirror)
+        ctx.set_option(14, lean)
+        ctx.set_option(6, 1)
+        ctx.vacuum_assign(None, 1.0)
+        n = ctx.assign('neargrid')
+        pre = ctx.download_labels(np.int32)
+        log = ctx.refine('changed', 2)
+        res.append((n, ctx.maxima(), pre, log, ctx.download_labels(np.int32), ctx.box_stats()))
+    ctx.close()
+    for r in res[1:]:
+        assert r[0] == res[0][0] and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+        assert r[3] == res[0][3] and np.array_equal(r[4], res[0][4])
+    # the prefilter decides a subset of the faces the exact test leaves closed: never fewer certified bricks with it
+    assert res[0][5][1] >= res[1][5][1] and res[2][5][1] >= res[3][5][1]
+    assert res[0][5] == res[2][5] and res[1][5] == res[3][5]          # the walker does not touch the regions
+    print('certified voxels with / without the mirror prefilter:', res[0][5][1], res[1][5][1])
