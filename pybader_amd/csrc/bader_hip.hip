@@ -104,6 +104,9 @@ struct xb_ctx {
     bool grad_valid = false;
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
+    int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
+    int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
+    long long stat_grow_retries = 0;
     int opt_trace_group = 8;   // persistent trace: waves per workgroup (the eighths of a brick on one compute unit, k_ng_trace_g)
     int opt_lean = 1;          // persistent trace: the lean walker (k_trace.h, ng_walk_lean); 0: ng_walk_wave (tests compare)
     int opt_mirror = 1;        // pass A: mirror prefilter of the ongrid face test (k_masks.h, bm_mirror)
@@ -1284,6 +1287,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         *box_max = c->boxbuf + (sparse ? BB_REGMAX : BB_BOXMAX), *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * XB_BOXES_MAX,
         *box_first = c->boxbuf + (sparse ? BB_REGFIRST : BB_EXT + 4 * XB_BOXES_MAX), *bad = c->boxbuf + BB_BAD;
     int *bmaxv = walk;   // (free until the walk list is made)
+    int *bpot = c->list + 5 * nbr;   // brick potentials of the region growth (k_grow_parent); buf1 doubles as the parent array
+    const bool chase = sparse && c->opt_chase;
     c->box_max_tab = box_max;
     const int stride = XB_BOX_K + 4;
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
@@ -1312,8 +1317,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                 int mirror = 0;
                 double mu_scale = 0.;
                 if (sym && c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
-                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror);
-                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0);
+                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
             } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);
@@ -1328,7 +1333,12 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             // seeds: the bricks that hold exactly one maximum (no cubes, no cap on the number of maxima); they are not
             // fixed: the kill iteration certifies them like every other brick
             k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
-            k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
+            if (chase) {   // provisional labels by one chase along the brick potentials instead of ~6 propagation launches
+                k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
+                k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64);
+                k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
+            } else
+                k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
         } else {
             // closed seed cubes around the maxima, then brick growth -- all decided on the device
             k_box_setup<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
@@ -1337,10 +1347,15 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             k_box_pick<<<1, XB_BOXES_MAX, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
             k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
         }
-        const int launches = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
+        // the worst-case schedule; after a chase only the kill iteration is left, which dies out within a few bricks of the
+        // dividing surfaces: a short schedule first, and a repeat of the whole assignment with the long one (FS_GROW_RETRY)
+        // for the rare density whose cascade runs deeper
+        const int long_schedule = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
+        const int launches = chase ? std::min(long_schedule, c->grow_kill_launches) : long_schedule;
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, sparse ? 0 : 1);
+        if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
         k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, sparse ? XB_REGIONS_MAX : XB_BOXES_MAX);
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr,
                                                  sparse ? 0 : 1);
@@ -1357,9 +1372,9 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             while ((1 << bits) < std::max(std::max(nb0, nb1), nb2)) bits++;
             const unsigned n_codes = 1u << (3 * bits);
             k_brick_walk_list_morton<<<(n_codes + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nb0, nb1, nb2, n_codes, c->blab, walk,
-                                                                                                  fs + FS_N_WALK);
+                                                                                                  fs + FS_N_WALK, fs + FS_GROW_RETRY);
         } else
-            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK);
+            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK, fs + FS_GROW_RETRY);
         if (sparse) {   // pass B: records for the bricks of the walk list only
             ScopedTimer t7(c, 7);
             const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
@@ -1371,7 +1386,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         }
         if (c->has_vacuum)
             k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
-                                                                fs + FS_N_MAX, c->max_cap);
+                                                                fs + FS_N_MAX, c->max_cap, fs + FS_GROW_RETRY);
         else {
             k_note_regions<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, nb1, nb2, fs, box_first, box_max, c->first, c->max_list, fs + FS_N_MAX, c->max_cap);
             c->regions_pending = true;
@@ -1421,6 +1436,12 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     HIPCHK(hipStreamSynchronize(c->stream));
     const int *h = c->host_ints;
     g.main_ties = 0;
+    if (h[FS_GROW_RETRY]) {   // the short kill schedule did not reach the fixpoint: once more, with the worst-case one from now on
+        c->grow_kill_launches = 1 << 20;
+        c->stat_grow_retries++;
+        c->grad_valid = false;
+        return assign_neargrid_fused(c, n_maxima);
+    }
     if (h[FS_TIES] == 0) c->grad_rule = 2;
     c->n_boxes = h[FS_N_BOXES];
     c->box_voxels = (long long)h[FS_N_CERTAIN] * BRK * BRK * BRK;
@@ -2369,8 +2390,8 @@ int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
             int mirror = 0;
             double mu_scale = 0.;
             if (c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
-            if (sym_grid(g, gs)) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, mu_scale, mirror);
-            else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, 0., 0);
+            if (sym_grid(g, gs)) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, mu_scale, mirror, nullptr);
+            else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, 0., 0, nullptr);
         }
         HIPCHK(hipGetLastError());
         int ties = 0;
@@ -2543,6 +2564,8 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 11) c->opt_morton = value != 0;
     else if (key == 12) c->opt_sparse = value != 0;   // 0: the round-1 route (a 32-byte record for every voxel)
     else if (key == 14) c->opt_lean = value != 0;
+    else if (key == 16) c->opt_chase = value != 0;
+    else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);

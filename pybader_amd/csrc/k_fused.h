@@ -30,6 +30,7 @@ enum {
     FS_CHANGED, FS_ESCAPED, FS_R_OVF,
     FS_R_DEFER,          // refinement: retraces handed to the from-rho kernel (their walk goes on through a brick without records)
     FS_N_TILES,          // refinement: tiles of the edge sweep that are not of one label with their surroundings
+    FS_GROW_RETRY,       // the scheduled kill launches did not reach the fixpoint: the host repeats the assignment with the long schedule
     FS_COUNT = 64,
     // 8 per-XCD work cursors of the persistent trace, one per 128-byte line: device-scope atomics on ONE line
     // serialise at ~88 per microsecond whatever the word (measured: 8 cursors in one line = one cursor)
@@ -37,6 +38,7 @@ enum {
     FS_TOTAL = FS_CURSOR0 + 8 * FS_CURSOR_STRIDE
 };
 
+#define XB_REGIONS_MAX 65535   // trapping regions seeded by bricks (k_seed_bricks)
 #define XB_BOX_K 32   // seed cubes are searched up to this radius (brick growth takes over from there)
 
 // seeds (unsorted, appended atomically by the table pass) -> sorted seeds, their coordinates and the largest
@@ -209,6 +211,54 @@ __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb
         }
     }
 }
+// Provisional labels of the region growth WITHOUT rounds (round 3; replaces phase 0 of k_brick_grow_dev on the one-GPU
+// path: ~6 dependent launches of labels crawling 8 bricks each).  Any guess is sound -- the kill iteration decides what
+// survives -- so every brick simply points at ONE brick it can move into, the one with the largest density maximum
+// (`bpot`, from pass A) provided that is larger than its own: potentials rise strictly along a chain, so chains cannot
+// cycle, and they end where no successor is higher -- in the brick that holds the basin's maximum (a seed: label = its
+// region id) or in a dead end (a brick with several maxima, or none higher around: label 0).  k_grow_chase follows the
+// chain of every brick at once; the parents are read-only, so no synchronisation is needed.
+__global__ __launch_bounds__(TPB) void k_grow_parent(int nb0, int nb1, int nb2, const int *__restrict__ bmask, const int *__restrict__ bpot,
+                                                     const int *__restrict__ seed, int *__restrict__ parent) {
+    const int b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= nb0 * nb1 * nb2) return;
+    const int m = bmask[b];
+    if (seed[b] != 0) { parent[b] = b; return; }            // exactly one maximum: the root of its region
+    if ((m >> 27) & 3) { parent[b] = -1; return; }          // several maxima (or a seed beyond the table): never certified
+    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+    int best = -1, bp = bpot[b];
+    for (unsigned mm = (unsigned)m & 0x7ffffffu; mm; mm &= mm - 1) {   // the bricks it can move into
+        const int k = __ffs(mm) - 1;
+        const int q = (wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2);
+        const int pq = bpot[q];
+        if (pq > bp) { bp = pq; best = q; }
+    }
+    parent[b] = best;
+}
+__global__ __launch_bounds__(TPB) void k_grow_chase(int nbr, const int *__restrict__ parent, const int *__restrict__ seed, int *__restrict__ lab,
+                                                    int limit) {
+    const int b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= nbr) return;
+    int p = b, l = 0;
+    for (int it = 0; it < limit; it++) {
+        const int pp = parent[p];
+        if (pp < 0) break;
+        if (pp == p) { l = seed[p]; break; }
+        p = pp;
+    }
+    lab[b] = l;
+}
+// after the seeds: straight to the kill iteration (the chase has made the provisional labels)
+__global__ void k_seed_finish_kill(int *fs) {
+    const int n = min(fs[FS_N_SEEDS], XB_REGIONS_MAX);
+    fs[FS_N_SEEDS_EFF] = n;
+    fs[FS_N_BOXES] = n;
+    fs[FS_GROW_PHASE] = n ? 1 : 2;   // nothing to grow without a seed
+    fs[FS_GROW_CONVERGED] = 0;
+    fs[FS_GROW_CUR] = 0;
+}
+// the scheduled kill launches are over: did they reach the fixpoint?  (if not, everything downstream is skipped)
+__global__ void k_grow_verdict(int *fs) { fs[FS_GROW_RETRY] = (fs[FS_GROW_PHASE] == 1 && !fs[FS_GROW_CONVERGED]) ? 1 : 0; }
 // blab := the surviving labels (a FIXPOINT of the kill iteration is closed under every move; without one fall
 // back to the seed cubes, which are trapping regions on their own); counts the certain bricks
 // box_first[id] (preset to INT_MAX): the smallest certain brick index of box id + 1 -- without vacuum every voxel of
@@ -219,6 +269,7 @@ __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restr
                                                      int *box_first, const int *__restrict__ bmask, unsigned char *brick_rec,
                                                      int seeds_fixed) {
     __shared__ int s_first[XB_BOXES_MAX];
+    if (fs[FS_GROW_RETRY]) return;
     // without a fixpoint only closed cubes are regions on their own; seed BRICKS alone certify nothing
     const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
     const int nbx = (fs[FS_GROW_CONVERGED] || seeds_fixed) ? fs[FS_N_BOXES] : 0;
@@ -244,6 +295,7 @@ __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restr
 __global__ __launch_bounds__(XB_BOXES_MAX) void k_note_regions(GridL g, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ box_first,
                                                      const int *__restrict__ box_max, int *first, int *max_list, int *max_count,
                                                      int max_cap) {
+    if (fs[FS_GROW_RETRY]) return;
     for (int t = threadIdx.x; t < fs[FS_N_BOXES]; t += blockDim.x) {
         if (box_first[t] == XB_INT_MAX) continue;
         const int b = box_first[t];
@@ -255,7 +307,6 @@ __global__ __launch_bounds__(XB_BOXES_MAX) void k_note_regions(GridL g, int nb1,
 // maximum starts with that maximum's region id.  No cap but the table size: a density with thousands of maxima (noise in
 // the vacuum of a real CHGCAR) still gets the regions of its atoms, and a brick with several maxima is simply never
 // certified.  Ids are handed out in arrival order (the basin numbering is decided later, by first voxel).
-#define XB_REGIONS_MAX 65535
 __global__ void k_seed_bricks(int nbr, const int *__restrict__ bmask, const int *__restrict__ bmaxv, int *fs, int *seed, int *buf0,
                               int *box_max) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,7 +359,7 @@ __global__ __launch_bounds__(1024) void k_number_maxima(int *fs, int *first, con
     __shared__ unsigned long long key[XB_SORT_MAX];
     const int n = fs[FS_N_MAX];
     // trajectories waiting for the exact slow kernel may still discover maxima: number on the host afterwards
-    if (n > XB_SORT_MAX || n > max_cap || fs[FS_N_OVF] > 0) { if (threadIdx.x == 0) fs[FS_SORT_OK] = 0; return; }
+    if (n > XB_SORT_MAX || n > max_cap || fs[FS_N_OVF] > 0 || fs[FS_GROW_RETRY]) { if (threadIdx.x == 0) fs[FS_SORT_OK] = 0; return; }
     int len = 64;   // sort the next power of two >= n (a handful of maxima is the common case)
     while (len < n) len <<= 1;
     for (int i = threadIdx.x; i < len; i += 1024)

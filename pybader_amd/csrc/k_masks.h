@@ -253,13 +253,14 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
 
 template <typename GT, int MT>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
-                                                     int *__restrict__ bmaxv, int *tie_count, int xbase, double mu_scale, int mirror) {
+                                                     int *__restrict__ bmaxv, int *tie_count, int xbase, double mu_scale, int mirror,
+                                                     int *__restrict__ bpot) {
     __shared__ double tile[GT_X + 2][GT_Y + 2][BM_ROW];
-    __shared__ int s_mask[GT_Z / 8], s_cnt[GT_Z / 8], s_mv[GT_Z / 8];
+    __shared__ int s_mask[GT_Z / 8], s_cnt[GT_Z / 8], s_mv[GT_Z / 8], s_pot[GT_Z / 8];
     __shared__ unsigned s_bmax;   // the largest |rho| of the haloed tile, as the high word of its double (mirror prefilter)
     // (xbase: the first plane; a slab runs the pass over its own planes only, brick aligned)
     const int x0 = xbase + blockIdx.z * GT_X, y0 = blockIdx.y * GT_Y, z0 = blockIdx.x * GT_Z;
-    if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; }
+    if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; s_pot[threadIdx.x] = -2147483647 - 1; }
     if (threadIdx.x == 0) s_bmax = 0;
     __syncthreads();
     {   // row-wise staging, every load of a wave in flight before the first wait (see k_grad_field)
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
         }
     int mine = 0;
     bool any_tie = false;
+    double cmax = -1.7976931348623157e308;   // the largest density of this column (brick potential of the region growth)
 #define BM_STEP(K)                                                                                                   \
     {                                                                                                                \
         _Pragma("unroll") for (int iy = 0; iy < 3; iy++) _Pragma("unroll") for (int iz = 0; iz < 3; iz++) {          \
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
             a[2][iy][iz] = tile[K + 2][ty + iy][tz + iz];                                                            \
         }                                                                                                            \
         const int x = x0 + K;                                                                                        \
+        cmax = max_raw(cmax, a[1][1][1]);                                                                            \
         bm_voxel<MT, K>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie,           \
                         &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror);                                                \
     }
@@ -334,9 +337,14 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     static_assert(GT_X == 8, "eight x-positions per column");
     if (__any(any_tie) && threadIdx.x % XB_WAVE == 0) atomicAdd(tie_count, 1);  // only != 0 matters
     atomicOr(&s_mask[tz >> 3], mine);
+    if (bpot && col_in) {   // float order as signed-int order (a potential only steers the growth's guess: precision is irrelevant)
+        const int fi = __float_as_int((float)cmax);
+        atomicMax(&s_pot[tz >> 3], fi >= 0 ? fi : fi ^ 0x7fffffff);
+    }
     __syncthreads();
     if (threadIdx.x < GT_Z / 8 && z0 + threadIdx.x * 8 < g.nz) {
         const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        if (bpot) bpot[((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x] = s_pot[threadIdx.x];
         // bits 0-26: the neighbour bricks a move can reach; bit 27: the brick holds a 26-neighbour maximum, bit 28: two or more
         const int b = ((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x, n = s_cnt[threadIdx.x];
         bmask[b] = (s_mask[threadIdx.x] & 0x7ffdfff) | (n >= 1 ? 1 << 27 : 0) | (n >= 2 ? 1 << 28 : 0);

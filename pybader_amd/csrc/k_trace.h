@@ -13,7 +13,8 @@
 // the maxima for the numbering.  The uncertain bricks go to the work list of k_ng_trace.
 __global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__restrict__ blab, int nb1, int nb2,
                                                       const int *__restrict__ box_max, int *labels, int *first,
-                                                      int *max_list, int *max_count, int max_cap) {
+                                                      int *max_list, int *max_count, int max_cap, const int *skip = nullptr) {
+    if (skip && *skip) return;
     const int vbeg = g.x0 * g.nyz, vend = g.x1 * g.nyz;
     const int v = vbeg + blockIdx.x * TPB + threadIdx.x;
     const bool in = v < vend;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *lab
 }
 // 16 bricks per thread, one atomic per block; the list keeps brick order inside a block's range
 __global__ __launch_bounds__(TPB) void k_brick_walk_list(int nbr, int b_lo, int b_hi, const int *__restrict__ blab,
-                                                         int *walk, int *n_walk) {
+                                                         int *walk, int *n_walk, const int *skip = nullptr) {
+    if (skip && *skip) return;
     const int base = (blockIdx.x * TPB + threadIdx.x) * 16;   // bricks [b_lo, b_hi) are the owned slab
     unsigned int hits = 0;
 #pragma unroll
@@ -177,7 +179,8 @@ __device__ __forceinline__ int compact3(unsigned x) {   // every third bit of x,
     return (int)x;
 }
 __global__ __launch_bounds__(TPB) void k_brick_walk_list_morton(int nb0, int nb1, int nb2, unsigned n_codes,
-                                                                const int *__restrict__ blab, int *walk, int *n_walk) {
+                                                                const int *__restrict__ blab, int *walk, int *n_walk, const int *skip) {
+    if (skip && *skip) return;   // (the region growth asks for a repeat: no list, nothing to trace)
     const unsigned base = (blockIdx.x * TPB + threadIdx.x) * 16u;   // 16 consecutive Morton codes per thread
     unsigned int hits = 0;
     int bidx[16];
