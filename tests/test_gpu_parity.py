@@ -2,11 +2,12 @@
 captured from the reference and (b) the CPU oracle on seeded inputs.  Integer maps bit-exact;
 charges/volumes to 1e-9 relative (north_star asks 1e-6)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
-from conftest import case_density, load_golden
+from conftest import GOLDEN, case_density, load_golden
 from pybader_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
@@ -466,3 +467,45 @@ def test_export_path_equals_the_reference(ctx, key, cname, kw, mode):
     for got, ref in zip(calls, want):
         assert got[:5] == ref[:5], (got[:3], ref[:3])
         assert got[5] == pytest.approx(ref[5], rel=1e-12)
+
+
+OUTPUT_SLOTS = ('_bader_maxima', 'bader_charge', 'bader_volume', 'bader_spin', 'bader_volumes', 'bader_atoms', 'bader_distance',
+                'atoms_charge', 'atoms_volume', 'atoms_spin', 'atoms_volumes', 'atoms_surface_distance')
+
+
+@pytest.mark.parametrize('profile', ['default', 'default_vacuum_spin', 'speed'])
+def test_pickle_attribute_contract(profile):
+    """SURVEY.md 8(b) last row: the slots the REAL pybader.interface.Bader pickles after __call__ -- recorded
+    from a reference run, name / dtype / shape / contiguity (tests/golden/pickle_contract.json, make_golden.py
+    run_contract_case) -- against what the drop-in leaves on its object for the same input and profile: every output slot
+    the reference stores must be there with exactly that dtype and shape, and no output slot the reference does not store
+    (`bader_volumes` is deleted in the speed profile, the spin sums only exist with spin_flag)."""
+    import json
+    from pybader_amd import thread_handlers
+    from pybader_amd.interface import Bader
+    thread_handlers.VERBOSE = False
+    with open(os.path.join(GOLDEN, 'pickle_contract.json')) as f:
+        contract = json.load(f)
+    rec = contract['profiles'][profile]
+    conf = {k: (tuple(v) if isinstance(v, list) else v) for k, v in rec['config'].items()}
+    g = load_golden('c40x48x56_tric')
+    assert list(g['shape']) == contract['shape']
+    rho = case_density(g)
+    spin = np.ascontiguousarray(rho[::-1] * 0.25)
+    b = Bader({'charge': rho, 'spin': spin}, g['lattice'], synth.atoms_cartesian(g['atoms'], g['lattice']), **conf)
+    b()
+    assert b._bader_maxima.shape[0] == rec['n_maxima']
+    for slot in OUTPUT_SLOTS:
+        want = rec['slots_set'].get(slot)
+        if want is None:
+            assert not hasattr(b, slot), f'{slot}: the reference does not store it in the {profile} profile'
+            continue
+        got = getattr(b, slot)
+        assert isinstance(got, np.ndarray), slot
+        assert got.dtype.str == want['dtype'] and list(got.shape) == want['shape'], (slot, got.dtype.str, got.shape, want)
+        assert got.flags.c_contiguous == want['c_contiguous'], slot
+    for name in ('_vacuum_charge', '_vacuum_volume'):     # plain Python floats in the pickle
+        want = rec['slots_set'][name]
+        got = getattr(b, name[1:])
+        assert isinstance(got, float) and want['type'] == 'float'
+        assert abs(got - want['value']) <= 1e-9 * max(1.0, abs(want['value'])), (name, got, want['value'])
