@@ -54,8 +54,13 @@ def cpu_baseline(size, method, mode, iters, lattice, atoms, background, full_siz
         t2 = time.perf_counter()
         return float(n) ** 3, t1 - t0, t2 - t1, (rho, dm, tg, main, bmax)
 
+    legs = {}
+    for n in (64, 256):        # configs 1 and 2 on the host, one core and the box's share of cores
+        for threads in (1, min(16, len(os.sched_getaffinity(0)))):
+            nv, a, r, _ = run(n, threads)
+            legs[f'{n}^3_{threads}core'] = {'value': nv / (a + r) / 1e6, 'assign_mvox_s': nv / a / 1e6, 'assign_s': a, 'refine_s': r}
     nvox, ta, tr, sample = run(size, 1)
-    out = {'value': nvox / (ta + tr) / 1e6, 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
+    out = {'value': nvox / (ta + tr) / 1e6, 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port', 'legs': legs,
            'sample': f'{size}^3 grid, same 8 atoms/cell, {method} assign + refine ({mode},{iters}), '
                      f'assign {ta:.2f}s + refine {tr:.2f}s, single thread C port of the numba path (threads=1)',
            'assign_mvox_s': nvox / ta / 1e6}
@@ -71,9 +76,22 @@ def cpu_baseline(size, method, mode, iters, lattice, atoms, background, full_siz
     return out, sample
 
 
+def source_hash():
+    """sha256 over the kernel sources (pybader_amd/csrc + include): a PMC summary names the build it was taken from"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'pybader_amd', 'csrc', '*')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profile(kernel, method):
-    """(bytes per launch, 'file sha256[:16]') of `kernel` from the newest committed PMC summary of this command, or
-    (None, None).  Lines look like `FETCH_SIZE  k_name<...>   launches=  1 KB=  1315370`."""
+    """(bytes, 'file sha256[:16]') from the newest committed PMC summary of this command: FETCH_SIZE + WRITE_SIZE of `kernel`
+    per launch, or of every kernel of ONE step (kernel None; the summary is of a one-step run) -- or (None, why) when there is
+    no summary or it was taken from other kernel sources than the ones running now (its `# sources` line; ADVICE r2: the
+    traffic must not silently describe an older build).  Lines look like `FETCH_SIZE  k_name<...>   launches=  1 KB=  1315370`."""
     import glob
     import hashlib
     import re
@@ -86,14 +104,25 @@ def traffic_from_profile(kernel, method):
         kb, launches = 0.0, 0
         with open(path) as f:
             text = f.read()
+        src = re.search(r'^# sources (\w+)', text, re.M)
+        name = f'{os.path.relpath(path, ROOT)} sha256:{hashlib.sha256(text.encode()).hexdigest()[:16]}'
+        if not src or src.group(1) != source_hash():
+            return None, f'{name} was taken from other kernel sources ({src.group(1) if src else "unrecorded"} != {source_hash()}): dropped'
         for line in text.splitlines():
             m = re.match(r'(FETCH_SIZE|WRITE_SIZE)\s+(\S+).*launches=\s*(\d+)\s+KB=\s*(\d+)', line)
-            if m and m.group(2).split('<')[0] == kernel:
+            if not m:
+                continue
+            k = m.group(2).split('<')[0]
+            if kernel is None:
+                if k not in ('k_synth_density', 'k_fill'):      # the generator and the one-off fill are not part of a step
+                    kb += float(m.group(4))
+                    launches = 1
+            elif k == kernel:
                 kb += float(m.group(4))
                 launches = max(launches, int(m.group(3)))
         if launches:
-            return kb * 1024.0 / launches, f'{os.path.relpath(path, ROOT)} sha256:{hashlib.sha256(text.encode()).hexdigest()[:16]}'
-    return None, None
+            return kb * 1024.0 / launches, name
+    return None, 'no PMC summary committed for this command'
 
 
 def dropin_leg(ctx, size=256, k=6, reps=3):
@@ -204,6 +233,19 @@ def main():
         dev_index = local_rank % max(1, _lib.load().xb_device_count())   # == local_rank on a full node
         ctx = _lib.Context(dev_index)
         comm = xcomm.RcclComm(ctx, store)
+        # A node with a GPU per rank must run on the device transport: the host-staged fallback is ~35x slower and would
+        # pass for a valid scaling number.  Fail loudly instead; fewer GPUs than ranks (the one-GPU
+        # rehearsal) may fall back.
+        n_dev = _lib.load().xb_device_count()
+        if comm.transport != 'rccl' and n_dev >= world and not os.environ.get('XB_ALLOW_STAGED'):
+            print(f'bench.py: rank {rank}: {n_dev} GPUs for {world} ranks but the device transport is not in use: '
+                  f'{comm.init_error}', file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps({'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid', 'value': None,
+                                  'n_gpus': world, 'error': 'device transport (RCCL) unavailable',
+                                  'config': {'transport': comm.transport, 'transport_error': comm.init_error}}), flush=True)
+            store.close()
+            raise SystemExit(4)
     else:
         class _Solo:
             rank, size, transport = 0, 1, 'none'
@@ -264,6 +306,16 @@ def main():
     dt = comm.max_float(time.perf_counter() - t0)       # max over ranks
 
     nvox = float(np.prod(shape))
+    # N > 1: where a slab step spends its time, from two EXTRA steps with a device sync around every scheduler phase
+    # (the timed steps above run without those syncs)
+    phase_ms = None
+    if world > 1:
+        runner.timing = {}
+        for _ in range(2):
+            step()
+        fence()
+        phase_ms = {k: v / 2 * 1e3 for k, v in runner.timing.items()}
+        runner.timing = None
     # outside the timed region: every voxel carries exactly one basin of the merged numbering, over all ranks together (a wrong
     # multi-rank map must be loud, not fast)
     _, vols = ctx.charge_sum(1.0, n_basins)
@@ -274,24 +326,31 @@ def main():
         raise SystemExit(f'map check failed: basin volumes {vols[:16]}... sum {sum(vols)} of {int(nvox)} voxels')
     ms_per_step = dt / args.steps * 1e3
     # HIP-event timings on the library's own stream (xb_kernel_time)
-    tm = {name: ctx.kernel_time(i) for i, name in enumerate(
-        ['assign_after_masks(walk_list+k_brick_records+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
-         'masks+trapping_regions', 'k_brick_masks', 'k_ng_trace_p', 'k_brick_records'])}
+    stage_names = ['assign_after_masks(walk_list+k_brick_records+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
+                   'masks+trapping_regions', 'k_brick_masks', 'k_ng_trace', 'k_brick_records']   # (6: whichever trace kernel ran)
+    tm = {name: ctx.kernel_time(i) for i, name in enumerate(stage_names)}
     avg = {k: (ms / n if n else 0.0) for k, (ms, n) in tm.items()}
-    # the dominant single kernel of the path (HIP events around that launch alone)
-    if args.method == 'neargrid':
-        dom = 'k_brick_masks' if avg['k_brick_masks'] >= avg['k_ng_trace_p'] else 'k_ng_trace_p'
-        k_avg, k_n = avg[dom], tm[dom][1]
-        own_frac = (runner.x_range[1] - runner.x_range[0]) / shape[0]
-        units = nvox * own_frac   # voxels this rank labels (its k_grad_field also covers the window margin)
-    else:
-        dom, k_avg, k_n, units = 'k_og_pointer', avg['k_og_pointer'], tm['k_og_pointer'][1], nvox
-    achieved = BYTES_ASSIGN * units / (k_avg * 1e-3) / 1e9 if k_avg > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel: read at run time from the committed summary of the rocprofv3
-    # --pmc passes of this very command (tools/profile_round.sh + tools/pmc_summary.py), named with its hash
-    traffic, traffic_src = None, None
+    own_frac = (runner.x_range[1] - runner.x_range[0]) / shape[0]
+    # roofline.achieved is the WHOLE PATH -- 25 algorithmic bytes per voxel (assign 12 + first refine sweep
+    # 13) over the step time; the single kernels (HIP events around each launch alone) sit under roofline.kernels with the
+    # stage's own algorithmic bytes (12 B per voxel this rank labels for an assignment kernel, 13 for the refinement's)
+    step_s = dt / args.steps
+    achieved = BYTES_PATH * nvox / step_s / 1e9
+    kernels = {}
+    for name, bytes_per_voxel in (('k_brick_masks', BYTES_ASSIGN), ('k_ng_trace', BYTES_ASSIGN), ('k_brick_records', BYTES_ASSIGN),
+                                  ('k_og_pointer', BYTES_ASSIGN), ('edge_find', 13), ('k_refine_trace', 13)):
+        if avg[name] > 0:
+            gbs = bytes_per_voxel * nvox * own_frac / (avg[name] * 1e-3) / 1e9
+            kernels[name] = {'ms_avg': avg[name], 'launches': int(tm[name][1]), 'algorithmic_bytes_per_voxel': bytes_per_voxel,
+                             'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS}
+    dom = max(kernels, key=lambda k: kernels[k]['ms_avg']) if kernels else None
+    # HBM bytes of one step (FETCH_SIZE + WRITE_SIZE over every kernel of a one-step run) from the committed summary of the
+    # rocprofv3 --pmc passes of this very command, dropped when that summary was taken from other kernel sources
+    traffic, traffic_src = None, 'only recorded for the 512^3 one-GPU configuration'
     if args.size == 512 and world == 1:
-        traffic, traffic_src = traffic_from_profile(dom, args.method)
+        traffic, traffic_src = traffic_from_profile(None, args.method)
+        if dom and dom != 'edge_find':
+            kernels[dom]['traffic'], _ = traffic_from_profile({'k_ng_trace': 'k_ng_trace_g'}.get(dom, dom), args.method)
 
     out = {
         'metric': f'Mvoxels/s {args.method} assign+refine on {args.size}^3 grid',
@@ -314,15 +373,13 @@ def main():
                                   f'table window {"slab+-%d planes" % args.table_margin if windowed else "whole grid"}',
                    'basins': int(n_basins), 'refine_log': log,
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
-        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_note': 'bytes/launch = (FETCH_SIZE + WRITE_SIZE) x 1024 of that kernel in ' + str(traffic_src) +
-                                     ' (separate rocprofv3 --pmc passes of this command; 8 B/lane row loads and 32 B record '
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': traffic,
+                     'traffic_note': 'HBM bytes of ONE step = (FETCH_SIZE + WRITE_SIZE) x 1024 summed over its kernels: ' + str(traffic_src) +
+                                     ' (separate rocprofv3 --pmc passes of this command; 8 B/lane row loads, 32 B gathers and record '
                                      'stores, so the gfx950 x2 rule for 16 B/lane streams does not apply)',
-                     'algorithmic_bytes_per_voxel': BYTES_ASSIGN, 'kernel_ms_avg': k_avg, 'launches': int(k_n),
-                     'whole_path': {'bytes_per_voxel': BYTES_PATH,
-                                    'achieved': BYTES_PATH * nvox / (dt / args.steps) / 1e9,
-                                    'frac': BYTES_PATH * nvox / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                     'algorithmic_bytes_per_voxel': BYTES_PATH, 'ms_per_step': ms_per_step,
+                     'dominant_kernel': dom, 'kernels': kernels,
                      'stage_ms_avg': avg},
     }
 
@@ -349,6 +406,31 @@ def main():
                           'basins': int(n5), 'refine_log': log5,
                           'whole_path_frac_of_hbm_roofline': BYTES_PATH * nvox / dt5 / 1e9 / HBM_PEAK_GBS,
                           'stage_ms_avg': {k: (ms / n if n else 0.0) for k, (ms, n) in tm5.items() if k != '-'}}
+        t5b, t5src = traffic_from_profile(None, 'ongrid') if args.size == 512 else (None, 'only recorded at 512^3')
+        out['config5']['traffic'] = t5b
+        out['config5']['traffic_note'] = 'HBM bytes of one step (FETCH_SIZE + WRITE_SIZE over its kernels): ' + str(t5src)
+        if not args.no_cpu:
+            # ongrid + refinement against the CPU oracle on the same bounded sample as the neargrid leg below
+            import oracle
+            shp = (args.cpu_size,) * 3
+            rho_s = oracle.synth_density(shp, lattice, atoms, background)
+            vls = np.divide(lattice, shp)
+            dm_s, tg_s = distance_matrix(vls), gradient_transform(vls)
+            t0 = time.perf_counter()
+            bmax5, want5 = oracle.bader_calc('ongrid', rho_s, np.zeros(shp, np.int32), dm_s, tg_s, 1)
+            oracle.refine('neargrid', (mode, iters), rho_s, want5, dm_s, tg_s, 1)
+            cpu5 = time.perf_counter() - t0
+            c5 = _lib.Context(0)
+            c5.set_grid(shp, dm_s, tg_s)
+            c5.upload_density(rho_s)
+            c5.vacuum_assign(None, 1.0)
+            c5.assign('ongrid')
+            c5.refine(mode, iters)
+            got5 = c5.download_labels(want5.dtype)
+            out['config5']['cpu_baseline'] = {'value': float(args.cpu_size) ** 3 / cpu5 / 1e6, 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
+                                              'sample': f'{args.cpu_size}^3 grid, ongrid assign + refine ({mode},{iters}), single thread C port',
+                                              'gpu_map_equals_cpu_map': bool(np.array_equal(got5, want5) and np.array_equal(c5.maxima(), bmax5))}
+            c5.close()
 
     # The Python drop-in (pybader_amd.thread_handlers, the reference's call signatures) on a density the headline does not
     # flatter: 216 atoms on a 256^3 grid (more maxima than round 1's 64 seed cubes), host arrays in, host arrays out --
@@ -360,8 +442,9 @@ def main():
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
     out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
     out['config']['retrace_passes_with_walkers'] = runner.n_fallbacks   # passes in which some retrace left a slab's valid planes (0 on one GPU)
-    if runner.timing is not None:   # XB_SLAB_TIMING=1: wall-clock per scheduler phase (adds a device sync around each)
-        out['config']['slab_phase_ms_avg'] = {k: v / args.steps * 1e3 for k, v in runner.timing.items()}
+    if phase_ms is not None:
+        out['config']['slab_phase_ms_avg'] = phase_ms
+        out['config']['halo_bytes_sent_per_step'] = ctx.comm_bytes_sent() / (args.warmup + args.steps + 2) if comm.transport == 'rccl' else None
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, (rho_s, dm_s, tg_s, want, bmax) = cpu_baseline(args.cpu_size, args.method, mode, iters,
                                                            lattice, atoms, background, args.size)

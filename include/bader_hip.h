@@ -207,6 +207,8 @@ int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);
 /* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order;
  * key 1: trapping boxes bit0 / brick growth bit1; key 2: trace threads per block; key 3: debug prints;
+ * key 13-18: round-3 switches, each an exactness cross-check in the tests (13 mirror prefilter of pass A, 14 lean walker,
+ * 15 waves per trace workgroup, 16 chase growth, 17 kill launches scheduled after a chase, 18 narrowed label halos);
  * key 4: workgroups of the edge_check chase; key 5: its LDS queue capacity, lowered in tests to force
  * the overflow hand-over; key 6: drop the cached gradient-field table, so that the next refinement
  * rebuilds it -- bench.py does this every step: a table kept from an earlier step would hide 1.6 ms) */
@@ -237,6 +239,8 @@ int xb_comm_allgather_i64(xb_ctx *c, const int64_t *in, int64_t n, int64_t *out)
 /* every rank's chunk [first[r], first[r]+count[r]) of the brick move masks (xb_brick_masks) and of the bricks'
  * single-maximum voxels to every rank */
 int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *count);
+/* plane bytes this rank has sent since xb_comm_init (label halos travel as dtype_calc(-n_maxima): int8 for up to 127 basins) */
+int xb_comm_stats(xb_ctx *c, int64_t *bytes_sent);
 
 #ifdef __cplusplus
 }

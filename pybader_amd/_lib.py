@@ -87,6 +87,7 @@ SYMBOLS = {
     'xb_comm_allreduce_i64': (_int, [_vp, _pi64, C.c_int64, _int]),
     'xb_comm_allgather_i64': (_int, [_vp, _pi64, C.c_int64, _pi64]),
     'xb_comm_share_brick_masks': (_int, [_vp, _pi64, _pi64]),
+    'xb_comm_stats': (_int, [_vp, _pi64]),
 }
 
 _lib = None
@@ -454,6 +455,11 @@ class Context:
     def comm_share_brick_masks(self, first, count):
         f, n = np.array(first, np.int64), np.array(count, np.int64)
         check(self.lib.xb_comm_share_brick_masks(self.h, f.ctypes.data_as(_pi64), n.ctypes.data_as(_pi64)))
+
+    def comm_bytes_sent(self):
+        n = C.c_int64(0)
+        check(self.lib.xb_comm_stats(self.h, C.byref(n)))
+        return int(n.value)
 
     def enable_timing(self, on=True):
         check(self.lib.xb_enable_timing(self.h, int(on)))

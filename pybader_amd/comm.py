@@ -2,25 +2,145 @@
 
 * `SocketStore`: the host side.  Ranks of one node find each other through a rendezvous file keyed by
   MASTER_PORT and the launcher's pid (torch.distributed.run keeps MASTER_PORT for its own store, so the
-  port itself is not ours to bind), then talk to rank 0 over TCP on 127.0.0.1: all-gather of small pickled
-  objects (maxima tables, seeds, path queries), barrier.
+  port itself is not ours to bind) -- a 0600 file in a 0700 per-user directory -- authenticate with a raw fixed-size
+  token frame (both ways, hmac), then talk to rank 0 over TCP on 127.0.0.1: all-gather of small objects (maxima tables,
+  seeds, path queries) in a tagged binary encoding (nothing received is ever unpickled), barrier.
 * `RcclComm`: the device side through the C ABI (`xb_comm_*`, csrc/comm.h): RCCL send/recv of halo planes
   over xGMI, all-reduce of the iteration counters, broadcast of the brick masks.  A start-up self-test
   (collectives, then a ring of real planes) decides -- unanimously -- between 'rccl' and 'host-staged-tcp'
   (planes staged through host memory and the store: slower, same result).
 
 The reference has no counterpart: its thread blocks share one address space (thread_handlers.py:28-58)."""
+import hmac
 import os
-import pickle
 import secrets
 import socket
+import stat
 import struct
 import tempfile
+import threading
 import time
 
 import numpy as np
 
 from . import _lib
+
+# ---- wire format ---------------------------------------------------------------------------------------------------
+# Nothing that arrives over a socket is ever unpickled (ADVICE r2: rank 0 used to pickle.loads the hello frame of any
+# local process that found its port).  The scheduler's messages are small trees of None / bool / int / float / str /
+# bytes / list / tuple / dict and numpy arrays of a few plain dtypes: encoded with a tagged binary codec that can
+# only ever produce those.  Frames are length-prefixed and capped; the hello is a fixed-size raw frame checked with
+# hmac.compare_digest before anything else is read from the peer.
+MAX_FRAME = 1 << 36            # planes of a 1024^3 halo are < 2^31 bytes; a stranger cannot make us allocate more than this
+HELLO_BYTES = 4 + 32           # rank (uint32) + 32 token characters
+_DTYPES = {'|i1', '<i2', '<i4', '<i8', '|u1', '<u2', '<u4', '<u8', '<f4', '<f8', '|b1'}
+
+
+def _enc(obj, out):
+    if obj is None:
+        out.append(b'N')
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b'T' if obj else b'F')
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b'i' + struct.pack('<q', int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b'f' + struct.pack('<d', float(obj)))
+    elif isinstance(obj, str):
+        raw = obj.encode('utf-8')
+        out.append(b's' + struct.pack('<Q', len(raw)) + raw)
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b'b' + struct.pack('<Q', len(obj)) + bytes(obj))
+    elif isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        if a.dtype.str not in _DTYPES:
+            raise TypeError(f'comm: dtype {a.dtype} does not travel')
+        ds = a.dtype.str.encode()
+        out.append(b'a' + struct.pack('<B', len(ds)) + ds + struct.pack('<B', a.ndim) + struct.pack(f'<{a.ndim}q', *a.shape))
+        out.append(a.tobytes())
+    elif isinstance(obj, (list, tuple)):
+        out.append((b'l' if isinstance(obj, list) else b't') + struct.pack('<Q', len(obj)))
+        for x in obj:
+            _enc(x, out)
+    elif isinstance(obj, dict):
+        out.append(b'd' + struct.pack('<Q', len(obj)))
+        for k, v in obj.items():
+            _enc(k, out)
+            _enc(v, out)
+    else:
+        raise TypeError(f'comm: {type(obj).__name__} does not travel')
+
+
+def encode(obj):
+    out = []
+    _enc(obj, out)
+    return b''.join(out)
+
+
+def _dec(buf, pos):
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b'N':
+        return None, pos
+    if tag == b'T':
+        return True, pos
+    if tag == b'F':
+        return False, pos
+    if tag == b'i':
+        return struct.unpack_from('<q', buf, pos)[0], pos + 8
+    if tag == b'f':
+        return struct.unpack_from('<d', buf, pos)[0], pos + 8
+    if tag in (b's', b'b'):
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError('comm: truncated frame')
+        raw = bytes(buf[pos:pos + n])
+        return (raw.decode('utf-8') if tag == b's' else raw), pos + n
+    if tag == b'a':
+        (dl,) = struct.unpack_from('<B', buf, pos)
+        ds = bytes(buf[pos + 1:pos + 1 + dl]).decode()
+        pos += 1 + dl
+        if ds not in _DTYPES:
+            raise ValueError('comm: unexpected dtype in a frame')
+        (nd,) = struct.unpack_from('<B', buf, pos)
+        shape = struct.unpack_from(f'<{nd}q', buf, pos + 1)
+        pos += 1 + 8 * nd
+        if any(d < 0 for d in shape):
+            raise ValueError('comm: bad shape in a frame')
+        dt = np.dtype(ds)
+        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize if nd else dt.itemsize
+        if n > len(buf) - pos:
+            raise ValueError('comm: truncated frame')
+        return np.frombuffer(buf, dt, count=n // dt.itemsize, offset=pos).reshape(shape).copy(), pos + n
+    if tag in (b'l', b't'):
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError('comm: truncated frame')
+        items = []
+        for _ in range(n):
+            x, pos = _dec(buf, pos)
+            items.append(x)
+        return (items if tag == b'l' else tuple(items)), pos
+    if tag == b'd':
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError('comm: truncated frame')
+        d = {}
+        for _ in range(n):
+            k, pos = _dec(buf, pos)
+            v, pos = _dec(buf, pos)
+            d[k] = v
+        return d, pos
+    raise ValueError('comm: unknown tag in a frame')
+
+
+def decode(buf):
+    obj, pos = _dec(memoryview(buf), 0)
+    if pos != len(buf):
+        raise ValueError('comm: trailing bytes in a frame')
+    return obj
 
 
 def _send_msg(sock, payload):
@@ -38,9 +158,28 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv_msg(sock):
+def _recv_msg(sock, limit=MAX_FRAME):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if n > limit:
+        raise ConnectionError(f'frame of {n} bytes exceeds the limit {limit}')
     return _recv_exact(sock, n)
+
+
+def _rendezvous_dir():
+    """A directory only this user can enter (0700, owned by us, not a symlink): the rendezvous file in it names the port
+    and the token, so whoever can write there can impersonate rank 0."""
+    base = os.environ.get('XDG_RUNTIME_DIR')
+    if not (base and os.path.isdir(base) and os.access(base, os.W_OK)):
+        base = tempfile.gettempdir()
+    path = os.path.join(base, f'pybader_amd-{os.geteuid()}')
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+        raise PermissionError(f'{path} is not a private directory of this user: refusing to rendezvous through it')
+    return path
 
 
 class SocketStore:
@@ -55,7 +194,8 @@ class SocketStore:
             return
         if key is None:
             key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', '')}_{os.getppid()}"
-        path = os.path.join(tempfile.gettempdir(), f'pybader_amd_rdzv_{key}')
+        key = ''.join(ch if ch.isalnum() or ch in '-_.' else '_' for ch in str(key))
+        path = os.path.join(_rendezvous_dir(), f'rdzv_{key}')
         deadline = time.monotonic() + timeout
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -64,37 +204,54 @@ class SocketStore:
             srv.listen(self.size)
             srv.settimeout(timeout)
             token = secrets.token_hex(16)
-            tmp = f'{path}.{os.getpid()}.tmp'
-            with open(tmp, 'w') as f:
+            try:
+                os.unlink(path)              # a stale file of an earlier run with the same key
+            except FileNotFoundError:
+                pass
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+            with os.fdopen(fd, 'w') as f:
                 f.write(f'{srv.getsockname()[1]} {token}\n')
-            os.replace(tmp, path)            # atomic: a reader sees the old file or the new one
             self._path = path
             slots = [None] * self.size
             while any(s is None for s in slots[1:]):
                 conn, _ = srv.accept()
-                conn.settimeout(timeout)
+                conn.settimeout(min(timeout, 10.0))
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                hello = pickle.loads(_recv_msg(conn))
-                if hello.get('token') != token or not (0 < hello.get('rank', -1) < self.size):
+                try:                         # fixed-size raw hello, authenticated before anything is decoded
+                    hello = _recv_exact(conn, HELLO_BYTES)
+                    (r,) = struct.unpack('<I', hello[:4])
+                    good = hmac.compare_digest(hello[4:], token.encode()) and 0 < r < self.size and slots[r] is None
+                except (OSError, ConnectionError):
+                    good = False
+                if not good:
                     conn.close()             # a stranger, or a rank of an earlier run that read a stale file
                     continue
-                slots[hello['rank']] = conn
-                _send_msg(conn, b'ok')
+                conn.settimeout(timeout)
+                slots[r] = conn
+                # mutual: the peer checks that the server it found knows the token too
+                conn.sendall(hmac.new(token.encode(), b'rank0:' + hello[:4], 'sha256').digest())
             srv.close()
             self.peers = slots
         else:
             while True:                      # the file may be missing or stale (an earlier run): retry until rank 0 answers
                 try:
-                    with open(path) as f:
+                    fd = os.open(path, os.O_RDONLY | getattr(os, 'O_NOFOLLOW', 0))
+                    with os.fdopen(fd) as f:
+                        st = os.fstat(f.fileno())
+                        if st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+                            raise PermissionError(f'{path} is not a private file of this user')
                         port, token = f.read().split()
                     s = socket.create_connection(('127.0.0.1', int(port)), timeout=5.0)
                     s.settimeout(timeout)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    _send_msg(s, pickle.dumps({'rank': self.rank, 'token': token}))
-                    if _recv_msg(s) == b'ok':
+                    me = struct.pack('<I', self.rank)
+                    s.sendall(me + token.encode())
+                    if hmac.compare_digest(_recv_exact(s, 32), hmac.new(token.encode(), b'rank0:' + me, 'sha256').digest()):
                         self.sock = s
                         break
                     s.close()
+                except PermissionError:
+                    raise
                 except (OSError, ValueError, ConnectionError):
                     pass
                 if time.monotonic() > deadline:
@@ -105,13 +262,13 @@ class SocketStore:
         if self.size == 1:
             return [obj]
         if self.rank == 0:
-            out = [obj] + [pickle.loads(_recv_msg(c)) for c in self.peers[1:]]
-            blob = pickle.dumps(out, protocol=pickle.HIGHEST_PROTOCOL)
+            out = [obj] + [decode(_recv_msg(c)) for c in self.peers[1:]]
+            blob = encode(out)
             for c in self.peers[1:]:
                 _send_msg(c, blob)
             return out
-        _send_msg(self.sock, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
-        return pickle.loads(_recv_msg(self.sock))
+        _send_msg(self.sock, encode(obj))
+        return decode(_recv_msg(self.sock))
 
     def barrier(self):
         self.allgather(None)
@@ -126,13 +283,15 @@ class SocketStore:
             for dst, obj in out.items():
                 boxes[dst][0] = obj
             for src in range(1, self.size):
-                for dst, obj in pickle.loads(_recv_msg(self.peers[src])).items():
+                for dst, obj in decode(_recv_msg(self.peers[src])).items():
+                    if not (isinstance(dst, int) and 0 <= dst < self.size):
+                        raise ValueError('comm: bad destination in a routed frame')
                     boxes[dst][src] = obj
             for dst in range(1, self.size):
-                _send_msg(self.peers[dst], pickle.dumps(boxes[dst], protocol=pickle.HIGHEST_PROTOCOL))
+                _send_msg(self.peers[dst], encode(boxes[dst]))
             return boxes[0]
-        _send_msg(self.sock, pickle.dumps(out, protocol=pickle.HIGHEST_PROTOCOL))
-        return pickle.loads(_recv_msg(self.sock))
+        _send_msg(self.sock, encode(out))
+        return decode(_recv_msg(self.sock))
 
     def close(self):
         for c in self.peers[1:] if self.peers else []:
@@ -145,6 +304,46 @@ class SocketStore:
             except OSError:
                 pass
         self.peers, self.sock, self._path = [], None, None
+
+
+class Watchdog:
+    """A device collective that a peer never joins does not return and cannot be cancelled: a rank whose ncclCommInitRank
+    failed, or that died, would leave the others waiting for ever.  Every device collective of RcclComm runs
+    under this deadline; when it passes the PROCESS exits non-zero with a message, so the launcher ends the job loudly
+    instead of hanging it.  ctypes releases the GIL during the library calls, so the timer thread does fire."""
+
+    def __init__(self, seconds=None):
+        self.seconds = float(os.environ.get('XB_COMM_TIMEOUT', '180')) if seconds is None else float(seconds)
+        self._deadline, self._what = None, ''
+        self._lock = threading.Lock()
+        self._thread = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                d, what = self._deadline, self._what
+            if d is not None and time.monotonic() > d:
+                import sys
+                print(f'pybader_amd.comm: device collective `{what}` did not complete within {self.seconds:.0f} s '
+                      '(a peer is missing or stuck); exiting', file=sys.stderr, flush=True)
+                os._exit(86)
+
+    def __call__(self, what):
+        self._what_next = what
+        return self
+
+    def __enter__(self):
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, name='xb-comm-watchdog', daemon=True)
+            self._thread.start()
+        with self._lock:
+            self._deadline, self._what = time.monotonic() + self.seconds, getattr(self, '_what_next', '')
+
+    def __exit__(self, *exc):
+        with self._lock:
+            self._deadline = None
+        return False
 
 
 class _stdout_to_stderr:
@@ -217,34 +416,57 @@ class RcclComm(HostComm):
         super().__init__(store)
         self.ctx = ctx
         self.device = False
+        self.init_error = None        # why the device transport is not in use (bench.py prints it and fails on a full node)
+        self.watchdog = Watchdog()
         self.transport = 'none' if self.size == 1 else 'host-staged-tcp'
         if self.size == 1:
             return
-        with _stdout_to_stderr():
-            uid = ctx.comm_unique_id() if self.rank == 0 else None
-        uid = self.allgather(uid)[0]
         ok = True
+        uid = None
         try:
             with _stdout_to_stderr():
-                ctx.comm_init(self.rank, self.size, uid)
+                uid = ctx.comm_unique_id() if self.rank == 0 else None
         except _lib.BaderHipError as err:
-            ok = False
             self.init_error = str(err)
+        uid = self.allgather(uid)[0]
+        if uid is None:
+            ok = False
+            self.init_error = self.init_error or 'rank 0 could not make an RCCL unique id'
+        else:
+            try:
+                with _stdout_to_stderr(), self.watchdog('ncclCommInitRank'):
+                    ctx.comm_init(self.rank, self.size, uid)
+            except _lib.BaderHipError as err:
+                ok = False
+                self.init_error = str(err)
         # first vote (over the store): a rank without a communicator must keep the others out of the device collectives,
         # which would wait for it for ever
         if all(self.allgather(bool(ok))):
             try:
                 n = self.size
-                ok = ctx.comm_allreduce([self.rank + 1, 1]) == [n * (n + 1) // 2, n]
-                ok = ok and ctx.comm_allgather([self.rank, 7 * self.rank]).reshape(n, 2).tolist() == [[r, 7 * r] for r in range(n)]
+                with self.watchdog('self-test collectives'):
+                    ok = ctx.comm_allreduce([self.rank + 1, 1]) == [n * (n + 1) // 2, n]
+                    ok = ok and ctx.comm_allgather([self.rank, 7 * self.rank]).reshape(n, 2).tolist() == [[r, 7 * r] for r in range(n)]
+                if not ok:
+                    self.init_error = 'the RCCL self-test collectives returned wrong values'
             except _lib.BaderHipError as err:
                 ok = False
                 self.init_error = str(err)
         else:
             ok = False
-        self.device = all(self.allgather(bool(ok)))     # unanimous: every rank takes the same transport
+            self.init_error = self.init_error or 'a peer rank has no RCCL communicator'
+        votes = self.allgather(bool(ok))
+        self.device = all(votes)     # unanimous: every rank takes the same transport
         if self.device:
             self.transport = 'rccl'
+        elif self.init_error is None:
+            self.init_error = f'ranks {[r for r, v in enumerate(votes) if not v]} failed the RCCL self-test'
+
+    watchdog = None
+
+    def _guard(self, what):
+        import contextlib
+        return self.watchdog(what) if self.watchdog is not None else contextlib.nullcontext()
 
     def selftest_planes(self, backend, ranges):
         """second stage of the self-test, on the arrays that will really travel: every rank's first owned label
@@ -258,19 +480,26 @@ class RcclComm(HostComm):
         ok = True
         try:
             ctx.copy_planes(0, True, plane, mine, mine + 1)
-            ctx.comm_exchange_planes(0, [(nxt, mine, mine + 1)], [(prv, theirs, theirs + 1)])
+            with self.watchdog('self-test plane ring'):
+                ctx.comm_exchange_planes(0, [(nxt, mine, mine + 1)], [(prv, theirs, theirs + 1)])
             got = np.empty_like(plane)
             ctx.copy_planes(0, False, got, theirs, theirs + 1)
             ok = bool((got == prv + 1).all())
-        except _lib.BaderHipError:
+            if not ok:
+                self.init_error = 'the RCCL plane ring delivered a wrong payload'
+        except _lib.BaderHipError as err:
             ok = False
-        if not all(self.allgather(ok)):
+            self.init_error = str(err)
+        votes = self.allgather(ok)
+        if not all(votes):
             self.device = False
             self.transport = 'host-staged-tcp'
+            self.init_error = self.init_error or f'ranks {[r for r, v in enumerate(votes) if not v]} failed the RCCL plane ring'
 
     def sum(self, *vals):
         if self.device:
-            return self.ctx.comm_allreduce([int(v) for v in vals])
+            with self._guard('allreduce'):
+                return self.ctx.comm_allreduce([int(v) for v in vals])
         return super().sum(*vals)
 
     FAST_ROWS = 32     # contributions up to this many rows travel in ONE collective (count + rows, padded)
@@ -283,14 +512,16 @@ class RcclComm(HostComm):
         first = np.zeros((self.FAST_ROWS + 1, w), np.int64)
         first[0, 0] = n
         first[1:1 + min(n, self.FAST_ROWS)] = rows[:self.FAST_ROWS]
-        got = self.ctx.comm_allgather(first.reshape(-1)).reshape(self.size, self.FAST_ROWS + 1, w)
+        with self._guard('allgather'):
+            got = self.ctx.comm_allgather(first.reshape(-1)).reshape(self.size, self.FAST_ROWS + 1, w)
         counts = got[:, 0, 0]
         cap = int(counts.max())
         if cap <= self.FAST_ROWS:       # the tie flags, the maxima rows, the last walker rounds
             return np.concatenate([got[r, 1:1 + int(counts[r])] for r in range(self.size)])
         padded = np.zeros((cap, w), np.int64)
         padded[:n] = rows
-        got = self.ctx.comm_allgather(padded.reshape(-1)).reshape(self.size, cap, w)
+        with self._guard('allgather'):
+            got = self.ctx.comm_allgather(padded.reshape(-1)).reshape(self.size, cap, w)
         return np.concatenate([got[r, :int(counts[r])] for r in range(self.size)])
 
     def exchange_planes(self, backend, which, sends, recvs):
@@ -298,7 +529,8 @@ class RcclComm(HostComm):
             return
         ctx = self.ctx
         if self.device:
-            ctx.comm_exchange_planes(which, sends, recvs)
+            with self._guard('plane exchange'):
+                ctx.comm_exchange_planes(which, sends, recvs)
             return
         dt = np.int32 if which == 0 else np.int8
         pe = ctx.plane_elems()
@@ -313,7 +545,8 @@ class RcclComm(HostComm):
     def share_brick_masks(self, backend, chunks):
         ctx = self.ctx
         if self.device:
-            ctx.comm_share_brick_masks([c[0] for c in chunks], [c[1] for c in chunks])
+            with self._guard('brick mask broadcast'):
+                ctx.comm_share_brick_masks([c[0] for c in chunks], [c[1] for c in chunks])
             return
         first, count = chunks[self.rank]
         parts = self.allgather(ctx.brick_masks_copy(None, first, count))

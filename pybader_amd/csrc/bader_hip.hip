@@ -104,6 +104,8 @@ struct xb_ctx {
     bool grad_valid = false;
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
+    int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
+    int opt_narrow_halo = 1;   // label halos travel as dtype_calc(-n_maxima) (int8 / int16) instead of int32 (comm.h)
     int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
     int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
     long long stat_grow_retries = 0;
@@ -375,9 +377,14 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     return XB_OK;
 }
 
+static int settle_labels(xb_ctx *c);
 int xb_set_halo(xb_ctx *c, int64_t halo) {
     if (!c || !c->has_grid) return fail(XB_E_STATE, "xb_set_halo: no grid");
     if (halo < 2) return fail(XB_E_ARG, "xb_set_halo: halo must be >= 2 planes");
+    // a deferred `labels := 0` was sized with the old halo: pay it first, and forget what is known to be zero outside
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = settle_labels(c)) return rc;
+    c->zero_outside[0] = -1;
     c->halo = (int)halo;
     set_valid_range(c);
     return XB_OK;
@@ -388,7 +395,7 @@ int xb_set_halo(xb_ctx *c, int64_t halo) {
 // entry point pays the debt first, so the deferral is not observable.
 static int zero_slab_labels(xb_ctx *c) {   // the owned + halo planes of a slab (the others are known to be zero)
     const Grid &g = c->g;
-    const int len = (g.x1 - g.x0) + 2 * c->halo, first = ((g.x0 - c->halo) % g.nx + g.nx) % g.nx;
+    const int len = std::min(g.nx, (g.x1 - g.x0) + 2 * c->halo), first = ((g.x0 - c->halo) % g.nx + g.nx) % g.nx;
     const int run1 = std::min(len, g.nx - first);
     HIPCHK(hipMemsetAsync(c->labels + (size_t)first * g.nyz, 0, (size_t)run1 * g.nyz * sizeof(int), c->stream));
     if (len > run1) HIPCHK(hipMemsetAsync(c->labels, 0, (size_t)(len - run1) * g.nyz * sizeof(int), c->stream));
@@ -2565,6 +2572,8 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 12) c->opt_sparse = value != 0;   // 0: the round-1 route (a 32-byte record for every voxel)
     else if (key == 14) c->opt_lean = value != 0;
     else if (key == 16) c->opt_chase = value != 0;
+    else if (key == 18) c->opt_narrow_halo = value != 0;
+    else if (key == 19) c->opt_self_exchange = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)

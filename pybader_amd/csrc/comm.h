@@ -67,6 +67,7 @@ struct State {
     int64_t *dbuf = nullptr;   // device staging for the small collectives
     int64_t *hbuf = nullptr;   // pinned
     size_t cap = 0;            // int64 entries of each
+    unsigned long long bytes_sent = 0;   // plane bytes this rank has sent (xb_comm_stats)
 };
 }  // namespace xbcomm
 
@@ -75,6 +76,21 @@ struct State {
         xbcomm::ncclResult_t r_ = (x);                                                                               \
         if (r_ != xbcomm::ncclSuccess)                                                                               \
             return fail(XB_E_COMM, "%s:%d %s: %s", __FILE__, __LINE__, #x, xbcomm::g_api.GetErrorString ? xbcomm::g_api.GetErrorString(r_) : "?"); \
+    } while (0)
+
+// Inside an ncclGroup an early return would leave the group OPEN, and the next collective of this rank would block for
+// ever: calls between GroupStart and GroupEnd record the first error instead, GroupEnd always runs, and the
+// error is reported after it.
+struct GroupErr {
+    xbcomm::ncclResult_t first = xbcomm::ncclSuccess;
+    const char *what = "";
+    void see(xbcomm::ncclResult_t r, const char *w) { if (r != xbcomm::ncclSuccess && first == xbcomm::ncclSuccess) { first = r; what = w; } }
+};
+#define NCCL_GROUP_END(ge, who)                                                                                       \
+    do {                                                                                                              \
+        (ge).see(xbcomm::g_api.GroupEnd(), "ncclGroupEnd");                                                           \
+        if ((ge).first != xbcomm::ncclSuccess)                                                                        \
+            return fail(XB_E_COMM, "%s: %s: %s", who, (ge).what, xbcomm::g_api.GetErrorString ? xbcomm::g_api.GetErrorString((ge).first) : "?"); \
     } while (0)
 
 static int comm_need(xb_ctx *c, const char *who) {
@@ -143,19 +159,73 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
     const size_t es = which == 0 ? 4 : 1;
     char *base = which == 0 ? (char *)c->labels : (char *)c->known;
     const int dt = which == 0 ? xbcomm::ncclInt32 : xbcomm::ncclInt8;
-    auto bad = [&](int peer, int64_t xa, int64_t xb) { return peer < 0 || peer >= c->comm->size || peer == c->comm->rank || xa < 0 || xb > g.nx || xa >= xb; };
+    // (a send to oneself is refused: no slab is its own neighbour -- except for the one-GPU test of this very path, option 19)
+    auto bad = [&](int peer, int64_t xa, int64_t xb) {
+        return peer < 0 || peer >= c->comm->size || (peer == c->comm->rank && !c->opt_self_exchange) || xa < 0 || xb > g.nx || xa >= xb;
+    };
     for (int i = 0; i < n_send; i++) if (bad(send_peer[i], send_xa[i], send_xb[i])) return fail(XB_E_ARG, "xb_comm_exchange_planes: bad send %d", i);
     for (int i = 0; i < n_recv; i++) if (bad(recv_peer[i], recv_xa[i], recv_xb[i])) return fail(XB_E_ARG, "xb_comm_exchange_planes: bad recv %d", i);
     if (n_recv) { c->list_valid = false; c->buni_valid = c->buni_valid && c->buni_halo_safe; }   // halo planes of peers that ran the same assignment
+    // Label planes travel in the narrowest signed type that holds every label (the reference's own dtype_calc(-n_maxima),
+    // thread_handlers.py:70-74: int8 for every BASELINE configuration -- a quarter of the int32 bytes per halo): packed into
+    // the staging buffer before the group, widened back behind it, all on the context's stream.
+    const size_t n_lab = c->maxima_sorted.size();
+    const int wire = (which == 0 && c->opt_narrow_halo && n_lab >= 1) ? (2 * n_lab <= 255 ? 1 : (2 * n_lab <= 65535 ? 2 : 4)) : (int)es;
+    size_t total = 0;
+    for (int i = 0; i < n_send; i++) total += (size_t)(send_xb[i] - send_xa[i]) * g.nyz;
+    for (int i = 0; i < n_recv; i++) total += (size_t)(recv_xb[i] - recv_xa[i]) * g.nyz;
+    const bool packed = which == 0 && wire < 4 && total * wire <= c->stage_bytes;
+    char *pk = (char *)c->stage;
+    std::vector<size_t> off_s(n_send), off_r(n_recv);
+    if (packed) {
+        size_t o = 0;
+        for (int i = 0; i < n_send; i++) {
+            off_s[i] = o;
+            const long long n = (long long)(send_xb[i] - send_xa[i]) * g.nyz;
+            const int *src = c->labels + (size_t)send_xa[i] * g.nyz;
+            if (wire == 1) k_narrow<int8_t><<<nblocks(n), TPB, 0, c->stream>>>(src, (int8_t *)(pk + o), n);
+            else k_narrow<int16_t><<<nblocks(n), TPB, 0, c->stream>>>(src, (int16_t *)(pk + o), n);
+            o += ((size_t)n * wire + 15) & ~(size_t)15;
+        }
+        for (int i = 0; i < n_recv; i++) {
+            off_r[i] = o;
+            o += ((size_t)(recv_xb[i] - recv_xa[i]) * g.nyz * wire + 15) & ~(size_t)15;
+        }
+        HIPCHK(hipGetLastError());
+    }
+    const int wdt = packed ? xbcomm::ncclInt8 : dt;           // packed planes travel as bytes (send / recv only move them)
+    const size_t wmul = packed ? (size_t)wire : 1;            // ... so their element count is a byte count
     NCCLCHK(xbcomm::g_api.GroupStart());
+    GroupErr ge;
     for (int i = 0; i < n_recv; i++)
-        NCCLCHK(xbcomm::g_api.Recv(base + (size_t)recv_xa[i] * g.nyz * es, (size_t)(recv_xb[i] - recv_xa[i]) * g.nyz, dt, recv_peer[i],
-                                   c->comm->comm, c->stream));
+        ge.see(xbcomm::g_api.Recv(packed ? pk + off_r[i] : base + (size_t)recv_xa[i] * g.nyz * es, (size_t)(recv_xb[i] - recv_xa[i]) * g.nyz * wmul, wdt,
+                                  recv_peer[i], c->comm->comm, c->stream), "ncclRecv");
     for (int i = 0; i < n_send; i++)
-        NCCLCHK(xbcomm::g_api.Send(base + (size_t)send_xa[i] * g.nyz * es, (size_t)(send_xb[i] - send_xa[i]) * g.nyz, dt, send_peer[i],
-                                   c->comm->comm, c->stream));
-    NCCLCHK(xbcomm::g_api.GroupEnd());
+        ge.see(xbcomm::g_api.Send(packed ? pk + off_s[i] : base + (size_t)send_xa[i] * g.nyz * es, (size_t)(send_xb[i] - send_xa[i]) * g.nyz * wmul, wdt,
+                                  send_peer[i], c->comm->comm, c->stream), "ncclSend");
+    NCCL_GROUP_END(ge, "xb_comm_exchange_planes");
+    if (packed) {
+        for (int i = 0; i < n_recv; i++) {
+            const long long n = (long long)(recv_xb[i] - recv_xa[i]) * g.nyz;
+            int *dst = c->labels + (size_t)recv_xa[i] * g.nyz;
+            if (wire == 1) k_widen<int8_t><<<nblocks(n), TPB, 0, c->stream>>>((const int8_t *)(pk + off_r[i]), dst, n);
+            else k_widen<int16_t><<<nblocks(n), TPB, 0, c->stream>>>((const int16_t *)(pk + off_r[i]), dst, n);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    {
+        size_t t = 0;
+        for (int i = 0; i < n_send; i++) t += (size_t)(send_xb[i] - send_xa[i]) * g.nyz;
+        c->comm->bytes_sent += (unsigned long long)t * (packed ? (size_t)wire : es);
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+// plane bytes this rank has sent since xb_comm_init (the narrowed halos show here)
+int xb_comm_stats(xb_ctx *c, int64_t *bytes_sent) {
+    if (!c || !c->comm) return fail(XB_E_STATE, "xb_comm_stats: call xb_comm_init first");
+    if (bytes_sent) *bytes_sent = (int64_t)c->comm->bytes_sent;
     return XB_OK;
 }
 
@@ -199,12 +269,13 @@ int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *co
     for (int r = 0; r < c->comm->size; r++)
         if (first[r] < 0 || count[r] < 0 || first[r] + count[r] > nbr) return fail(XB_E_ARG, "xb_comm_share_brick_masks: bad chunk of rank %d", r);
     NCCLCHK(xbcomm::g_api.GroupStart());
+    GroupErr ge;
     for (int r = 0; r < c->comm->size; r++)
         if (count[r]) {
-            NCCLCHK(xbcomm::g_api.Broadcast(masks + first[r], masks + first[r], (size_t)count[r], xbcomm::ncclInt32, r, c->comm->comm, c->stream));
-            NCCLCHK(xbcomm::g_api.Broadcast(maxvox + first[r], maxvox + first[r], (size_t)count[r], xbcomm::ncclInt32, r, c->comm->comm, c->stream));
+            ge.see(xbcomm::g_api.Broadcast(masks + first[r], masks + first[r], (size_t)count[r], xbcomm::ncclInt32, r, c->comm->comm, c->stream), "ncclBroadcast");
+            ge.see(xbcomm::g_api.Broadcast(maxvox + first[r], maxvox + first[r], (size_t)count[r], xbcomm::ncclInt32, r, c->comm->comm, c->stream), "ncclBroadcast");
         }
-    NCCLCHK(xbcomm::g_api.GroupEnd());
+    NCCL_GROUP_END(ge, "xb_comm_share_brick_masks");
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;
 }

@@ -134,7 +134,9 @@ class SlabRunner:
         self.shape = tuple(int(s) for s in shape)
         self.ranges = slab_ranges(self.shape[0], comm.size)
         self.x_range = self.ranges[comm.rank]
-        self.halo = max(2, min(int(halo), self.shape[0]))
+        # (two planes carry a one-GPU run; across slabs the 'changed' refinement's edge_check needs three: refuse less up
+        # front rather than mid-run, after collectives have been issued)
+        self.halo = max(3 if comm.size > 1 else 2, min(int(halo), self.shape[0]))
         self.be.set_grid(self.shape, dist_mat, T_grad, self.x_range, self.halo)
         self.sends, self.recvs = halo_plan(self.ranges, comm.rank, self.halo, self.shape[0])
         self.n_maxima = 0

@@ -271,6 +271,22 @@ def test_rccl_transport_through_the_c_abi_single_rank():
     assert n == 8 and np.array_equal(ctx.download_labels(np.int32), before)
     with pytest.raises(_lib.BaderHipError):
         ctx.comm_exchange_planes(0, [(0, 0, 1)], [])       # a send to myself is refused
+    # the narrowed halo (round 3): 8 basins -> label planes travel as int8, packed before the group and widened behind it.
+    # One GPU can run that very code with itself as the peer (test switch 19): planes [3, 7) -> [40, 44), a second run
+    # [60, 62) -> [10, 12) in the same group, then the same with int32 on the wire (switch 18 off)
+    nyz = rho.shape[1] * rho.shape[2]
+    ctx.set_option(19, 1)
+    for narrow, width in ((1, 1), (0, 4)):
+        ctx.set_option(18, narrow)
+        ctx.upload_labels(before)
+        sent0 = ctx.comm_bytes_sent()
+        ctx.comm_exchange_planes(0, [(0, 3, 7), (0, 60, 62)], [(0, 40, 44), (0, 10, 12)])
+        want = before.copy()
+        want[40:44], want[10:12] = before[3:7], before[60:62]
+        assert np.array_equal(ctx.download_labels(np.int32), want)
+        assert ctx.comm_bytes_sent() - sent0 == 6 * nyz * width
+    ctx.set_option(19, 0)
+    ctx.set_option(18, 1)
     # RcclComm.gather_rows through the device collectives (one rank: what comes back is what went in): the single
     # collective for short contributions, the second one for long ones
     from pybader_amd import comm as pcomm

@@ -4,6 +4,7 @@ the oracle; the assembled map must equal the single-rank result and the referenc
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -344,3 +345,95 @@ def test_socket_store_route_delivers_point_to_point():
         want = {src: 10 * src + r for src in range(n) if src != r and (src + r) % 2 == 1}
         assert sorted(got[r]) == sorted(want)
         assert all(np.array_equal(got[r][src], np.full(3, v)) for src, v in want.items())
+
+
+def test_wire_codec_roundtrip_and_rejects_garbage():
+    """nothing received over a socket is unpickled -- the store's frames are a tagged binary encoding of plain
+    values and numpy arrays of a few dtypes; anything else does not encode, and malformed frames do not decode."""
+    import struct
+    from pybader_amd import comm as pcomm
+    obj = {'a': [1, 2.5, None, True, (3, 'x', b'yy')], 3: np.arange(6, dtype=np.int32).reshape(2, 3), (1, 2): {0: np.zeros(0, np.int8)},
+           'rows': np.arange(20, dtype=np.int64).reshape(-1, 10)}
+    back = pcomm.decode(pcomm.encode(obj))
+    assert back['a'] == obj['a'] and np.array_equal(back[3], obj[3]) and back[3].dtype == np.int32
+    assert back[(1, 2)][0].shape == (0,) and np.array_equal(back['rows'], obj['rows'])
+    good = pcomm.encode(obj)
+    for bad in (b'', b'Z', b'i\x00', good + b'x', good[:-3], b'l' + struct.pack('<Q', 1 << 60),
+                b'a\x03<f8\x01' + struct.pack('<q', 1 << 40), b'a\x03<c8\x01' + struct.pack('<q', 0), b's' + struct.pack('<Q', 99) + b'abc'):
+        with pytest.raises((ValueError, struct.error)):
+            pcomm.decode(bad)
+    for unsendable in (object(), {1: {2, 3}}, np.zeros(2, np.complex128), np.array(['a'], dtype=object)):
+        with pytest.raises(TypeError):
+            pcomm.encode(unsendable)
+
+
+def test_store_authenticates_before_it_reads_anything_else(tmp_path):
+    """A local stranger that finds rank 0's port is dropped on its (wrong) fixed-size hello: the pickle it sends along is
+    never looked at, a giant length prefix allocates nothing, and the real rank 1 still gets in afterwards.  The rendezvous
+    file is a 0600 file in a 0700 directory of this user."""
+    import os
+    import pickle
+    import socket
+    import stat
+    import struct
+    import threading
+    from pybader_amd import comm as pcomm
+    key = f'test_auth_{os.getpid()}'
+    marker = tmp_path / 'pwned'
+    out = {}
+
+    def rank0():
+        st = pcomm.SocketStore(0, 2, key=key, timeout=60.0)
+        out['gathered'] = st.allgather({'rank': 0})
+        st.close()
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    d = pcomm._rendezvous_dir()
+    assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    path = os.path.join(d, f'rdzv_{key}')
+    for _ in range(200):
+        if os.path.exists(path):
+            break
+        time.sleep(0.05)
+    assert stat.S_IMODE(os.lstat(path).st_mode) == 0o600
+    port = int(open(path).read().split()[0])
+
+    class Bomb:
+        def __reduce__(self):
+            return (open, (str(marker), 'w'))
+
+    for payload in (struct.pack('<I', 1) + b'0' * 32 + pickle.dumps(Bomb()),            # wrong token, pickle behind it
+                    struct.pack('<Q', 1 << 62) + pickle.dumps({'rank': 1, 'token': 'x'}),   # round 2's frame layout, absurd length
+                    b'short'):
+        s = socket.create_connection(('127.0.0.1', port), timeout=5.0)
+        s.sendall(payload)
+        s.shutdown(socket.SHUT_WR)
+        try:
+            assert s.recv(64) == b''      # dropped without an answer
+        except ConnectionResetError:      # (closed with the rest of the stranger's bytes unread)
+            pass
+        s.close()
+    assert not marker.exists()
+    st1 = pcomm.SocketStore(1, 2, key=key, timeout=60.0)
+    got = st1.allgather({'rank': 1})
+    st1.close()
+    t.join()
+    assert got == [{'rank': 0}, {'rank': 1}] == out['gathered']
+    assert not marker.exists() and not os.path.exists(path)
+
+
+def test_comm_watchdog_ends_the_process_when_a_collective_never_returns():
+    """A device collective a peer never joins cannot be cancelled: the watchdog ends the PROCESS with a message
+    and a non-zero code, so the launcher sees a failure instead of a hang."""
+    import subprocess
+    import sys
+    code = ("import time, sys; sys.path.insert(0, %r)\n"
+            "from pybader_amd.comm import Watchdog\n"
+            "w = Watchdog(0.4)\n"
+            "with w('ncclAllReduce (test)'):\n"
+            "    time.sleep(0.05)\n"          # a collective that completes: nothing happens
+            "with w('ncclCommInitRank (test)'):\n"
+            "    time.sleep(30)\n") % ROOT
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=25, text=True)
+    assert r.returncode == 86 and 'ncclCommInitRank (test)' in r.stderr and 'did not complete' in r.stderr

@@ -8,6 +8,14 @@ def short(name):
     return name.split('(')[0]
 
 root = sys.argv[1]
+# the kernel sources this summary was taken from (bench.py drops a `traffic` figure whose sources are not the running ones)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import source_hash
+    print(f'# sources {source_hash()}')
+except Exception as err:   # pragma: no cover
+    print(f'# sources unknown ({err})')
 for sub in ('fetch', 'write'):
     files = glob.glob(f'{root}/{sub}/**/*counter_collection.csv', recursive=True)
     tot, cnt = defaultdict(float), defaultdict(int)
