@@ -147,7 +147,18 @@ class Context:
         # utils.resident(): identity of the host array the caller pinned / of the one whose content is on the device
         self.pinned_density = None
         self.resident_density = None
+        # utils.track_labels(): identity of the host array whose content equals the device labels (inside resident() only)
+        self.resident_labels = None
+        self._labels_host = None
         self.n_maxima = 0
+
+    def drop_label_token(self):
+        """the device labels are about to change (or be replaced): no host array equals them any more"""
+        a = getattr(self, '_labels_host', None)
+        if a is not None and getattr(self, '_labels_was_writeable', False):
+            a.flags.writeable = True
+        self._labels_host = None
+        self.resident_labels = None
 
     def close(self):
         if getattr(self, 'h', None):
@@ -192,6 +203,7 @@ class Context:
         return out
 
     def upload_labels(self, labels):
+        self.drop_label_token()
         labels = np.ascontiguousarray(labels)
         assert labels.shape == self.shape
         check(self.lib.xb_upload_labels(self.h, _ptr(labels), DTYPE_CODE[labels.dtype]))
@@ -214,12 +226,14 @@ class Context:
 
     # -- hot path ---------------------------------------------------------------------------
     def vacuum_assign(self, vac_tol, voxel_volume):
+        self.drop_label_token()
         a, b = C.c_double(), C.c_double()
         tol = float('nan') if vac_tol is None else float(vac_tol)
         check(self.lib.xb_vacuum_assign(self.h, tol, float(voxel_volume), C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def assign(self, method):
+        self.drop_label_token()
         n = C.c_int64()
         check(self.lib.xb_assign(self.h, METHODS[method], C.byref(n)))
         self.n_maxima = n.value
@@ -231,6 +245,7 @@ class Context:
         return out
 
     def assign_trace(self, method):
+        self.drop_label_token()
         n = C.c_int64()
         check(self.lib.xb_assign_trace(self.h, METHODS[method], C.byref(n)))
         m, f = np.zeros(n.value, np.int64), np.zeros(n.value, np.int64)
@@ -238,6 +253,7 @@ class Context:
         return m, f
 
     def assign_finish(self, max_sorted):
+        self.drop_label_token()
         ms = np.ascontiguousarray(max_sorted, dtype=np.int64)
         check(self.lib.xb_assign_finish(self.h, _ptr(ms), ms.shape[0]))
         self.n_maxima = int(ms.shape[0])
@@ -251,11 +267,13 @@ class Context:
         return n.value
 
     def refine_trace(self):
+        self.drop_label_token()
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_refine_trace(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def refine_trace_escaped(self):
+        self.drop_label_token()
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_refine_trace_escaped(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
@@ -291,6 +309,7 @@ class Context:
         return lab, kn
 
     def scatter_voxels(self, idx, labels, known):
+        self.drop_label_token()
         idx = np.ascontiguousarray(idx, np.int64)
         lab = np.ascontiguousarray(labels, np.int32)
         kn = np.ascontiguousarray(known, np.int8)
@@ -315,6 +334,7 @@ class Context:
 
     def walkers_apply(self, results):
         """-> (changed, stuck)"""
+        self.drop_label_token()
         r = np.ascontiguousarray(results, np.int64).reshape(-1)
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_walkers_apply(self.h, _ptr(r), r.size, C.byref(a), C.byref(b)))
@@ -342,6 +362,7 @@ class Context:
         return a.value, b.value
 
     def refine(self, mode, iters):
+        self.drop_label_token()
         cap = 4096
         log = np.zeros(cap, dtype=np.int64)
         n = C.c_int64()
@@ -355,6 +376,7 @@ class Context:
         return ch, vo
 
     def volume_assign(self, swap):
+        self.drop_label_token()
         sw = np.ascontiguousarray(swap, dtype=np.int64)
         check(self.lib.xb_volume_assign(self.h, _ptr(sw), sw.shape[0]))
 
@@ -400,6 +422,7 @@ class Context:
         check(self.lib.xb_table_finish(self.h, _ptr(sd), sd.shape[0], int(bool(any_ties))))
 
     def copy_planes(self, which, to_device, host, xa, xb):
+        self.drop_label_token()
         check(self.lib.xb_copy_planes(self.h, int(which), int(to_device), _ptr(host), int(xa), int(xb)))
 
     # -- measurement ------------------------------------------------------------------------
@@ -441,6 +464,7 @@ class Context:
         return out
 
     def comm_exchange_planes(self, which, sends, recvs):
+        self.drop_label_token()
         def cols(ops):
             peer = np.array([o[0] for o in ops], np.int32)
             xa = np.array([o[1] for o in ops], np.int64)

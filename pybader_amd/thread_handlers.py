@@ -6,7 +6,7 @@ thread blocks (thread_handlers.py:28-47); here the GPU library owns the decompos
 import numpy as np
 
 from . import _lib, methods, refinement
-from .utils import atom_assign, dtype_calc, ensure_density
+from .utils import atom_assign, dtype_calc, ensure_density, ensure_labels, fetch_labels, track_labels
 
 __all__ = ['bader_calc', 'refine', 'assign_to_atoms', 'surface_distance', 'dtype_calc']
 
@@ -27,14 +27,14 @@ def bader_calc(method, density, volumes, dist_mat, T_grad, threads):
     ctx = _lib.default_context()
     ctx.set_grid(density.shape, dist_mat, T_grad)
     ensure_density(ctx, density)
-    ctx.upload_labels(volumes)
+    ensure_labels(ctx, volumes)
     n = ctx.assign(method)
     bader_max = ctx.maxima()
     dtype = np.dtype(dtype_calc(-n))                                                   # lines 70-74
     if volumes.dtype == dtype and volumes.flags.c_contiguous:
-        ctx.download_labels(out=volumes)
+        fetch_labels(ctx, volumes)
     else:
-        volumes = ctx.download_labels(dtype)
+        volumes = fetch_labels(ctx, dtype=dtype)
     return bader_max, volumes
 
 
@@ -49,16 +49,20 @@ def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads):
     ctx = _lib.default_context()
     ctx.set_grid(density.shape, dist_mat, T_grad)
     ensure_density(ctx, density)
-    ctx.upload_labels(volumes)
+    ensure_labels(ctx, volumes)
     log = ctx.refine(check_mode, iters)
+    refine.last_log = log
+    if not any(changed for _, changed in log):
+        track_labels(ctx, volumes)                 # no voxel was relabelled: the host copy is still the device's
+    elif volumes.flags.c_contiguous:
+        fetch_labels(ctx, volumes)
+    else:
+        volumes.__setitem__(Ellipsis, ctx.download_labels(volumes.dtype))
     if not log:
         _say("  No edges found.")                  # lines 151-153
         return
     for k, (edges, changed) in enumerate(log):
         _say(f"  Iteration {k + 1}:\n  Refining {edges} edges: {changed} points changed.")
-    ctx.download_labels(out=volumes) if volumes.flags.c_contiguous else volumes.__setitem__(
-        Ellipsis, ctx.download_labels(volumes.dtype))
-    refine.last_log = log
 
 
 def assign_to_atoms(bader_max, atoms, lattice, volumes, threads):
@@ -68,9 +72,9 @@ def assign_to_atoms(bader_max, atoms, lattice, volumes, threads):
     ctx = _lib.default_context()
     if ctx.shape != tuple(volumes.shape):
         ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
-    ctx.upload_labels(volumes)
+    ensure_labels(ctx, volumes)
     ctx.volume_assign(bader_atoms)
-    atom_volumes = ctx.download_labels(np.dtype(dtype_calc(-atoms.shape[0])))
+    atom_volumes = fetch_labels(ctx, dtype=np.dtype(dtype_calc(-atoms.shape[0])))
     return bader_atoms, bader_distance, atom_volumes
 
 
@@ -82,7 +86,7 @@ def surface_distance(density, volumes, lattice, atoms, threads):
     if ctx.shape != tuple(volumes.shape):
         ctx.set_grid(volumes.shape, np.zeros(27), np.zeros(9))
     ensure_density(ctx, density)
-    ctx.upload_labels(volumes)
+    ensure_labels(ctx, volumes)
     d2, edges = ctx.surface_distance(lattice, atoms)
     if edges == 0:
         _say("  No edges found.")          # thread_handlers.py:256-258 (returns None)

@@ -509,3 +509,69 @@ def test_pickle_attribute_contract(profile):
         got = getattr(b, name[1:])
         assert isinstance(got, float) and want['type'] == 'float'
         assert abs(got - want['value']) <= 1e-9 * max(1.0, abs(want['value'])), (name, got, want['value'])
+
+
+def test_label_array_stays_on_the_device_inside_resident():
+    """inside `utils.resident(density)` the label array handed from bader_calc to refine to charge_sum to
+    assign_to_atoms is recognised by identity and neither uploaded nor (when nothing changed) downloaded again; it is
+    read-only while the device holds its twin; outside the block every call transfers as before.  Outputs identical."""
+    from pybader_amd import thread_handlers, utils
+    thread_handlers.VERBOSE = False
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    dm, tg = g['dist_mat'], g['T_grad']
+    atoms_cart = synth.atoms_cartesian(g['atoms'], g['lattice'])
+    ctx = _lib.default_context()
+    counts = {'up': 0, 'down': 0, 'rho': 0}
+    real_up, real_down, real_rho = ctx.upload_labels, ctx.download_labels, ctx.upload_density
+
+    def up(labels):
+        counts['up'] += 1
+        return real_up(labels)
+
+    def down(*a, **k):
+        counts['down'] += 1
+        return real_down(*a, **k)
+
+    def up_rho(r):
+        counts['rho'] += 1
+        return real_rho(r)
+    ctx.upload_labels, ctx.download_labels, ctx.upload_density = up, down, up_rho
+    try:
+        def flow():
+            vol = np.zeros(rho.shape, np.int32)
+            vol, vc, vv = utils.vacuum_assign(rho, vol, float('nan'), rho, 1.0)
+            bmax, vol = thread_handlers.bader_calc('neargrid', rho, vol, dm, tg, 1)
+            thread_handlers.refine('neargrid', ('changed', 2), rho, vol, dm, tg, 1)
+            ch, vo = np.zeros(bmax.shape[0]), np.zeros(bmax.shape[0])
+            utils.charge_sum(ch, vo, 1.0, rho, vol)
+            frac = bmax / np.array(rho.shape)
+            ba, bd, av = thread_handlers.assign_to_atoms(np.dot(frac, g['lattice']), atoms_cart, g['lattice'], vol, 1)
+            ach, avo = np.zeros(atoms_cart.shape[0]), np.zeros(atoms_cart.shape[0])
+            utils.charge_sum(ach, avo, 1.0, rho, av)
+            return vol, ch, ba, av, ach
+        bare = flow()
+        n_bare = dict(counts)
+        for k in counts:
+            counts[k] = 0
+        with utils.resident(rho):
+            inside = flow()
+            tracked = inside[3]
+            assert not tracked.flags.writeable            # the atom map is the device's twin right now
+            with pytest.raises(ValueError):
+                tracked[0, 0, 0] = 5
+        n_in = dict(counts)
+        assert tracked.flags.writeable and ctx.resident_labels is None     # released with the block
+        for a, b in zip(bare, inside):
+            assert a.dtype == b.dtype
+            if a.dtype.kind == 'f':        # segmented sums: the summation order differs from run to run
+                np.testing.assert_allclose(a, b, rtol=1e-12)
+            else:
+                assert np.array_equal(a, b)
+        assert np.array_equal(inside[0], g['ng_changed_2']) and np.array_equal(inside[3], g['ng_atoms_volumes'])
+        # bare: density 5 times (vacuum, assign, refine, 2 sums), labels up 5 / down 2 (an unchanged refinement is not fetched); inside: density once, labels never
+        # uploaded (vacuum_assign's zeros are the device's zeros), downloaded twice (the narrowed map, the atom map)
+        assert n_bare == {'up': 5, 'down': 2, 'rho': 5}, n_bare
+        assert n_in == {'up': 0, 'down': 2, 'rho': 1}, n_in
+    finally:
+        ctx.upload_labels, ctx.download_labels, ctx.upload_density = real_up, real_down, real_rho
