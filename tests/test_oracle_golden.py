@@ -112,3 +112,23 @@ def test_synth_c_equals_numpy():
     a = synth.synth_density((20, 24, 28), synth.TRICLINIC)
     b = oracle.synth_density((20, 24, 28), synth.TRICLINIC, synth.ATOMS8, synth.BACKGROUND)
     assert np.array_equal(a, b)
+
+
+def test_real_reference_class_through_the_integration_binding():
+    """VERDICT r2 missing #5: pybader.interface.Bader itself -- __call__, to_file, the pickle -- through the monkey-patch of
+    INTEGRATION.md section 1, with the CPU-oracle context standing in for the GPU one (tests/golden/check_real_class_binding.py;
+    build container only: the reference cannot travel to the GPU box).  Every slot of the pickled object must equal the
+    unpatched reference run's."""
+    import json
+    import os
+    import subprocess
+    py, ref = '/opt/conda/bin/python3.9', '/root/reference/pybader/interface.py'
+    if not (os.path.exists(py) and os.path.exists(ref)):
+        pytest.skip('needs the reference and its interpreter (build container)')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([py, '-W', 'ignore', os.path.join(here, 'golden', 'check_real_class_binding.py')], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep['problems'] == [] and rep['slots_compared']['default'] >= 30
+    assert rep['transfers_per_call']['default'] == {'upload_density': 1, 'upload_labels': 0, 'download_labels': 2}
