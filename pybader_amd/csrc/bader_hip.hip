@@ -107,6 +107,7 @@ struct xb_ctx {
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
+    int opt_mask_diag = 1;     // pass A: the three-product form of T_grad . grad on orthogonal lattices (tests compare)
     int opt_narrow_halo = 1;   // label halos travel as dtype_calc(-n_maxima) (int8 / int16) instead of int32 (comm.h)
     int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
     int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
@@ -1390,8 +1391,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                 int mirror = 0;
                 double mu_scale = 0.;
                 if (sym && c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
-                if (sym) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
-                else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
+                // (an orthogonal lattice has a diagonal T_grad: exact zeros off the diagonal)
+                const bool diag = c->opt_mask_diag && g.T[1] == 0. && g.T[2] == 0. && g.T[3] == 0. && g.T[5] == 0. && g.T[6] == 0. && g.T[7] == 0.;
+                if (sym && diag) k_brick_masks<GridS, 1, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                else if (sym) k_brick_masks<GridS, 1, false><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                else k_brick_masks<Grid, 1, false><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
             } else if (sym)
                 k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                 bmask, fs + FS_TIES);
@@ -2463,8 +2467,8 @@ int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
             int mirror = 0;
             double mu_scale = 0.;
             if (c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
-            if (sym_grid(g, gs)) k_brick_masks<GridS, 1><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, mu_scale, mirror, nullptr);
-            else k_brick_masks<Grid, 1><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, 0., 0, nullptr);
+            if (sym_grid(g, gs)) k_brick_masks<GridS, 1, false><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, mu_scale, mirror, nullptr);
+            else k_brick_masks<Grid, 1, false><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, g.x0, 0., 0, nullptr);
         }
         HIPCHK(hipGetLastError());
         int ties = 0;
@@ -2640,6 +2644,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 16) c->opt_chase = value != 0;
     else if (key == 18) c->opt_narrow_halo = value != 0;
     else if (key == 19) c->opt_self_exchange = value != 0;
+    else if (key == 20) c->opt_mask_diag = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)

@@ -29,14 +29,23 @@
 __device__ unsigned long long xb_dbg[16];
 #endif
 
-// thread -> (y, z) column of the 8 x 32 tile face.  The columns on a y- or z-face of their brick (28 of 64 per brick)
-// come first, sorted by side: wave 0 holds the low-side columns (y == 0 or z == 0) and the four mixed corners per
-// tile row, wave 1 the purely high-side ones (y == 7 or z == 7), waves 2-3 (and the last lanes of 0-1) interior
-// columns.  An interior column needs the 27-point ongrid scan on the two x-faces of the brick only, and a field
-// that points the same way across the tile leaves one of the two border waves without any face to test.
+// thread -> (y, z) column of the 8 x 32 tile face, sorted by what a column can contribute to its brick's move mask:
+//   wave 0  the low-side border columns (y == 0 or z == 0) and the four mixed corners per tile row (+ 4 second-layer ones),
+//   wave 1  the purely high-side border columns (y == 7 or z == 7) (+ 12 second-layer ones),
+//   wave 2  second-layer columns (y or z in {1, 6}, none on a face: a move of two voxels still leaves the brick from there),
+//   wave 3  the 64 DEEP columns (y and z in 2..5): no y- or z-face within reach of any move, and at x-positions 2..5 no
+//           x-face either -- there wave 3 skips the gradient altogether (only the maximum test is left).
+// A border wave needs the ongrid face test on its own faces only, and a field that points the same way across the tile
+// leaves one of the two border waves without any face to test.
 #ifndef BM_ROW
 #define BM_ROW 38   // row length of the LDS tile in doubles (34 are used): with the column order below the 9 reads per voxel
 #endif              // meet fewer bank conflicts at a stride of 38 or 39 -- worth 2 % of the kernel (0.918 -> 0.90 ms): LDS time hides behind the VALU work
+__device__ __forceinline__ void bm_second_layer(int i, int &yy, int &zz) {   // i = 0..19: the ring y, z in 1..6 with y or z in {1, 6}
+    if (i < 6) { yy = 1; zz = 1 + i; }            // y == 1, z 1..6   (i == 0 is (1,1))
+    else if (i < 12) { yy = 6; zz = i - 5; }      // y == 6, z 1..6
+    else if (i < 16) { yy = i - 10; zz = 1; }     // z == 1, y 2..5
+    else { yy = i - 14; zz = 6; }                 // z == 6, y 2..5
+}
 __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
     int bz, yy, zz;
     if (t < 60) {            // wave 0: per brick 13 low-side columns + 2 mixed corners
@@ -46,19 +55,23 @@ __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
         else if (i < 13) { yy = i - 6; zz = 0; }          // z == 0, y 1..6
         else if (i == 13) { yy = 0; zz = 7; }             // mixed corners
         else { yy = 7; zz = 0; }
-    } else if (t < 64) {     // 4 interior columns fill wave 0
-        bz = t - 60; yy = 1; zz = 1;
+    } else if (t < 64) {     // 4 second-layer columns fill wave 0
+        bz = t - 60; bm_second_layer(0, yy, zz);
     } else if (t < 116) {    // wave 1: per brick 13 high-side columns
         const int u = t - 64;
         bz = u / 13;
         const int i = u - bz * 13;
         if (i < 7) { yy = 7; zz = i + 1; }                // y == 7, z 1..7
         else { yy = i - 6; zz = 7; }                      // z == 7, y 1..6
-    } else {                 // the other 35 interior columns of each brick: 12 lanes of wave 1, waves 2-3
+    } else if (t < 128) {    // 12 second-layer columns fill wave 1
         const int u = t - 116;
-        bz = u / 35;
-        const int i = u - bz * 35 + 1;                    // 1..35 of the 6 x 6 interior, (1,1) is taken
-        yy = 1 + i / 6; zz = 1 + i % 6;
+        bz = u / 3; bm_second_layer(1 + u % 3, yy, zz);
+    } else if (t < 192) {    // wave 2: the other 16 second-layer columns of each brick
+        const int u = t - 128;
+        bz = u >> 4; bm_second_layer(4 + (u & 15), yy, zz);
+    } else {                 // wave 3: the 16 deep columns of each brick
+        const int u = t - 192;
+        bz = u >> 4; yy = 2 + ((u >> 2) & 3); zz = 2 + (u & 3);
     }
     ty = yy; tz = bz * 8 + zz;
 }
@@ -108,56 +121,73 @@ __device__ __forceinline__ void bm_mirror(const double (&a)[3][3][3], bool want_
         nhi = nhi && !(m < -mu);
     }
 }
-// One tie rule's contribution to the face-crossing booleans of a voxel at (k, ty, zz) of its brick.  MT: methods.py:324
-// (1) or refinement.py:111 (0), compile time -- with the rule in a register both variants were evaluated and blended.
-template <int MT, int K, typename GT>
-__device__ __forceinline__ void bm_cross(const GT &g, double c, double hx, double lx, double hy, double ly, double hz, double lz,
-                                         int ty, int zz, bool &xl, bool &xh, bool &yl, bool &yh, bool &zl, bool &zh) {
-    // methods.py:324-327 / refinement.py:111-130: the gradient direction before its normalisation
-    const bool f0 = MT ? (hx <= c && c >= lx) : (hx < c && c > lx);
-    const bool f1 = MT ? (hy <= c && c >= ly) : (hy < c && c > ly);
-    const bool f2 = MT ? (hz <= c && c >= lz) : (hz < c && c > lz);
-    const double g0 = f0 ? 0. : (hx - lx) / 2.;
-    const double g1 = f1 ? 0. : (hy - ly) / 2.;
-    const double g2 = f2 ? 0. : (hz - lz) / 2.;
-    const double d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
-    const double d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
-    const double d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
+// One tie rule's contribution to the face-crossing booleans of a voxel at x-position K of its column.  MT: methods.py:324
+// (1) or refinement.py:111 (0), compile time.  Round-3 diet (the pass is VALU-issue bound, ~140 of its 162 instructions per
+// voxel were here): the masks are internal -- any SUPERSET of the possible moves is sound, and the slivers of BM_EPS leave
+// 1e-12 of slack -- so nothing below has to reproduce the reference's roundings:
+//   * `m_j = max(h_j, l_j)` (shared with the maximum test) gives the axis tests of both rules: flat under methods.py:324
+//     iff m_j <= c, under refinement.py:111 iff m_j < c, and a tie iff m_j == c;
+//   * the halving of the central difference is dropped: d' = T (h - l) = 2 d exactly (scaling by two commutes with
+//     every rounding), so d' is compared against thresholds of mg' = 2 mg and `max_grad < 1E-14` reads mg' < 2E-14;
+//   * DIAG: T_grad is diagonal (an orthogonal lattice): d'_j = T_jj e_j, three products instead of nine and six sums
+//     (the off-diagonal terms are exact zeros in the reference's sum);
+//   * the two-threshold test per face is ONE product and ONE comparison against mg' * coef, coef a per-lane constant of
+//     the column: +EPS on the face (offset -1 reachable when d < tiny), -(1 - EPS) one voxel in (offset -2 when d <
+//     -nearm), -inf elsewhere (no move reaches the face); mirrored for the high face.
+struct BmCoef { double yl, yh, zl, zh; };
+template <int MT, int K, bool DIAG, typename GT>
+__device__ __forceinline__ void bm_cross(const GT &g, double c, double ex, double ey, double ez, double mx, double my, double mz,
+                                         const BmCoef &co, bool &xl, bool &xh, bool &yl, bool &yh, bool &zl, bool &zh) {
+    const bool f0 = MT ? (mx <= c) : (mx < c), f1 = MT ? (my <= c) : (my < c), f2 = MT ? (mz <= c) : (mz < c);
+    const double g0 = f0 ? 0. : ex, g1 = f1 ? 0. : ey, g2 = f2 ? 0. : ez;
+    double d0, d1, d2;
+    if (DIAG) {
+        d0 = g.T[0] * g0; d1 = g.T[4] * g1; d2 = g.T[8] * g2;
+    } else {
+        d0 = ((g.T[0] * g0) + (g.T[1] * g1)) + (g.T[2] * g2);
+        d1 = ((g.T[3] * g0) + (g.T[4] * g1)) + (g.T[5] * g2);
+        d2 = ((g.T[6] * g0) + (g.T[7] * g1)) + (g.T[8] * g2);
+    }
     const double mg = fmax(fmax(fabs(d0), fabs(d1)), fabs(d2));
-    const bool moves = !(mg < 1E-14);   // max_grad < 1E-14: the ongrid step only
-    const double tiny = mg * BM_EPS, nearm = mg * (1. - BM_EPS);
-    if (K == 0) xl |= moves && d0 < tiny;
-    if (K <= 1) xl |= moves && d0 < -nearm;
-    if (K == GT_X - 1) xh |= moves && d0 > -tiny;
-    if (K >= GT_X - 2) xh |= moves && d0 > nearm;
-    yl |= moves && ((ty == 0 && d1 < tiny) || (ty <= 1 && d1 < -nearm));
-    yh |= moves && ((ty == 7 && d1 > -tiny) || (ty >= 6 && d1 > nearm));
-    zl |= moves && ((zz == 0 && d2 < tiny) || (zz <= 1 && d2 < -nearm));
-    zh |= moves && ((zz == 7 && d2 > -tiny) || (zz >= 6 && d2 > nearm));
+    const bool moves = !(mg < 2E-14);   // max_grad < 1E-14 (d is doubled here): the ongrid step only
+    if (K == 0) xl |= moves && d0 < mg * BM_EPS;
+    if (K == 1) xl |= moves && d0 < mg * -(1. - BM_EPS);
+    if (K == GT_X - 1) xh |= moves && d0 > mg * -BM_EPS;
+    if (K == GT_X - 2) xh |= moves && d0 > mg * (1. - BM_EPS);
+    yl |= moves && d1 < mg * co.yl;
+    yh |= moves && d1 > mg * co.yh;
+    zl |= moves && d2 < mg * co.zl;
+    zh |= moves && d2 > mg * co.zh;
 }
 
 // one x-position K of the column: everything below the window update
-template <int MT, int K, typename GT>
+template <int MT, int K, bool DIAG, typename GT>
 __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3], double dface, bool in, int v, int ty, int zz,
-                                         int &mine, bool &any_tie, int *s_cnt, int *s_mv, double mu, int mirror) {
+                                         int &mine, bool &any_tie, int *s_cnt, int *s_mv, double mu, int mirror, const BmCoef &co,
+                                         bool deep) {
     const double c = a[1][1][1];
     const double hx = a[2][1][1], lx = a[0][1][1], hy = a[1][2][1], ly = a[1][0][1], hz = a[1][1][2], lz = a[1][1][0];
-    const bool tie = axis_tie(hx, c, lx) || axis_tie(hy, c, ly) || axis_tie(hz, c, lz);
+    const double mx = max_raw(hx, lx), my = max_raw(hy, ly), mz = max_raw(hz, lz);
+    // an axis tie (the two rules disagree on this voxel: methods.py:324 zeroes the axis, refinement.py:111 does not)
+    const bool tie = mx == c || my == c || mz == c;
     any_tie |= in && tie;
     // can a move of this voxel leave its brick through the low / high face of each axis?  A move reaches offset
     // -1 when d < tiny and -2 when d < -nearm (mirrored upwards), so at position p of 0..7 the low face is crossed
     // iff (p == 0 and d < tiny) or (p <= 1 and d < -nearm).  Booleans throughout: they stay lane masks.
     bool xl = false, xh = false, yl = false, yh = false, zl = false, zh = false;
-    bm_cross<MT, K>(g, c, hx, lx, hy, ly, hz, lz, ty, zz, xl, xh, yl, yh, zl, zh);
-    // a voxel with a tie axis has TWO gradient directions (methods.py:324 zeroes the axis, refinement.py:111 does
-    // not): it gets the union, so that a trapping region is closed for the assignment's walkers AND for the
-    // refinement's retraces (k_refine_trace stops a retrace that enters a region)
-    if (__any(tie)) bm_cross<!MT, K>(g, c, hx, lx, hy, ly, hz, lz, ty, zz, xl, xh, yl, yh, zl, zh);
+    // (a deep column at x-positions 2..5 has no face within reach of any move: `deep` is wave uniform)
+    if (!(deep && K >= 2 && K <= GT_X - 3)) {
+        const double ex = hx - lx, ey = hy - ly, ez = hz - lz;
+        bm_cross<MT, K, DIAG>(g, c, ex, ey, ez, mx, my, mz, co, xl, xh, yl, yh, zl, zh);
+        // a voxel with a tie axis gets the union of both rules, so that a trapping region is closed for the assignment's
+        // walkers AND for the refinement's retraces (k_refine_trace stops a retrace that enters a region)
+        if (__any(tie)) bm_cross<!MT, K, DIAG>(g, c, ex, ey, ez, mx, my, mz, co, xl, xh, yl, yh, zl, zh);
+    }
     // Does this voxel need its exact ongrid successor?  (a) it lies on a face of its brick that its gradient
     // interval does not cross already (an ongrid move is one voxel long: only face voxels can leave the brick
     // by it); (b) it may be a 26-neighbour maximum: not ruled out by a face neighbour whose weighted value
     // (bounded from below with the smallest face distance; fl(.) is monotone) exceeds c.
-    const double r6 = max_raw(max_raw(max_raw(hx, lx), max_raw(hy, ly)), max_raw(hz, lz));
+    const double r6 = max_raw(max_raw(mx, my), mz);
     double wq = (r6 - c) * dface;
     wq += c;
     const bool not_max = wq > c;
@@ -251,7 +281,7 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
     }
 }
 
-template <typename GT, int MT>
+template <typename GT, int MT, bool DIAG>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
                                                      int *__restrict__ bmaxv, int *tie_count, int xbase, double mu_scale, int mirror,
                                                      int *__restrict__ bpot) {
@@ -303,6 +333,13 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     int ty, tz;
     bm_column(threadIdx.x, ty, tz);
     const int zz = tz & 7;
+    const bool deep = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE) == 3;   // wave 3 holds the deep columns (bm_column)
+    const double kInf = __builtin_huge_val();
+    BmCoef co;   // per-lane threshold coefficients of the y / z faces (bm_cross)
+    co.yl = ty == 0 ? BM_EPS : (ty == 1 ? -(1. - BM_EPS) : -kInf);
+    co.yh = ty == 7 ? -BM_EPS : (ty == 6 ? (1. - BM_EPS) : kInf);
+    co.zl = zz == 0 ? BM_EPS : (zz == 1 ? -(1. - BM_EPS) : -kInf);
+    co.zh = zz == 7 ? -BM_EPS : (zz == 6 ? (1. - BM_EPS) : kInf);
     const int y = y0 + ty, z = z0 + tz;
     const bool col_in = y < g.ny && z < g.nz;
     // the smallest of the six face distances: a lower bound of any face neighbour's weighted value (maximum test)
@@ -329,8 +366,8 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
         }                                                                                                            \
         const int x = x0 + K;                                                                                        \
         cmax = max_raw(cmax, a[1][1][1]);                                                                            \
-        bm_voxel<MT, K>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie,           \
-                        &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror);                                                \
+        bm_voxel<MT, K, DIAG>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie,     \
+                              &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror, co, deep);                                \
     }
     BM_STEP(0) BM_STEP(1) BM_STEP(2) BM_STEP(3) BM_STEP(4) BM_STEP(5) BM_STEP(6) BM_STEP(7)
 #undef BM_STEP

@@ -297,9 +297,10 @@ def test_mirror_prefilter_and_lean_walker_do_not_change_the_map(shape, lattice, 
         rho = np.ascontiguousarray(rho + noise * np.random.default_rng(3).random(shape))
         ctx.upload_density(rho)
     res = []
-    for mirror, lean in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    for mirror, lean, diag in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)):
         ctx.set_option(13, mirror)
         ctx.set_option(14, lean)
+        ctx.set_option(20, diag)      # the three-product T_grad . grad of orthogonal lattices (exact zeros off the diagonal)
         ctx.set_option(6, 1)
         ctx.vacuum_assign(None, 1.0)
         n = ctx.assign('neargrid')
@@ -313,4 +314,5 @@ def test_mirror_prefilter_and_lean_walker_do_not_change_the_map(shape, lattice, 
     # the prefilter decides a subset of the faces the exact test leaves closed: never fewer certified bricks with it
     assert res[0][5][1] >= res[1][5][1] and res[2][5][1] >= res[3][5][1]
     assert res[0][5] == res[2][5] and res[1][5] == res[3][5]          # the walker does not touch the regions
+    assert res[0][5] == res[4][5]                                     # nor does the diagonal form of T_grad . grad
     print('certified voxels with / without the mirror prefilter:', res[0][5][1], res[1][5][1])
