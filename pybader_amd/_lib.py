@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libbader_hip.so')
+LIB_PATH = os.environ.get('XB_LIBRARY') or os.path.join(HERE, 'libbader_hip.so')   # (XB_LIBRARY: A/B runs of two builds)
 
 METHODS = {'ongrid': 0, 'neargrid': 1}          # methods.__contains__ (methods.py:12)
 REFINE_MODES = {'all': 0, 'changed': 1}         # refine_mode[0] (thread_handlers.py:201-205)
