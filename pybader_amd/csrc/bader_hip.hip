@@ -107,6 +107,7 @@ struct xb_ctx {
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
+    int opt_trace_cache = 1;   // group trace: the own brick's records in LDS (k_ng_trace_g, LEAN 3 / 4)
     int opt_mask_diag = 1;     // pass A: the three-product form of T_grad . grad on orthogonal lattices (tests compare)
     int opt_narrow_halo = 1;   // label halos travel as dtype_calc(-n_maxima) (int8 / int16) instead of int32 (comm.h)
     int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
@@ -1479,6 +1480,10 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                       maxsteps, c->has_vacuum ? 1 : 0
             if (gw > 1) {
                 const int groups = std::max(1, c->opt_trace_grid / gw), ch = std::max(8, c->opt_trace_chunk);
+                if (lean && gw == 8 && ch == 8 && c->opt_trace_cache) {   // one brick per pull: its records go through LDS
+                    if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                    else k_ng_trace_g<2, 3><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                } else
                 if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
                 else if (lean == 1) k_ng_trace_g<2, 1><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
                 else k_ng_trace_g<2, 0><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
@@ -2645,6 +2650,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 18) c->opt_narrow_halo = value != 0;
     else if (key == 19) c->opt_self_exchange = value != 0;
     else if (key == 20) c->opt_mask_diag = value != 0;
+    else if (key == 21) c->opt_trace_cache = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)

@@ -321,15 +321,20 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
     if (OFF32) return *reinterpret_cast<const GradRec *>(reinterpret_cast<const char *>(G) + ((unsigned)l << 5));
     return fetch_rec(G, l);
 }
-template <bool OFF32>
+// CACHE: the 512 records of the walkers' OWN brick sit in LDS (s_rec, loaded by the workgroup before its eight waves start:
+// k_ng_trace_g) -- the start record and every step that stays inside the brick (about 40 % of the fetches) read them there,
+// and the own brick, a walk-list brick, needs no brick-label lookup either.  The trace is bound by its L2 requests.
+template <bool OFF32, bool CACHE>
 __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
                                              int *labels, int *first, int *max_list, int *max_count, int max_cap,
-                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum) {
+                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum,
+                                             const GradRec *s_rec = nullptr) {
     // every start voxel is valid: the walk list holds whole bricks of a grid made of whole bricks
     const int v = lin24(g, sx, sy, sz);
     const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
-    GradRec rec = fetch_rec_o<OFF32>(G, v);
+    const int ox8 = sx & ~7, oy8 = sy & ~7, oz8 = sz & ~7;   // origin of the own brick
+    GradRec rec = CACHE ? s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, v);
     bool moving = lab0 != -1;
     int result = -1;
     int px = sx, py = sy, pz = sz, steps = 0;
@@ -368,9 +373,14 @@ __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__re
                 }
             }
             // both loads in flight together; a lane at its maximum reloads its own record (harmless)
-            rec = fetch_rec_o<OFF32>(G, lq);
-            const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
-            const int bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
+            int bl = 0;
+            const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
+            if (own) rec = s_rec[((px & 7) << 6) | ((py & 7) << 3) | (pz & 7)];
+            else {
+                rec = fetch_rec_o<OFF32>(G, lq);
+                const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
+                bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
+            }
             steps++;
             // arrived inside a trapping region (q cannot be an old path voxel: the trajectory would have stopped there
             // already); membership undecidable from the window: exact slow kernel (ongrid moves are appended without a
@@ -499,8 +509,8 @@ __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *
                 int sx, sy, sz;
                 brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
                 if (LEAN)
-                    ng_walk_lean<LEAN == 2>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX], max_cap, ovf_list,
-                                 &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
+                    ng_walk_lean<LEAN == 2, false>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX], max_cap, ovf_list,
+                                                   &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
                 else
                     ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                            max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
@@ -515,6 +525,8 @@ __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *
 // loads meet in that unit's L1 (hit, or merged with the miss in flight) instead of each occupying a miss slot of a
 // different unit.  The trace is bound by exactly that: L2 requests x L2 latency / misses in flight per compute unit
 // (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
+// LEAN 3 / 4 (= 1 / 2 with the brick cache): the workgroup is exactly eight waves, a pull is exactly one brick, and its 512
+// records are copied into LDS (16 KB) before the waves start (see ng_walk_lean).
 template <int K, int LEAN>
 __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                        const int *__restrict__ blab, int nb1, int nb2,
@@ -522,6 +534,8 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                                                        int *max_list, int max_cap, int *ovf_list, int ovf_cap, int maxsteps,
                                                        int has_vacuum, int CH, int xcd_split) {
     __shared__ int s_base, s_next;
+    constexpr bool CACHE = LEAN >= 3;
+    __shared__ GradRec s_rec[CACHE ? 512 : 1];
     const int n_items = fs[FS_N_WALK] * 8;
     const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
     const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
@@ -539,6 +553,13 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
             const int base = s_base;
             if (base >= end) break;   // uniform over the workgroup
             const int stop = min(base + CH, end);
+            if (CACHE) {   // (CH == 8, base a multiple of 8: one brick) thread t copies the record of voxel t of the brick
+                const int b = walk[base >> 3];
+                const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+                const int t = threadIdx.x;
+                s_rec[t] = fetch_rec(G, lin24(g, b0 * 8 + (t >> 6), b1 * 8 + ((t >> 3) & 7), b2 * 8 + (t & 7)));
+                __syncthreads();
+            }
             for (;;) {
                 int i = 0;
                 if (lane == 0) i = atomicAdd(&s_next, 1);
@@ -547,8 +568,8 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 int sx, sy, sz;
                 brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
                 if (LEAN)
-                    ng_walk_lean<LEAN == 2>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX], max_cap, ovf_list,
-                                            &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
+                    ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0, s_rec);
                 else
                     ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                            max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
