@@ -461,6 +461,8 @@ def main():
         out['dropin_many_atoms'] = dropin_leg(ctx)
 
     out['config']['map_check'] = {'voxels_labelled': int(sum(vols)), 'smallest_basin': int(min(vols)) if vols else 0, 'largest_basin': int(max(vols)) if vols else 0}
+    mem = ctx.memory_stats()
+    out['config']['device_bytes_per_rank'] = {'total': mem[0], 'table': mem[1], 'scratch': mem[2], 'per_voxel_of_the_grid': mem[0] / nvox}
     out['config']['slow_path_trajectories(assign,refine)'] = list(ctx.slow_path_stats())
     out['config']['retraces_redone_from_rho'] = ctx.deferred_stats()
     out['config']['retrace_passes_with_walkers'] = runner.n_fallbacks   # passes in which some retrace left a slab's valid planes (0 on one GPU)

@@ -208,11 +208,16 @@ int xb_enable_timing(xb_ctx *c, int on);
 /* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order;
  * key 1: trapping boxes bit0 / brick growth bit1; key 2: trace threads per block; key 3: debug prints;
  * key 13-18: round-3 switches, each an exactness cross-check in the tests (13 mirror prefilter of pass A, 14 lean walker,
- * 15 waves per trace workgroup, 16 chase growth, 17 kill launches scheduled after a chase, 18 narrowed label halos);
+ * 15 waves per trace workgroup, 16 chase growth, 17 kill launches scheduled after a chase, 18 narrowed label halos,
+ * 19 self exchange (tests), 20 diagonal T_grad form, 21 brick cache of the trace, 22 slab-sized table / scratch (before xb_set_grid));
  * key 4: workgroups of the edge_check chase; key 5: its LDS queue capacity, lowered in tests to force
  * the overflow hand-over; key 6: drop the cached gradient-field table, so that the next refinement
  * rebuilds it -- bench.py does this every step: a table kept from an earlier step would hide 1.6 ms) */
 int xb_set_option(xb_ctx *c, int key, int value);
+/* device bytes held for the grid (density, labels, flags, numbering + the table of the window planes + scratch sized by the
+ * slab): what a rank of the slab decomposition costs; the reference's blocks are copies of the block extent
+ * (thread_handlers.py:31-47, utils.py:424-458) */
+int xb_memory_stats(xb_ctx *c, int64_t *bytes_total, int64_t *bytes_table, int64_t *bytes_scratch);
 /* statistics of the last assignment: trapping boxes found and voxels they cover */
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);
 /* trajectories / retraces handed to the exact slow kernel since the context was created */

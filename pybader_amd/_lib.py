@@ -88,6 +88,7 @@ SYMBOLS = {
     'xb_comm_allgather_i64': (_int, [_vp, _pi64, C.c_int64, _pi64]),
     'xb_comm_share_brick_masks': (_int, [_vp, _pi64, _pi64]),
     'xb_comm_stats': (_int, [_vp, _pi64]),
+    'xb_memory_stats': (_int, [_vp, _pi64, _pi64, _pi64]),
 }
 
 _lib = None
@@ -479,6 +480,12 @@ class Context:
     def comm_share_brick_masks(self, first, count):
         f, n = np.array(first, np.int64), np.array(count, np.int64)
         check(self.lib.xb_comm_share_brick_masks(self.h, f.ctypes.data_as(_pi64), n.ctypes.data_as(_pi64)))
+
+    def memory_stats(self):
+        """(total, table, scratch) device bytes this context holds for the grid"""
+        a, b, d = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.xb_memory_stats(self.h, C.byref(a), C.byref(b), C.byref(d)))
+        return int(a.value), int(b.value), int(d.value)
 
     def comm_bytes_sent(self):
         n = C.c_int64(0)

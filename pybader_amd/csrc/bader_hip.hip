@@ -61,7 +61,11 @@ struct xb_ctx {
     long long N = 0;
     int halo = 0;
     double *rho = nullptr;
-    GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel
+    GradRec *grad = nullptr;   // gradient-field table, 32 B per voxel of the table window (the whole grid on one GPU)
+    long long grad_cap = 0;    // records allocated
+    long long list_cap = 0;    // ints allocated for `list` (N on one GPU; the slab's planes + scratch on a slab)
+    int *ec_buf = nullptr;     // edge_check's two seed / overflow lists when `stage` is too small for them (slabs)
+    long long ec_buf_cap = 0;
     double *dist_dev = nullptr; // dist_mat on the device
     int *boxbuf = nullptr;      // seeds / box tables of the table build (BB_* layout)
     int *box_max_tab = nullptr; // region id - 1 -> voxel of the region's maximum (inside boxbuf: BB_BOXMAX or BB_REGMAX)
@@ -107,6 +111,7 @@ struct xb_ctx {
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
+    int opt_lean_mem = 1;      // slabs: table, `list` and `stage` sized by the slab instead of the grid (0: everything full size)
     int opt_trace_cache = 1;   // group trace: the own brick's records in LDS (k_ng_trace_g, LEAN 3 / 4)
     int opt_mask_diag = 1;     // pass A: the three-product form of T_grad . grad on orthogonal lattices (tests compare)
     int opt_narrow_halo = 1;   // label halos travel as dtype_calc(-n_maxima) (int8 / int16) instead of int32 (comm.h)
@@ -165,7 +170,7 @@ static GridL light(const Grid &g) {
     GridL l;
     l.nx = g.nx; l.ny = g.ny; l.nz = g.nz; l.nyz = g.nyz;
     l.x0 = g.x0; l.x1 = g.x1; l.vx0 = g.vx0; l.vlen = g.vlen;
-    l.wx0 = g.wx0; l.wlen = g.wlen;
+    l.wx0 = g.wx0; l.wlen = g.wlen; l.wbase = g.wbase; l.ntot = g.ntot;
     l.use24 = ((long long)g.nx * g.ny < (1 << 24)) && g.nz < (1 << 24);
     l.main_ties = g.main_ties;
     return l;
@@ -185,7 +190,7 @@ struct DevBuf {
 // the 14-distance form of the grid for the tiled field kernels; false when dist_mat is not symmetric
 static bool sym_grid(const Grid &g, GridS &s) {
     s.nx = g.nx; s.ny = g.ny; s.nz = g.nz; s.nyz = g.nyz;
-    s.x0 = g.x0; s.x1 = g.x1; s.vx0 = g.vx0; s.vlen = g.vlen; s.wx0 = g.wx0; s.wlen = g.wlen;
+    s.x0 = g.x0; s.x1 = g.x1; s.vx0 = g.vx0; s.vlen = g.vlen; s.wx0 = g.wx0; s.wlen = g.wlen; s.wbase = g.wbase; s.ntot = g.ntot;
     s.main_ties = g.main_ties;
     for (int k = 0; k < 9; k++) s.T[k] = g.T[k];
     auto at = [&](int idx) {
@@ -282,6 +287,7 @@ static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
     hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->labels_zero_pending = false;
+    hipFree(c->ec_buf); c->ec_buf = nullptr; c->ec_buf_cap = 0; c->grad_cap = 0; c->list_cap = 0;
     c->brick_rec = nullptr; c->grad_cover = 0;
     c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
@@ -313,6 +319,47 @@ int xb_sync(xb_ctx *c) {
 }
 void *xb_stream(xb_ctx *c) { return (void *)c->stream; }
 
+// `list` and `stage` hold lists over the planes a rank works on (edges, tiles, walkers, dtype staging) and a few
+// per-brick arrays: the whole grid's worth on one GPU, the slab + halo (+ tile rounding) on a slab.  Grown on demand,
+// never shrunk while the grid stays; contents are scratch between calls EXCEPT the walk list (set up after this).
+static int need_scratch(xb_ctx *c) {
+    const Grid &g = c->g;
+    const long long N = c->N ? c->N : (long long)g.nx * g.nyz;
+    const int own = g.x1 - g.x0;
+    long long planes = own + 2LL * (std::max(c->halo, 16) + 16);
+    if (own == g.nx || planes >= g.nx || !c->opt_lean_mem) planes = g.nx;
+    const long long list_want = planes == g.nx ? N : std::max<long long>(planes * g.nyz, 8 * (N / 512) + 4096);
+    const size_t stage_want = planes == g.nx ? (size_t)N * 8 : std::max<size_t>((size_t)planes * g.nyz * 8, (size_t)64 << 20);
+    if (c->list_cap < list_want) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->list); c->list = nullptr; c->list_cap = 0;
+        HIPCHK(hipMalloc(&c->list, (size_t)list_want * sizeof(int)));
+        c->list_cap = list_want;
+        c->list_valid = false; c->walk = nullptr; c->n_walk = 0;
+    }
+    if (c->stage_bytes < stage_want) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0;
+        HIPCHK(hipMalloc(&c->stage, stage_want));
+        c->stage_bytes = stage_want;
+    }
+    return XB_OK;
+}
+// the table: one record per voxel of the window planes (xb_set_table_window), allocated when a build first needs it
+static int need_grad(xb_ctx *c) {
+    Grid &g = c->g;
+    const long long want = (long long)g.wlen * g.nyz;
+    g.wbase = g.wlen < g.nx ? g.wx0 * g.nyz : 0;
+    g.ntot = (int)c->N;
+    if (c->grad_cap < want || c->grad_cap > 2 * want) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->grad); c->grad = nullptr; c->grad_cap = 0; c->grad_valid = false;
+        HIPCHK(hipMalloc(&c->grad, (size_t)want * sizeof(GradRec)));
+        c->grad_cap = want;
+    }
+    return XB_OK;
+}
+
 static void set_valid_range(xb_ctx *c) {
     Grid &g = c->g;
     const int own = g.x1 - g.x0;
@@ -337,14 +384,12 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     if (N != c->n_alloc) {
         free_grid(c);
         HIPCHK(hipMalloc(&c->rho, N * sizeof(double)));
-        HIPCHK(hipMalloc(&c->grad, N * sizeof(GradRec)));
+        // (the table -- 32 B per voxel of its window -- and the two scratch arrays are sized by what this rank works on:
+        // need_grad / need_scratch, below and on xb_set_halo / xb_set_table_window)
         HIPCHK(hipMalloc(&c->labels, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->known, N + 16));  // slack: edge_check reads the 3 z-neighbours as one 32-bit word
         HIPCHK(hipMalloc(&c->first, N * sizeof(int)));
-        HIPCHK(hipMalloc(&c->list, N * sizeof(int)));
         HIPCHK(hipMalloc(&c->st, N));
-        c->stage_bytes = (size_t)N * 8;
-        HIPCHK(hipMalloc(&c->stage, c->stage_bytes));
         c->max_cap = (int)std::min<long long>(N, 1 << 22);
         HIPCHK(hipMalloc(&c->max_list, c->max_cap * sizeof(int)));
         HIPCHK(hipMalloc(&c->max_aux, c->max_cap * sizeof(int)));
@@ -372,7 +417,9 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     c->halo = (x0 == 0 && x1 == shape[0]) ? g.nx : 0;
     set_valid_range(c);
     g.wx0 = 0; g.wlen = g.nx;      // table window: whole grid unless xb_set_table_window says otherwise
+    g.wbase = 0; g.ntot = (int)N;
     c->table_margin = -1;
+    if (int rc = need_scratch(c)) return rc;
     c->table_stage = 0;
     c->has_grid = true;
     c->maxima_sorted.clear();
@@ -394,7 +441,7 @@ int xb_set_halo(xb_ctx *c, int64_t halo) {
     c->zero_outside[0] = -1;
     c->halo = (int)halo;
     set_valid_range(c);
-    return XB_OK;
+    return need_scratch(c);
 }
 
 // volumes_init without vacuum owes `labels := 0` (xb_vacuum_assign defers the 4 B/voxel memset because the
@@ -622,11 +669,16 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     if (dtype == XB_I32) {
         if (int rc = staged_h2d(c, c->labels, labels_host, c->N * 4)) return rc;
     } else {
-        if (int rc = staged_h2d(c, c->stage, labels_host, c->N * sz)) return rc;
-        if (dtype == XB_I8) k_widen<int8_t><<<nblocks(c->N), TPB, 0, c->stream>>>((const int8_t *)c->stage, c->labels, c->N);
-        else if (dtype == XB_I16) k_widen<int16_t><<<nblocks(c->N), TPB, 0, c->stream>>>((const int16_t *)c->stage, c->labels, c->N);
-        else k_widen<long long><<<nblocks(c->N), TPB, 0, c->stream>>>((const long long *)c->stage, c->labels, c->N);
-        HIPCHK(hipGetLastError());
+        // through `stage`, a chunk at a time when it is smaller than the grid (slabs)
+        const long long per = std::max<long long>(1, (long long)(c->stage_bytes / sz));
+        for (long long o = 0; o < c->N; o += per) {
+            const long long n = std::min(per, c->N - o);
+            if (int rc = staged_h2d(c, c->stage, (const char *)labels_host + (size_t)o * sz, (size_t)n * sz)) return rc;
+            if (dtype == XB_I8) k_widen<int8_t><<<nblocks(n), TPB, 0, c->stream>>>((const int8_t *)c->stage, c->labels + o, n);
+            else if (dtype == XB_I16) k_widen<int16_t><<<nblocks(n), TPB, 0, c->stream>>>((const int16_t *)c->stage, c->labels + o, n);
+            else k_widen<long long><<<nblocks(n), TPB, 0, c->stream>>>((const long long *)c->stage, c->labels + o, n);
+            HIPCHK(hipGetLastError());
+        }
     }
     // vacuum voxels present?  (the reference's callers hand bader_calc the volumes_init map: -1 only with a vacuum_tol)
     HIPCHK(hipMemsetAsync(c->counters + 14, 0, sizeof(int), c->stream));
@@ -644,11 +696,15 @@ int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {
     if (dtype == XB_I32) {
         if (int rc = staged_d2h(c, labels_host, c->labels, c->N * 4)) return rc;
     } else {
-        if (dtype == XB_I8) k_narrow<int8_t><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (int8_t *)c->stage, c->N);
-        else if (dtype == XB_I16) k_narrow<int16_t><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (int16_t *)c->stage, c->N);
-        else k_narrow<long long><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (long long *)c->stage, c->N);
-        HIPCHK(hipGetLastError());
-        if (int rc = staged_d2h(c, labels_host, c->stage, c->N * sz)) return rc;
+        const long long per = std::max<long long>(1, (long long)(c->stage_bytes / sz));
+        for (long long o = 0; o < c->N; o += per) {
+            const long long n = std::min(per, c->N - o);
+            if (dtype == XB_I8) k_narrow<int8_t><<<nblocks(n), TPB, 0, c->stream>>>(c->labels + o, (int8_t *)c->stage, n);
+            else if (dtype == XB_I16) k_narrow<int16_t><<<nblocks(n), TPB, 0, c->stream>>>(c->labels + o, (int16_t *)c->stage, n);
+            else k_narrow<long long><<<nblocks(n), TPB, 0, c->stream>>>(c->labels + o, (long long *)c->stage, n);
+            HIPCHK(hipGetLastError());
+            if (int rc = staged_d2h(c, (char *)labels_host + (size_t)o * sz, c->stage, (size_t)n * sz)) return rc;   // (waits: `stage` is free again)
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;
@@ -736,6 +792,7 @@ static int ensure_brick_bytes(xb_ctx *c, int nbr) {
 // main_rule: records under the assignment's tie test (methods.py:324) instead of the refinement's
 // (refinement.py:111); a table built for one rule serves the other when no voxel of the density has such a tie.
 static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
+    if (int rc = need_grad(c)) return rc;
     c->g.main_ties = main_rule ? 1 : 0;   // the trace / slow kernels of this phase follow the same rule
     if (c->grad_valid && !force && (c->grad_rule == 2 || c->grad_rule == (main_rule ? 1 : 0))) return XB_OK;
     const Grid &g = c->g;
@@ -1042,6 +1099,7 @@ static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int 
 
 int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     NEED_GRID_RAW("xb_assign_trace");
+    if (int rc = need_grad(c)) return rc;
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     // a deferred labels := 0 is dropped when this call writes every owned label without reading any: a neargrid assignment
@@ -1350,6 +1408,7 @@ static bool fused_ok(const xb_ctx *c) {
 static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
 
 static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
+    if (int rc = need_grad(c)) return rc;
     Grid &g = c->g;
     const GridL gl0 = light(g);
     const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
@@ -2037,8 +2096,19 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
         // chased asynchronously by a small grid of workgroups; queue overflows seed another launch.  Scratch: two
         // seed / overflow lists of N ints in the staging buffer, 16 bits per voxel for the counters (only
         // 'changed' refinement needs them).
-        const int cap = (int)std::min<long long>(c->N, 1LL << 30);
+        // (the seed / overflow lists: in `stage` when it is grid sized, else in a buffer of their own -- at most every listed
+        // voxel is queued at once)
+        int cap = (int)std::min<long long>(c->N, 1LL << 30);
         int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
+        if (c->stage_bytes < 8 * (size_t)c->N) {
+            cap = (int)std::min<long long>(c->N, std::max<long long>(2LL * n + 65536, 1 << 20));
+            if (c->ec_buf_cap < 2LL * cap) {
+                hipFree(c->ec_buf); c->ec_buf = nullptr; c->ec_buf_cap = 0;
+                HIPCHK(hipMalloc(&c->ec_buf, 2 * (size_t)cap * sizeof(int)));
+                c->ec_buf_cap = 2LL * cap;
+            }
+            buf[0] = c->ec_buf; buf[1] = c->ec_buf + cap;
+        }
         if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 8 * (size_t)c->N + 16));
         ec_word *pend_w = c->ec_pend;
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
@@ -2071,7 +2141,7 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
     }
     if (near_np < g.nx) k_ec_keep_near<<<nblocks(n), TPB, 0, c->stream>>>(g, c->list, n, c->st, near_xa, near_np);
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
-    const int new_cap = (int)std::min<long long>(c->N - n, 1LL << 30);   // the rest of `list` behind the compacted edges
+    const int new_cap = (int)std::min<long long>(c->list_cap - n, 1LL << 30);   // the rest of `list` behind the compacted edges
     HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
     k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1,
                                                   c->list + n, c->counters + 7, new_cap);
@@ -2161,7 +2231,7 @@ int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64
         if (len > run1) HIPCHK(hipMemsetAsync(c->known, 2, (size_t)(len - run1) * g.nyz, c->stream));
     }
     int8_t *dcls = c->st + (c->N - n);   // the tail of `st` (its head receives the decisions of k_ec_collect)
-    if (2 * n > c->N) return fail(XB_E_LIMIT, "xb_edge_check_global: list longer than half the grid");
+    if (2 * n > c->N || 2 * n > c->list_cap) return fail(XB_E_LIMIT, "xb_edge_check_global: list longer than half the grid / the list buffer");
     if (int rc = upload_pinned(c, c->list, i32.data(), n * sizeof(int))) return rc;
     if (int rc = upload_pinned(c, dcls, cls, n, (n * sizeof(int) + 255) & ~(size_t)255)) return rc;
     k_scatter_byte<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->known, c->list, (int)n, (int8_t)-2);
@@ -2436,15 +2506,15 @@ int xb_set_table_window(xb_ctx *c, int64_t margin) {
     c->grad_valid = false;
     c->table_stage = 0;
     const int own = g.x1 - g.x0;
-    if (margin < 0 || own == g.nx) { g.wx0 = 0; g.wlen = g.nx; c->table_margin = -1; return XB_OK; }
+    if (margin < 0 || own == g.nx) { g.wx0 = 0; g.wlen = g.nx; c->table_margin = -1; g.wbase = 0; return XB_OK; }
     if (g.nx % 8 || g.ny % 8 || g.nz % 8 || g.x0 % 8 || g.x1 % 8)
         return fail(XB_E_ARG, "xb_set_table_window: grid and slab must be made of whole 8^3 bricks");
     const int m8 = (int)((std::max<int64_t>(margin, c->halo) + 7) / 8) * 8;
-    if (own + 2 * m8 >= g.nx) { g.wx0 = 0; g.wlen = g.nx; c->table_margin = -1; return XB_OK; }
+    if (own + 2 * m8 >= g.nx) { g.wx0 = 0; g.wlen = g.nx; c->table_margin = -1; g.wbase = 0; return XB_OK; }
     g.wx0 = ((g.x0 - m8) % g.nx + g.nx) % g.nx;
     g.wlen = own + 2 * m8;
     c->table_margin = m8;
-    return XB_OK;
+    return need_grad(c);     // the table shrinks to the window: 32 B per voxel of slab + margins instead of the grid
 }
 static bool slab_sparse_ok(const xb_ctx *c) {
     const Grid &g = c->g;
@@ -2453,6 +2523,7 @@ static bool slab_sparse_ok(const xb_ctx *c) {
 }
 int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
     NEED_GRID_RAW("xb_table_build");   // (no label is read here: a deferred labels := 0 stays deferred)
+    if (int rc = need_grad(c)) return rc;
     c->slab_sparse = false;
     if (slab_sparse_ok(c)) {
         // pass A over the OWN planes: move masks, maxima count and the single maximum of every own brick (k_brick_masks);
@@ -2651,6 +2722,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 19) c->opt_self_exchange = value != 0;
     else if (key == 20) c->opt_mask_diag = value != 0;
     else if (key == 21) c->opt_trace_cache = value != 0;
+    else if (key == 22) c->opt_lean_mem = value != 0;   // (before xb_set_grid)
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)
@@ -2666,6 +2738,20 @@ int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total) 
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (assign_total) *assign_total = c->stat_ovf_assign;
     if (refine_total) *refine_total = c->stat_ovf_refine;
+    return XB_OK;
+}
+// device bytes this context holds for the grid: density, labels, flags, numbering, the table (its window), scratch
+int xb_memory_stats(xb_ctx *c, int64_t *bytes_total, int64_t *bytes_table, int64_t *bytes_scratch) {
+    if (!c || !c->has_grid) return fail(XB_E_STATE, "xb_memory_stats: no grid");
+    const long long N = c->N;
+    const long long table = c->grad_cap * (long long)sizeof(GradRec);
+    const long long scratch = c->list_cap * 4 + (long long)c->stage_bytes + c->ec_buf_cap * 4 + (c->ec_pend ? 8 * N + 16 : 0);
+    const long long fixed = 8 * N /* rho */ + 4 * N /* labels */ + (N + 16) /* known */ + 4 * N /* first */ + N /* st */ +
+                            2LL * c->max_cap * 4 + (long long)c->ovf_cap * 4 + c->blab_alloc * 5 + (long long)c->walk_cap * 3 * 80 +
+                            (1 << 22) /* boxbuf */;
+    if (bytes_total) *bytes_total = fixed + table + scratch;
+    if (bytes_table) *bytes_table = table;
+    if (bytes_scratch) *bytes_scratch = scratch;
     return XB_OK;
 }
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels) {

@@ -13,6 +13,7 @@ struct Grid {
     int x0, x1;       // owned slab: planes [x0, x1)
     int vx0, vlen;    // planes whose labels/known are valid: [vx0, vx0+vlen) modulo nx
     int wx0, wlen;    // planes whose gradient-field table records exist: [wx0, wx0+wlen) modulo nx
+    int wbase, ntot;  // the table holds ONLY those planes: record of voxel l at slot (l - wbase) mod ntot (rec_slot); ntot = nx*ny*nz
     int main_ties;    // 1: the axis tie test of methods.py:324 (`<= >=`, the assignment), 0: refinement.py:111 (`< >`)
     double T[9];      // T_grad, row-major (interface.py:285-290)
     double dist[27];  // dist_mat [3][3][3], index 2 == -1 (interface.py:242-259)
@@ -26,6 +27,7 @@ struct GridS {
     int nx, ny, nz, nyz;
     int x0, x1, vx0, vlen;
     int wx0, wlen;
+    int wbase, ntot;
     int main_ties;
     double T[9];
     double dsym[14];
@@ -43,6 +45,7 @@ struct GridL {
     int nx, ny, nz, nyz;
     int x0, x1, vx0, vlen;
     int wx0, wlen;    // table window (see Grid)
+    int wbase, ntot;  // ... and where its records lie (rec_slot)
     int use24;        // nx*ny < 2^24 and nz < 2^24: linear indices via 24-bit multiplies
     int main_ties;    // see Grid
 };
@@ -149,6 +152,17 @@ struct __attribute__((aligned(32))) GradRec { double r0, r1, r2, key; };
 __device__ __forceinline__ GradRec fetch_rec(const GradRec *__restrict__ G, int l) {
     return *reinterpret_cast<const GradRec *>(reinterpret_cast<const char *>(G) + ((unsigned long long)(unsigned)l << 5));
 }
+
+// The table of a slab holds the records of its window planes only (round 3: a rank no longer allocates 32 B for every voxel
+// of the grid): voxel l of a window plane lies at slot (l - wbase) mod ntot, the window's planes in order even when the
+// window wraps round the periodic boundary.  With the whole grid as window (one GPU) wbase = 0 and the slot is l.
+template <typename GT>
+__device__ __forceinline__ int rec_slot(const GT &g, int l) {
+    const int s = l - g.wbase;
+    return s + ((s >> 31) & g.ntot);
+}
+template <typename GT>
+__device__ __forceinline__ GradRec fetch_rec_w(const GT &g, const GradRec *__restrict__ G, int l) { return fetch_rec(G, rec_slot(g, l)); }
 
 __device__ __forceinline__ double pack_key(double rho, int code, int og) {
     return __longlong_as_double((__double_as_longlong(rho) & ~0x1FFFFFLL) | (long long)(code | (og << 6)));

@@ -307,7 +307,7 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
             // the table knows the best distance-weighted neighbour of v; if there is one (and it is not vacuum) that
             // neighbour is denser than v: not a maximum.  (weighted > rho(v) implies rho(n) > rho(v); the converse can
             // fail by rounding, so "no such neighbour" still takes the full test)
-            const int og = key_og(G[v].key);
+            const int og = key_og(G[rec_slot(g, v)].key);
             if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
                 is_max = false;
                 decided = true;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         py = r / g.nz;
         pz = r - py * g.nz;
         lp = v;
-        rec = fetch_rec(G, v);
+        rec = fetch_rec_w(g, G, v);
         vol_num = labels[v];
         moving = true;
         if (region_blab && region_blab[((px >> 3) * (g.ny >> 3) + (py >> 3)) * (g.nz >> 3) + (pz >> 3)] > 0) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                 // the record is gathered speculatively, together with the flag and the brick byte: asking the brick byte
                 // first saved the gathers of never-written records (most of this kernel's HBM traffic) but cost more in
                 // dependent latency than it saved (0.49 -> 0.55 ms)
-                GradRec nr = fetch_rec(G, in_win ? lq : lp);
+                GradRec nr = fetch_rec(G, in_win ? rec_slot(g, lq) : 0);   // (outside the window: any valid slot, the value is not used)
                 const int8_t kq = known[ok_plane ? lq : lp];
                 const bool missing = !(in_win && rec_exists(brick_rec, g, qx, qy, qz));
                 // slabs (region_blab: the brick labels of the trapping regions, the same on every rank): a retrace that

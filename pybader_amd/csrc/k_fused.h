@@ -92,7 +92,7 @@ __global__ __launch_bounds__(TPB) void k_box_shells_dev(Grid g, const double *__
                   z = wrap_any(mxyz[3 * m + 2] + o[2], g.nz);
         int lo[3], hi[3];
         if (FROM_RHO) move_ranges_rho(rho, g, x, y, z, lo, hi);
-        else move_ranges(fetch_rec(G, (x * g.ny + y) * g.nz + z), lo, hi);
+        else move_ranges(fetch_rec_w(g, G, (x * g.ny + y) * g.nz + z), lo, hi);
         int D = 0;
 #pragma unroll
         for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(TPB) void k_brick_records(GT g, const double *__res
                 code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
             }
             o.key = pack_key(c, code, og);
-            G[((x0 + tx) * g.ny + (y0 + ty)) * g.nz + z0 + tz] = o;
+            G[rec_slot(g, ((x0 + tx) * g.ny + (y0 + ty)) * g.nz + z0 + tz)] = o;
         }
         if (threadIdx.x == 0) brick_rec[b] |= 1;
     }

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(TPB) void k_grad_field(GT g, const double *__restri
             code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
         }
         o.key = pack_key(c, code, og);
-        G[v] = o;
+        G[rec_slot(g, v)] = o;
         if (og == XB_OG_SELF) {
             const int q = atomicAdd(seed_count, 1);
             if (q < seed_cap) seeds[q] = v;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(TPB) void k_box_shells(GridL g, const GradRec *__re
     if (d < rlo) return;
     const int x = wrap_any(mxyz[3 * m] + o[0], g.nx), y = wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
               z = wrap_any(mxyz[3 * m + 2] + o[2], g.nz);
-    const GradRec rec = fetch_rec(G, (x * g.ny + y) * g.nz + z);
+    const GradRec rec = fetch_rec_w(g, G, (x * g.ny + y) * g.nz + z);
     int lo[3], hi[3];
     move_ranges(rec, lo, hi);
     int D = 0;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(TPB) void k_box_stamp(GridL g, GradRec *G, int mx, 
     if (t >= n) return;
     const int dz = (int)(t % w), dy = (int)((t / w) % w), dx = (int)(t / ((long long)w * w));
     const int x = wrap_any(mx + dx - R, g.nx), y = wrap_any(my + dy - R, g.ny), z = wrap_any(mz + dz - R, g.nz);
-    long long *kp = reinterpret_cast<long long *>(&G[(x * g.ny + y) * g.nz + z].key);
+    long long *kp = reinterpret_cast<long long *>(&G[rec_slot(g, (x * g.ny + y) * g.nz + z)].key);
     *kp = (*kp & ~(0x3FFLL << 11)) | ((long long)id << 11);
 }
 

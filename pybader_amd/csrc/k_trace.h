@@ -231,7 +231,7 @@ __device__ __forceinline__ void ng_walk_wave(const GridL &g, const GradRec *__re
         // voxel from the work list lies in an uncertain brick by construction
         const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
         int b = (blab && !in_walk) ? blab[((sx >> 3) * nb1 + (sy >> 3)) * nb2 + (sz >> 3)] : 0;
-        rec = fetch_rec(G, v);
+        rec = fetch_rec_w(g, G, v);
         if (lab0 != -1) {
             px = sx; py = sy; pz = sz;
             lp = v;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void ng_walk_wave(const GridL &g, const GradRec *__re
             }
             if (moving) {
                 const bool in_win = plane_in_window(g, qx);  // the table only exists inside the window (slabs)
-                GradRec nr = fetch_rec(G, in_win ? lq : lp);  // issued before the brick label: both in flight
+                GradRec nr = fetch_rec(G, in_win ? rec_slot(g, lq) : 0);  // issued before the brick label: both in flight (outside the window: any valid slot)
                 const int bl = blab ? blab[((qx >> 3) * nb1 + (qy >> 3)) * nb2 + (qz >> 3)] : 0;
                 if (WIN && !in_win && bl <= 0) nr = make_rec_rho(g, rho, gc, qx, qy, qz);  // outside the window: from rho
                 const int b = bl > 0 ? bl : key_box(nr.key);

@@ -149,10 +149,11 @@ def test_trapping_regions_do_not_change_the_map(size, lattice):
     ctx.close()
 
 
-def test_config4_1024_one_gpu_two_and_four_slabs():
-    """BASELINE config 4 (1024^3, axis-0 slabs) as far as one GPU carries it: the whole grid in one context (66.6 GB),
-    then two and FOUR logical slabs on the same device (4 x 66.6 GB = 266 of the 288 GB: every rank keeps full-size
-    arrays, eight do not fit) -- properties of the map, and N-slab == 1-slab bit for bit (int8 labels, hashed)."""
+def test_config4_1024_one_gpu_four_and_eight_slabs():
+    """BASELINE config 4 (1024^3, EIGHT axis-0 slabs of 128 planes) on one GPU: the whole grid in one context (66.6 GB), then
+    four and eight logical slabs on the same device -- since round 3 a rank's table and scratch are sized by its slab
+    (30 GB per rank on eight slabs, 243 GB in all; round 2's full-size arrays stopped at four) -- properties of the map, and
+    N-slab == 1-slab bit for bit (int8 labels, hashed)."""
     import hashlib
     from test_gpu_slabs import run_slabs
     size = 1024
@@ -177,7 +178,7 @@ def test_config4_1024_one_gpu_two_and_four_slabs():
     del lab
     ctx.close()
     g = {'dist_mat': dm, 'T_grad': tg}
-    for n_slabs, margin in ((2, 32), (4, 64)):
+    for n_slabs, margin in ((4, 64), (8, 64)):
         pre, post, slog, mx, ch2, vo2, fb = run_slabs(n_slabs, g, None, 'neargrid', 'changed', 2, 16, None, shape=shape,
                                                       synth_args=(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND),
                                                       label_dtype=np.int8, keep_pre=False, margin=margin)
@@ -186,6 +187,9 @@ def test_config4_1024_one_gpu_two_and_four_slabs():
         assert np.array_equal(np.array(np.unravel_index(mx, shape)).T, maxima)
         assert np.array_equal(vo2, vo) and np.allclose(ch2, ch, rtol=1e-12)
         assert [tuple(x) for x in slog] == [tuple(x) for x in log]
+        per_rank = max(m[0] for m in run_slabs.last_memory)
+        print(f'{n_slabs} slabs of 1024^3: {per_rank / 2**30:.1f} GiB per rank')
+        assert per_rank < (36 << 30 if n_slabs == 8 else 48 << 30)
 
 
 def test_many_atoms_keep_their_trapping_regions():
