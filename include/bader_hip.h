@@ -197,6 +197,41 @@ int xb_copy_planes(xb_ctx *c, int which /*0 labels,1 known*/, int to_device, voi
 int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, int64_t count);
 int xb_set_halo(xb_ctx *c, int64_t halo); /* planes each side of [x0,x1) that hold valid neighbour data */
 
+/* ---- the slab step with its control flow on the device (csrc/slab_step.h) ------------------------------------
+ * The same work as xb_table_build .. xb_assign_finish and xb_edge_find + xb_refine_trace above (thread_handlers.py:28-75,
+ * 128-236 across slabs), but no list length, counter or table goes through the host between the launches: TWO host waits
+ * per assignment + refinement pass instead of about fifteen.  Between the calls the scheduler (pybader_amd/slab.py) runs the
+ * exchanges on device "blocks" (xb_slab_block): 0-2 the brick arrays of pass A, 3 the ranks' tie flags, 4 their maxima
+ * tables, 6 / 7 the walkers of a refinement pass (all gathered: xb_comm_allgather_block), 5 the counters of a refinement
+ * pass (summed: xb_comm_allreduce_block).
+ *   xb_slab_assign_masks -> [blocks 0-3] -> xb_slab_assign_trace -> [block 4] -> xb_slab_assign_finish (waits)
+ *   [label halos] -> xb_slab_refine_pass -> { [block 6 / 7] -> xb_slab_walkers_round } -> [block 5] -> xb_slab_refine_counts (waits)
+ * xb_slab_supported: whole-brick slabs with a table window, no vacuum, at most 64 ranks.  xb_slab_assign_finish status:
+ * 0 done, 1 repeat the step (the region growth wants its long schedule; every rank sees the same verdict), 2 use the
+ * host-driven calls for this density (a rank has more than 1024 maxima or trajectories for the exact slow kernel). */
+int xb_slab_supported(xb_ctx *c, int nranks, int64_t *ok);
+int xb_slab_assign_masks(xb_ctx *c, int rank, int nranks);
+int xb_slab_assign_trace(xb_ctx *c);
+int xb_slab_assign_finish(xb_ctx *c, int64_t *n_maxima, int64_t *status);
+int xb_slab_refine_pass(xb_ctx *c);
+/* the walkers of the pass (retraces that left this rank's valid planes) travel in blocks 6 / 7, alternately: after block
+ * 6 + src was gathered, its results are applied and -- unless `last` -- its walkers that arrive on this rank's planes are
+ * carried on into this rank's part of the other block.  The last round packs the counters into block 5. */
+int xb_slab_walkers_round(xb_ctx *c, int src, int last);
+/* what travels of a rank's part of blocks 6 / 7 (fixed sizes: no count goes through the host): [0] bytes of a part,
+ * [1] header + walkers of the pass itself, [2] header + walkers of a later round, [3] offset and [4] bytes of the results */
+int xb_slab_walk_layout(int64_t out[5]);
+/* local[8], global[8]: edges, changed, escaped, walkers still travelling after the last round (all ranks; not summed),
+ * retraces redone by the exact slow kernel (then local[1], local[2] are the counts after it and the caller sums once more),
+ * walkers lost to a full block or stuck (their voxels stay parked: xb_escaped_paths), this rank's travelling walkers
+ * (xb_walkers_fetch), 0 */
+int xb_slab_refine_counts(xb_ctx *c, int64_t *local, int64_t *global);
+int xb_slab_block(xb_ctx *c, int which, void **dev_ptr, int64_t *bytes_total, int64_t *own_offset, int64_t *own_bytes);
+/* bytes [off, off + bytes) of a block from (to_device 1) or to (0) host memory: the host-staged transports */
+int xb_slab_block_copy(xb_ctx *c, int which, int to_device, void *host, int64_t off, int64_t bytes);
+/* waits of the host for the card inside library calls made by the calling thread since it started */
+int xb_host_waits(int64_t *n);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel, measured on the context's stream: accumulated
  * milliseconds and launch count since the last reset.  which: 0 neargrid assignment after the table
@@ -209,7 +244,8 @@ int xb_enable_timing(xb_ctx *c, int on);
  * key 1: trapping boxes bit0 / brick growth bit1; key 2: trace threads per block; key 3: debug prints;
  * key 13-18: round-3 switches, each an exactness cross-check in the tests (13 mirror prefilter of pass A, 14 lean walker,
  * 15 waves per trace workgroup, 16 chase growth, 17 kill launches scheduled after a chase, 18 narrowed label halos,
- * 19 self exchange (tests), 20 diagonal T_grad form, 21 brick cache of the trace, 22 slab-sized table / scratch (before xb_set_grid));
+ * 19 self exchange (tests), 20 diagonal T_grad form, 21 brick cache of the trace, 22 slab-sized table / scratch (before xb_set_grid), 24 collectives return
+ * without waiting (ordered on the stream));
  * key 4: workgroups of the edge_check chase; key 5: its LDS queue capacity, lowered in tests to force
  * the overflow hand-over; key 6: drop the cached gradient-field table, so that the next refinement
  * rebuilds it -- bench.py does this every step: a table kept from an earlier step would hide 1.6 ms) */
@@ -244,6 +280,10 @@ int xb_comm_allgather_i64(xb_ctx *c, const int64_t *in, int64_t n, int64_t *out)
 /* every rank's chunk [first[r], first[r]+count[r]) of the brick move masks (xb_brick_masks) and of the bricks'
  * single-maximum voxels to every rank */
 int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *count);
+/* blocks 0-4 of the device-driven slab step: part [first[r], first[r] + count[r]) (bytes) from rank r to every rank;
+ * block 5: summed := sum over the ranks of local.  Ordered on the context's stream, no host wait. */
+int xb_comm_allgather_block(xb_ctx *c, int which, const int64_t *first, const int64_t *count);
+int xb_comm_allreduce_block(xb_ctx *c);
 /* plane bytes this rank has sent since xb_comm_init (label halos travel as dtype_calc(-n_maxima): int8 for up to 127 basins) */
 int xb_comm_stats(xb_ctx *c, int64_t *bytes_sent);
 

@@ -87,6 +87,19 @@ SYMBOLS = {
     'xb_comm_allreduce_i64': (_int, [_vp, _pi64, C.c_int64, _int]),
     'xb_comm_allgather_i64': (_int, [_vp, _pi64, C.c_int64, _pi64]),
     'xb_comm_share_brick_masks': (_int, [_vp, _pi64, _pi64]),
+    'xb_comm_allgather_block': (_int, [_vp, _int, _pi64, _pi64]),
+    'xb_comm_allreduce_block': (_int, [_vp]),
+    'xb_slab_supported': (_int, [_vp, _int, _pi64]),
+    'xb_slab_assign_masks': (_int, [_vp, _int, _int]),
+    'xb_slab_assign_trace': (_int, [_vp]),
+    'xb_slab_assign_finish': (_int, [_vp, _pi64, _pi64]),
+    'xb_slab_refine_pass': (_int, [_vp]),
+    'xb_slab_walkers_round': (_int, [_vp, _int, _int]),
+    'xb_slab_walk_layout': (_int, [_pi64]),
+    'xb_slab_refine_counts': (_int, [_vp, _pi64, _pi64]),
+    'xb_slab_block': (_int, [_vp, _int, C.POINTER(_vp), _pi64, _pi64, _pi64]),
+    'xb_slab_block_copy': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
+    'xb_host_waits': (_int, [_pi64]),
     'xb_comm_stats': (_int, [_vp, _pi64]),
     'xb_memory_stats': (_int, [_vp, _pi64, _pi64, _pi64]),
 }
@@ -480,6 +493,73 @@ class Context:
     def comm_share_brick_masks(self, first, count):
         f, n = np.array(first, np.int64), np.array(count, np.int64)
         check(self.lib.xb_comm_share_brick_masks(self.h, f.ctypes.data_as(_pi64), n.ctypes.data_as(_pi64)))
+
+    # ---- the slab step with its control flow on the device (csrc/slab_step.h) ----
+    def slab_supported(self, nranks):
+        a = C.c_int64(0)
+        check(self.lib.xb_slab_supported(self.h, int(nranks), C.byref(a)))
+        return bool(a.value)
+
+    def slab_assign_masks(self, rank, nranks):
+        check(self.lib.xb_slab_assign_masks(self.h, int(rank), int(nranks)))
+
+    def slab_assign_trace(self):
+        self.drop_label_token()
+        check(self.lib.xb_slab_assign_trace(self.h))
+
+    def slab_assign_finish(self):
+        """-> (n_maxima, status): 0 done, 1 repeat the step, 2 use the host-driven calls"""
+        self.drop_label_token()
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self.lib.xb_slab_assign_finish(self.h, C.byref(a), C.byref(b)))
+        if b.value == 0:
+            self.n_maxima = int(a.value)
+        return int(a.value), int(b.value)
+
+    def slab_refine_pass(self):
+        self.drop_label_token()
+        check(self.lib.xb_slab_refine_pass(self.h))
+
+    def slab_walkers_round(self, src, last):
+        self.drop_label_token()
+        check(self.lib.xb_slab_walkers_round(self.h, int(src), 1 if last else 0))
+
+    def slab_walk_layout(self):
+        """(part bytes, header + walkers of round 0, header + walkers of later rounds, results offset, results bytes)"""
+        out = np.zeros(5, np.int64)
+        check(self.lib.xb_slab_walk_layout(out.ctypes.data_as(_pi64)))
+        return [int(v) for v in out]
+
+    def slab_refine_counts(self):
+        """-> (local, summed): int64[8] each -- edges, changed, escaped, walkers still travelling (all ranks), slow-path
+        retraces, walkers lost or stuck, this rank's travelling walkers, 0"""
+        loc, glo = np.zeros(8, np.int64), np.zeros(8, np.int64)
+        check(self.lib.xb_slab_refine_counts(self.h, loc.ctypes.data_as(_pi64), glo.ctypes.data_as(_pi64)))
+        return loc, glo
+
+    def slab_block(self, which):
+        """(device pointer, bytes, offset of this rank's part, its bytes) of exchange block `which`"""
+        p, a, b, d = _vp(), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.xb_slab_block(self.h, int(which), C.byref(p), C.byref(a), C.byref(b), C.byref(d)))
+        return int(p.value or 0), int(a.value), int(b.value), int(d.value)
+
+    def slab_block_copy(self, which, host, off, to_device):
+        """bytes [off, off + host.nbytes) of block `which` from (to_device) or into the uint8 array `host`"""
+        assert host.dtype == np.uint8 and host.flags.c_contiguous
+        check(self.lib.xb_slab_block_copy(self.h, int(which), 1 if to_device else 0, _ptr(host), int(off), host.nbytes))
+
+    def comm_allgather_block(self, which, first, count):
+        f, n = np.array(first, np.int64), np.array(count, np.int64)
+        check(self.lib.xb_comm_allgather_block(self.h, int(which), f.ctypes.data_as(_pi64), n.ctypes.data_as(_pi64)))
+
+    def comm_allreduce_block(self):
+        check(self.lib.xb_comm_allreduce_block(self.h))
+
+    def host_waits(self):
+        """waits of the host for the card inside library calls made by this thread"""
+        a = C.c_int64(0)
+        check(self.lib.xb_host_waits(C.byref(a)))
+        return int(a.value)
 
     def memory_stats(self):
         """(total, table, scratch) device bytes this context holds for the grid"""

@@ -408,6 +408,24 @@ class HostComm:
     def share_brick_masks(self, backend, chunks):
         raise NotImplementedError('host backends build the whole table themselves')
 
+    # ---- exchange blocks of the device-driven slab step (csrc/slab_step.h), staged through the host ----
+    def allgather_block(self, backend, which, parts):
+        """every rank's part (offset, bytes) of block `which` to every rank"""
+        off, n = parts[self.rank]
+        mine = np.empty(n, np.uint8)
+        backend.slab_block_copy(which, mine, off, False)
+        got = self.allgather(mine)
+        for r, (o, m) in enumerate(parts):
+            if r != self.rank and m:
+                backend.slab_block_copy(which, np.ascontiguousarray(got[r], np.uint8), o, True)
+
+    def allreduce_block(self, backend):
+        """block 5: summed[0..8) := sum over the ranks of local[0..8) (int64)"""
+        mine = np.empty(64, np.uint8)
+        backend.slab_block_copy(5, mine, 0, False)
+        total = np.sum([np.frombuffer(np.ascontiguousarray(g, np.uint8).tobytes(), np.int64) for g in self.allgather(mine)], axis=0)
+        backend.slab_block_copy(5, np.frombuffer(total.astype(np.int64).tobytes(), np.uint8).copy(), 64, True)
+
 
 class RcclComm(HostComm):
     """Device transport through libbader_hip.so's xb_comm_* (RCCL), host objects through the store."""
@@ -541,6 +559,21 @@ class RcclComm(HostComm):
             return buf
 
         self._staged(sends, recvs, fetch, lambda a, b, v: ctx.copy_planes(which, True, np.ascontiguousarray(v, dt), a, b))
+
+    @property
+    def stream_ordered(self):
+        """the device collectives are ordered on the context's stream: nothing has to wait for the card before them"""
+        return self.device
+
+    def allgather_block(self, backend, which, parts):
+        if not self.device:
+            return super().allgather_block(backend, which, parts)
+        self.ctx.comm_allgather_block(which, [p[0] for p in parts], [p[1] for p in parts])
+
+    def allreduce_block(self, backend):
+        if not self.device:
+            return super().allreduce_block(backend)
+        self.ctx.comm_allreduce_block()
 
     def share_brick_masks(self, backend, chunks):
         ctx = self.ctx

@@ -12,6 +12,11 @@
 #include <thread>
 #include <vector>
 
+// every wait of the host for the card made inside the library is counted (per calling thread: xb_host_waits)
+static thread_local long long xb_waits = 0;
+static inline hipError_t xb_counted_sync(hipStream_t s) { xb_waits++; return (hipStreamSynchronize)(s); }
+#define hipStreamSynchronize(s) xb_counted_sync(s)
+
 // =============================================================================================
 // kernels
 // =============================================================================================
@@ -110,6 +115,12 @@ struct xb_ctx {
     bool grad_valid = false;
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
+    void *xbuf = nullptr;      // the device-driven slab step's exchange blocks 3-5 (slab_step.h): tie flags, counters, maxima tables
+    int slab_rank = 0, slab_nranks = 0, slab_stage = 0;
+    void *wbuf[2] = {nullptr, nullptr};   // ... blocks 6 / 7: the walkers of a refinement pass and their results, one part per rank
+    void *wk_in = nullptr;                // the walkers this rank carries on in a round (+ their count)
+    int wbuf_ranks = 0, walk_last = -1;
+    int opt_async_comm = 0;    // collectives return without waiting (they are ordered on the context's stream); the device-driven slab step sets it
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
     int opt_lean_mem = 1;      // slabs: table, `list` and `stage` sized by the slab instead of the grid (0: everything full size)
     int opt_trace_cache = 1;   // group trace: the own brick's records in LDS (k_ng_trace_g, LEAN 3 / 4)
@@ -304,7 +315,7 @@ void xb_destroy(xb_ctx *c) {
         for (auto &p : t.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     free_grid(c);
     hipFree(c->counters); hipFree(c->counters64); hipFree(c->dsum); hipFree(c->dist_dev); hipFree(c->boxbuf);
-    hipFree(c->walk_in); hipFree(c->walk_out2); hipFree(c->walk_res);
+    hipFree(c->walk_in); hipFree(c->walk_out2); hipFree(c->walk_res); hipFree(c->xbuf); hipFree(c->wbuf[0]); hipFree(c->wbuf[1]); hipFree(c->wk_in);
     hipHostFree(c->host_ints);
     hipHostFree(c->pin);
     for (int k = 0; k < 2; k++) { hipHostFree(c->big_pin[k]); if (c->big_ev[k]) hipEventDestroy(c->big_ev[k]); }
@@ -1674,8 +1685,9 @@ static void plane_range(const Grid &g, int ext, int &xa, int &np) {
     else { xa = ((g.x0 - ext) % g.nx + g.nx) % g.nx; np = own + 2 * ext; }
 }
 
-int xb_edge_find(xb_ctx *c, int64_t *edges) {
-    NEED_GRID("xb_edge_find");
+// the sweep's launches; the edge count stays on the device (counters[5]).  *dilate_owned: the owned edges still have to
+// dilate from the list (k_edge_dilate_list over counters[5] entries)
+static int edge_find_launch(xb_ctx *c, bool *dilate_owned) {
     const Grid &g = c->g;
     const bool whole = (g.x1 - g.x0 == g.nx);
     if (!whole && c->halo < 2) return fail(XB_E_STATE, "xb_edge_find: slab needs a label halo (xb_set_halo)");
@@ -1766,9 +1778,17 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
         }
     }
     HIPCHK(hipGetLastError());
+    *dilate_owned = whole || !all;
+    return XB_OK;
+}
+int xb_edge_find(xb_ctx *c, int64_t *edges) {
+    NEED_GRID("xb_edge_find");
+    const Grid &g = c->g;
+    bool dilate_owned = false;
+    if (int rc = edge_find_launch(c, &dilate_owned)) return rc;
     int n = 0;
     if (int rc = read_counter(c, 5, &n)) return rc;
-    if ((whole || !all) && n) {  // the list holds every owned edge: dilate from it
+    if (dilate_owned && n) {  // the list holds every owned edge: dilate from it
         ScopedTimer t(c, 2);
         k_edge_dilate_list<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->known, c->list, n, nullptr);
         HIPCHK(hipGetLastError());
@@ -2723,6 +2743,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 20) c->opt_mask_diag = value != 0;
     else if (key == 21) c->opt_trace_cache = value != 0;
     else if (key == 22) c->opt_lean_mem = value != 0;   // (before xb_set_grid)
+    else if (key == 24) c->opt_async_comm = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)
@@ -2810,3 +2831,4 @@ int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches) {
 }  // extern "C"
 
 #include "comm.h"
+#include "slab_step.h"

@@ -218,7 +218,7 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
         for (int i = 0; i < n_send; i++) t += (size_t)(send_xb[i] - send_xa[i]) * g.nyz;
         c->comm->bytes_sent += (unsigned long long)t * (packed ? (size_t)wire : es);
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->opt_async_comm) HIPCHK(hipStreamSynchronize(c->stream));   // (option 24: whatever reads the planes next is ordered behind them)
     return XB_OK;
 }
 

@@ -31,6 +31,7 @@ enum {
     FS_R_DEFER,          // refinement: retraces handed to the from-rho kernel (their walk goes on through a brick without records)
     FS_N_TILES,          // refinement: tiles of the edge sweep that are not of one label with their surroundings
     FS_GROW_RETRY,       // the scheduled kill launches did not reach the fixpoint: the host repeats the assignment with the long schedule
+    FS_N_RECL,           // slabs: bricks of the table window that get records (the walk list holds the owned ones among them)
     FS_COUNT = 64,
     // 8 per-XCD work cursors of the persistent trace, one per 128-byte line: device-scope atomics on ONE line
     // serialise at ~88 per microsecond whatever the word (measured: 8 cursors in one line = one cursor)

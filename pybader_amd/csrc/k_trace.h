@@ -39,7 +39,8 @@ __global__ __launch_bounds__(TPB) void k_fill_certain(GridL g, const int *__rest
 // labels themselves are written by k_relabel_regions after the trace.
 __global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_lo, int b_hi,
                                       const int *__restrict__ blab, const int *__restrict__ box_max, int *first,
-                                      int *max_list, int *max_count, int max_cap) {
+                                      int *max_list, int *max_count, int max_cap, const int *skip = nullptr) {
+    if (skip && *skip) return;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int l = (b < nb0 * nb1 * nb2 && b >= b_lo && b < b_hi) ? blab[b] : 0;
     const bool has = l > 0;

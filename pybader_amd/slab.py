@@ -141,6 +141,7 @@ class SlabRunner:
         self.sends, self.recvs = halo_plan(self.ranges, comm.rank, self.halo, self.shape[0])
         self.n_maxima = 0
         self.n_fallbacks = 0
+        self.n_device_steps = 0      # assignments that ran as the device-driven step (csrc/slab_step.h)
         self.timing = {} if os.environ.get('XB_SLAB_TIMING') else None
         if comm.size > 1 and hasattr(comm, 'selftest_planes'):
             self.be.sync()
@@ -163,6 +164,95 @@ class SlabRunner:
         self.windowed = ok
         return ok
 
+    # ---- the step with its control flow on the device (csrc/slab_step.h): two host waits per assignment + refinement pass ----
+    def _device_step(self):
+        """whether this decomposition takes the device-driven step: voted once (every rank must take the same branch), then
+        checked locally per call (vacuum switches it off; the tolerance is the same on every rank)"""
+        if getattr(self, '_step_vote', None) is None:
+            ok = (getattr(self, 'windowed', False) and hasattr(self.be, 'slab_supported') and hasattr(self.comm, 'allgather_block')
+                  and not os.environ.get('XB_SLAB_HOST_DRIVEN'))
+            self._step_vote = all(self.comm.allgather(bool(ok)))
+            if self._step_vote and hasattr(self.be, 'set_option'):
+                self.be.set_option(24, 1)      # collectives are ordered on the stream: nothing waits for them on the host
+        return self._step_vote and not getattr(self, '_step_declined', False) and self.be.slab_supported(self.comm.size)
+
+    def _guard(self, what):
+        """the collectives of the device-driven step are ordered on the stream: a peer that never arrives shows at the
+        step's host waits, so those carry the transport's hang watchdog"""
+        import contextlib
+        g = getattr(self.comm, '_guard', None)
+        return g(what) if g is not None else contextlib.nullcontext()
+
+    def _parts(self, which):
+        """(offset, bytes) of every rank's part of exchange block `which` (static for a decomposition)"""
+        cache = self.__dict__.setdefault('_block_parts', {})
+        if which not in cache:
+            _, _, off, n = self.be.slab_block(which)
+            cache[which] = self.comm.allgather((int(off), int(n)))
+        return cache[which]
+
+    def _assign_device_step(self):
+        """-> n_maxima, or None when this density is not for the device-driven step (the host-driven calls take over)"""
+        for _ in range(2):
+            with _Phase(self, 'masks'):
+                self.be.slab_assign_masks(self.comm.rank, self.comm.size)
+            with _Phase(self, 'brick_exchange'):
+                for which in (0, 1, 2, 3):
+                    self.comm.allgather_block(self.be, which, self._parts(which))
+            with _Phase(self, 'assign_trace'):
+                self.be.slab_assign_trace()
+            with _Phase(self, 'maxima_exchange'):
+                self.comm.allgather_block(self.be, 4, self._parts(4))
+            with _Phase(self, 'assign_finish'), self._guard('assignment'):
+                n, status = self.be.slab_assign_finish()
+            if status == 0:
+                self.n_maxima = n
+                self.maxima = np.ravel_multi_index(tuple(self.be.maxima().T), self.shape) if n else np.zeros(0, np.int64)
+                return n
+            if status == 2:
+                return None
+        raise RuntimeError('the region growth asked for a repeat twice')
+
+    def _refine_pass_device(self):
+        """edge sweep + retraces of one iteration: -> (edges, changed), summed over the ranks"""
+        self.exchange_label_halo()
+        with _Phase(self, 'refine_pass'):
+            self.be.slab_refine_pass()
+        # Some retraces walk out of the valid planes before they meet a known == 2 voxel (they slide along a dividing
+        # surface for tens of planes: about 1 % of them with a 16-plane halo at 512^3).  They are parked and exported as
+        # walkers; the rank that owns the plane they entered carries them on.  A fixed number of rounds runs without asking
+        # the host whether any walker is left (an empty round costs a few small launches); what still travels afterwards
+        # (or needs the exact slow path) is finished by the host-driven loop.
+        rounds = int(os.environ.get('XB_SLAB_WALKER_ROUNDS', '3'))
+        with _Phase(self, 'walkers'):
+            if getattr(self, '_walk_layout', None) is None:
+                self._walk_layout = self.be.slab_walk_layout()
+            part, first, later, res_off, res_n = self._walk_layout
+            src = 0
+            for k in range(rounds + 1):
+                # (fixed sizes: the walkers the pass may export / a later round may export again, and every result)
+                self.comm.allgather_block(self.be, 6 + src, [(r * part, first if k == 0 else later) for r in range(self.comm.size)])
+                if k:
+                    self.comm.allgather_block(self.be, 6 + src, [(r * part + res_off, res_n) for r in range(self.comm.size)])
+                self.be.slab_walkers_round(src, k == rounds)
+                src ^= 1
+        with _Phase(self, 'sums'):
+            self.comm.allreduce_block(self.be)
+        with _Phase(self, 'refine_wait'), self._guard('refinement pass'):
+            loc, glo = self.be.slab_refine_counts()
+        edges, changed = int(glo[0]), int(glo[1])
+        if os.environ.get('XB_SLAB_DEBUG'):
+            print(f'[rank {self.comm.rank}] refinement pass: local {loc.tolist()} summed {glo.tolist()}', file=sys.stderr, flush=True)
+        if glo[4]:      # rare: some retraces went through the exact slow kernel after the sums were taken
+            with _Phase(self, 'sums'):
+                changed, = self.comm.sum(int(loc[1]))
+        if glo[2]:
+            self.n_fallbacks += 1
+        if loc[3] or glo[5]:
+            changed += self._finish_escaped(int(loc[6] + loc[5]))
+            self.n_fallbacks -= 1
+        return edges, changed
+
     def assign(self, method):
         """thread_handlers.bader_calc: per-slab trajectories, then one tiny table merge for numbering."""
         if self.comm.size == 1 and hasattr(self.be, 'assign'):
@@ -170,6 +260,14 @@ class SlabRunner:
             self.n_maxima = int(self.be.assign(method))
             self.maxima = np.ravel_multi_index(tuple(self.be.maxima().T), self.shape) if self.n_maxima else np.zeros(0, np.int64)
             return self.n_maxima
+        self._stepped = False
+        if method == 'neargrid' and self._device_step():
+            n = self._assign_device_step()
+            if n is not None:
+                self.n_device_steps += 1
+                self._stepped = True      # (the refinement may use the device-driven pass: labels, regions and table are this step's)
+                return n
+            self._step_declined = True    # this density: host-driven from here on (every rank got the same status)
         if getattr(self, 'windowed', False) and method == 'neargrid':
             # windowed table: the trapping regions need every rank's maxima and brick masks
             with _Phase(self, 'table_build'):
@@ -212,7 +310,8 @@ class SlabRunner:
     def exchange_label_halo(self):
         if self.comm.size > 1:
             with _Phase(self, 'label_halo'):
-                self.be.sync()
+                if not getattr(self.comm, 'stream_ordered', False):
+                    self.be.sync()
                 self.comm.exchange_planes(self.be, 0, self.sends, self.recvs)
 
     def _trace(self, edges=None):
@@ -233,24 +332,29 @@ class SlabRunner:
         with _Phase(self, 'sums'):
             changed, escaped, edges = self.comm.sum(changed, escaped, edges)
         if escaped:
-            # Some retraces walked out of the valid planes before meeting a known==2 voxel (they slide along a
-            # dividing surface for tens of planes: about 1 % of them with a 16-plane halo at 512^3).  They were parked
-            # (known == -6) untouched and exported as walkers: the rank that owns the plane they entered carries them on.
-            self.n_fallbacks += 1
-            ch2, left = 0, local_escaped
-            if hasattr(self.be, 'walkers_continue') and hasattr(self.comm, 'gather_rows'):
-                with _Phase(self, 'walkers'):
-                    ch2, left = self._migrate_walkers(local_escaped)
-            with _Phase(self, 'sums'):
-                ch2, left = self.comm.sum(ch2, left)
-            changed += ch2
-            if left:      # no walker transport (host backend), or walkers that need the exact slow path
-                with _Phase(self, 'escaped_path_queries'):
-                    ch3 = self._resolve_escaped()
-                with _Phase(self, 'sums'):
-                    ch3, = self.comm.sum(ch3)
-                changed += ch3
+            changed += self._finish_escaped(local_escaped)
         return changed, edges
+
+    def _finish_escaped(self, local_escaped):
+        """the retraces that left the valid planes (parked, exported as walkers): -> voxels relabelled by finishing them,
+        summed over the ranks"""
+        # Some retraces walked out of the valid planes before meeting a known==2 voxel (they slide along a dividing
+        # surface for tens of planes: about 1 % of them with a 16-plane halo at 512^3).  They were parked (known == -6)
+        # untouched and exported as walkers: the rank that owns the plane they entered carries them on.
+        self.n_fallbacks += 1
+        changed, left = 0, local_escaped
+        if hasattr(self.be, 'walkers_continue') and hasattr(self.comm, 'gather_rows'):
+            with _Phase(self, 'walkers'):
+                changed, left = self._migrate_walkers(local_escaped)
+        with _Phase(self, 'sums'):
+            changed, left = self.comm.sum(changed, left)
+        if left:      # no walker transport (host backend), or walkers that need the exact slow path
+            with _Phase(self, 'escaped_path_queries'):
+                ch3 = self._resolve_escaped()
+            with _Phase(self, 'sums'):
+                ch3, = self.comm.sum(ch3)
+            changed += ch3
+        return changed
 
     def _migrate_walkers(self, local_escaped):
         """Rounds of: all-gather the open walkers together with the results of the round before; apply the results
@@ -371,31 +475,40 @@ class SlabRunner:
             return log
         if self.comm.size == 1 and hasattr(self.be, 'refine') and hasattr(self.be, 'ctx'):
             return self.be.refine(mode, iters)      # one GPU: xb_refine (one host wait per iteration)
-        self.exchange_label_halo()
-        if hasattr(self.be, 'prepare_refine') and not getattr(self, 'windowed', False):
-            with _Phase(self, 'table_build'):
-                self.be.prepare_refine()     # the retraces need the table anyway; edge_find profits from it
-        with _Phase(self, 'edge_find'):
-            edges = self.be.edge_find()
-        # (the edge count travels with the retrace counters: one collective; without an edge anywhere the pass is empty)
-        changed, edges = self._trace(edges)
+        stepped = getattr(self, '_stepped', False) and self._device_step()
+        if stepped:
+            edges, changed = self._refine_pass_device()
+        else:
+            self.exchange_label_halo()
+            if hasattr(self.be, 'prepare_refine') and not getattr(self, 'windowed', False):
+                with _Phase(self, 'table_build'):
+                    self.be.prepare_refine()     # the retraces need the table anyway; edge_find profits from it
+            with _Phase(self, 'edge_find'):
+                edges = self.be.edge_find()
+            # (the edge count travels with the retrace counters: one collective; without an edge anywhere the pass is empty)
+            changed, edges = self._trace(edges)
         if edges == 0:
             return log
         log.append((edges, changed))
         it = 2
         while iters < 0 or it <= iters:
             if mode.lower() == 'all':
-                self.exchange_label_halo()
-                edges = self.be.edge_find()
-                changed, edges = self._trace(edges)
+                if stepped:
+                    edges, changed = self._refine_pass_device()
+                else:
+                    self.exchange_label_halo()
+                    edges = self.be.edge_find()
+                    changed, edges = self._trace(edges)
             else:
                 if self.comm.size == 1:
                     _, edges = self.be.edge_check()
+                    changed = self._trace()
                 elif changed == 0:
-                    edges = 0                      # no voxel is flagged -2: edge_check is the identity
+                    # no voxel is flagged -2: edge_check is the identity (refinement.py:425-427) and the retrace has no work
+                    edges, changed = 0, 0
                 else:
                     edges = self._edge_check_slabs()
-                changed = self._trace()
+                    changed = self._trace()
             log.append((edges, changed))
             if changed == 0:
                 break

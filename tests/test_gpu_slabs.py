@@ -10,7 +10,7 @@ import pytest
 from conftest import case_density, load_golden
 from pybader_amd import _lib, slab, synth
 from pybader_amd.interface import distance_matrix, gradient_transform
-from torch_comm import device_views
+from torch_comm import block_view, device_views
 
 pytestmark = pytest.mark.gpu
 
@@ -64,6 +64,32 @@ class ThreadComm:
     def gather_rows(self, rows):
         return np.concatenate(self.allgather(np.ascontiguousarray(rows, np.int64)))
 
+    # the exchange blocks of the device-driven step: device-to-device copies between the contexts of this one card
+    def allgather_block(self, backend, which, parts):
+        import torch
+        backend.ctx.sync()
+        mine = block_view(backend.ctx, which)
+        self.sh.cur[self.rank] = mine
+        self.sh.barrier.wait()
+        for r, (off, n) in enumerate(parts):
+            if r != self.rank and n:
+                mine[off:off + n].copy_(self.sh.cur[r][off:off + n])
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
+
+    def allreduce_block(self, backend):
+        import torch
+        backend.ctx.sync()
+        mine = block_view(backend.ctx, 5).view(torch.int64)
+        self.sh.cur[self.rank] = mine
+        self.sh.barrier.wait()
+        total = torch.stack([t[:8] for t in self.sh.cur]).sum(0)
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
+        mine[8:16].copy_(total)
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
+
     def barrier(self):
         self.sh.barrier.wait()
 
@@ -92,7 +118,7 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
             log = runner.refine(mode, iters)
             post = ctx.download_labels(label_dtype)[x0:x1].copy()
             ch, vo = ctx.charge_sum(1.0, nb)
-            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats(), ctx.memory_stats())
+            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats(), ctx.memory_stats(), runner.n_device_steps)
             ctx.close()
         except Exception as e:  # noqa: BLE001
             sh.errors.append(repr(e))
@@ -112,6 +138,8 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
     run_slabs.last_windowed = [r[8] for r in res]
     run_slabs.last_slow = [r[9] for r in res]
     run_slabs.last_memory = [r[10] for r in res]
+    run_slabs.last_device_steps = [r[11] for r in res]
+    print('device-driven steps per rank:', run_slabs.last_device_steps)
     return pre, post, res[0][3], res[0][4], ch, vo, max(r[7] for r in res)
 
 

@@ -59,3 +59,10 @@ def device_views(ctx, device_index=0):
     # the bricks' single-maximum voxels live three brick arrays behind the masks (csrc: list + nbr / list + 4 nbr)
     maxvox = torch.as_tensor(_DevArray(ptr + 3 * n * 4, (n,), '<i4'), device=dev) if n else None
     return lab, kn, masks, maxvox
+
+
+def block_view(ctx, which, device_index=0):
+    """zero-copy uint8 torch view of exchange block `which` of the device-driven slab step (csrc/slab_step.h)"""
+    import torch
+    ptr, total, _, _ = ctx.slab_block(which)
+    return torch.as_tensor(_DevArray(ptr, (total,), '|u1'), device=f'cuda:{device_index}')

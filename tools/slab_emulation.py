@@ -37,6 +37,7 @@ class LockedBackend(slab.GpuBackend):
     def __init__(self, ctx, book):
         super().__init__(ctx, 0)
         self.book = book
+        self.waits = {}
 
     def __getattr__(self, name):
         f = getattr(self.ctx, name)
@@ -47,10 +48,14 @@ class LockedBackend(slab.GpuBackend):
             with GPU:
                 self.ctx.sync()
                 t0 = time.perf_counter()
+                w0 = self.ctx.host_waits()
                 r = f(*a, **k)
+                w1 = self.ctx.host_waits()
                 self.ctx.sync()
                 dt = time.perf_counter() - t0
                 self.book[name] = self.book.get(name, 0.0) + dt
+                if w1 > w0:      # waits of the host for the card inside the library call itself (not the emulation's own syncs)
+                    self.waits[name] = self.waits.get(name, 0) + (w1 - w0)
                 if dt > 2e-3 and os.environ.get('XB_EMUL_DEBUG'):
                     print(f'slow call {name}: {1e3 * dt:.1f} ms args {[getattr(x, "shape", x) for x in a]}', file=sys.stderr, flush=True)
             return r
@@ -61,6 +66,8 @@ def run(n, shape, g, halo, margin, steps, warmup, mode, iters):
     from test_gpu_slabs import Shared, ThreadComm
     sh = Shared(n)
     books = [dict() for _ in range(n)]
+    waits = [dict() for _ in range(n)]
+    steps_dev = [0] * n
     walls = [0.0] * n
 
     def work(rank):
@@ -78,6 +85,7 @@ def run(n, shape, g, halo, margin, steps, warmup, mode, iters):
             for it in range(warmup + steps):
                 if it == warmup:
                     be.book = books[rank]
+                    be.waits = waits[rank]
                     comm.barrier()
                     t0 = time.perf_counter()
                 be.vacuum_assign(None, 1.0)
@@ -85,6 +93,7 @@ def run(n, shape, g, halo, margin, steps, warmup, mode, iters):
                 runner.refine(mode, iters)
             comm.barrier()
             walls[rank] = time.perf_counter() - t0
+            steps_dev[rank] = runner.n_device_steps
             ctx.close()
         except Exception as e:  # noqa: BLE001
             sh.errors.append(repr(e))
@@ -103,6 +112,9 @@ def run(n, shape, g, halo, margin, steps, warmup, mode, iters):
     return {'ranks': n, 'halo': halo, 'projected_ms': round(sum(slowest.values()), 3),
             'busiest_rank_ms': round(max(sum(b.values()) for b in books) * 1e3 / steps, 3),
             'phases_ms_slowest_rank': {k: round(v, 3) for k, v in slowest.items()},
+            'host_waits_per_step': max(sum(w.values()) for w in waits) / steps,
+            'host_waits_by_call': {k: max(w.get(k, 0) for w in waits) / steps for k in sorted({k for w in waits for k in w})},
+            'device_driven_steps': min(steps_dev),
             'serialised_wall_ms': round(1e3 * max(walls) / steps, 3)}
 
 
