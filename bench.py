@@ -286,8 +286,6 @@ def main():
 
     halo = args.halo if args.halo is not None else (16 if world > 1 else 8)
     runner = slab.SlabRunner(slab.GpuBackend(ctx, dev_index), comm, shape, dm, tg, halo=halo)
-    if args.table_margin is None:
-        args.table_margin = max(32, shape[0] // 16)
     windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
     ctx.enable_timing(True)
@@ -321,11 +319,13 @@ def main():
     if runner.timing is not None:
         runner.timing.clear()
     fence()
+    waits0 = ctx.host_waits()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_basins, log = step()
     fence()
     dt = comm.max_float(time.perf_counter() - t0)       # max over ranks
+    host_waits = (ctx.host_waits() - waits0 - 1) / args.steps   # waits of this rank for its card inside library calls (less the fence's)
 
     nvox = float(np.prod(shape))
     # N > 1: where a slab step spends its time, from two EXTRA steps with a device sync around every scheduler phase
@@ -392,7 +392,8 @@ def main():
                                'density resident in HBM',
                    'grid': list(shape), 'method': args.method, 'refine_mode': [mode, iters],
                    'parallelism': f'{world} axis-0 slab(s), density replicated, halo {runner.halo}, transport {comm.transport}, '
-                                  f'table window {"slab+-%d planes" % args.table_margin if windowed else "whole grid"}',
+                                  f'table window {"slab+-%d planes" % runner.table_margin if windowed else "whole grid"}',
+                   'host_waits_per_step': host_waits, 'device_driven_slab_step': bool(runner.n_device_steps),
                    'basins': int(n_basins), 'refine_log': log,
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

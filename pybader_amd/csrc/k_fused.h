@@ -32,6 +32,7 @@ enum {
     FS_N_TILES,          // refinement: tiles of the edge sweep that are not of one label with their surroundings
     FS_GROW_RETRY,       // the scheduled kill launches did not reach the fixpoint: the host repeats the assignment with the long schedule
     FS_N_RECL,           // slabs: bricks of the table window that get records (the walk list holds the owned ones among them)
+    FS_N_REDO,           // slabs: trajectories that left the table window and were redone from rho (statistics)
     FS_COUNT = 64,
     // 8 per-XCD work cursors of the persistent trace, one per 128-byte line: device-scope atomics on ONE line
     // serialise at ~88 per microsecond whatever the word (measured: 8 cursors in one line = one cursor)

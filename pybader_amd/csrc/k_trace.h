@@ -325,7 +325,10 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // CACHE: the 512 records of the walkers' OWN brick sit in LDS (s_rec, loaded by the workgroup before its eight waves start:
 // k_ng_trace_g) -- the start record and every step that stays inside the brick (about 40 % of the fetches) read them there,
 // and the own brick, a walk-list brick, needs no brick-label lookup either.  The trace is bound by its L2 requests.
-template <bool OFF32, bool CACHE>
+// WINDOW (slabs): the table covers the planes of a window only (rec_slot); a walker that steps out of it without landing in a
+// trapping region ends with -2 like an undecidable one -- its start voxel goes to `ovf_list`, here the list of the
+// trajectories the caller redoes with records derived from rho (k_ng_trace_list)
+template <bool OFF32, bool CACHE, bool WINDOW = false>
 __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
                                              int *labels, int *first, int *max_list, int *max_count, int max_cap,
@@ -335,7 +338,7 @@ __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__re
     const int v = lin24(g, sx, sy, sz);
     const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
     const int ox8 = sx & ~7, oy8 = sy & ~7, oz8 = sz & ~7;   // origin of the own brick
-    GradRec rec = CACHE ? s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, v);
+    GradRec rec = CACHE ? s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
     bool moving = lab0 != -1;
     int result = -1;
     int px = sx, py = sy, pz = sz, steps = 0;
@@ -376,9 +379,10 @@ __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__re
             // both loads in flight together; a lane at its maximum reloads its own record (harmless)
             int bl = 0;
             const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
+            const bool in_win = !WINDOW || own || plane_in_window(g, px);
             if (own) rec = s_rec[((px & 7) << 6) | ((py & 7) << 3) | (pz & 7)];
             else {
-                rec = fetch_rec_o<OFF32>(G, lq);
+                rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);   // (outside the window: any valid slot, the value is not used)
                 const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
                 bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
             }
@@ -387,7 +391,7 @@ __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__re
             // already); membership undecidable from the window: exact slow kernel (ongrid moves are appended without a
             // membership test, methods.py:513-521)
             const bool arrived = bl > 0 && !at_max;
-            const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps;
+            const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps || (WINDOW && !in_win);
             if (arrived) result = box_max[bl - 1];
             else if (at_max) result = i0;
             else if (undecided) result = -2;
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *
 // (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
 // LEAN 3 / 4 (= 1 / 2 with the brick cache): the workgroup is exactly eight waves, a pull is exactly one brick, and its 512
 // records are copied into LDS (16 KB) before the waves start (see ng_walk_lean).
-template <int K, int LEAN>
+template <int K, int LEAN, bool WINDOW = false>
 __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                        const int *__restrict__ blab, int nb1, int nb2,
                                                        const int *__restrict__ walk, int *fs, int *labels, int *first,
@@ -558,7 +562,8 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 const int b = walk[base >> 3];
                 const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
                 const int t = threadIdx.x;
-                s_rec[t] = fetch_rec(G, lin24(g, b0 * 8 + (t >> 6), b1 * 8 + ((t >> 3) & 7), b2 * 8 + (t & 7)));
+                const int lt = lin24(g, b0 * 8 + (t >> 6), b1 * 8 + ((t >> 3) & 7), b2 * 8 + (t & 7));
+                s_rec[t] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
                 __syncthreads();
             }
             for (;;) {
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 int sx, sy, sz;
                 brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
                 if (LEAN)
-                    ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                    ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                                                 max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0, s_rec);
                 else
                     ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],

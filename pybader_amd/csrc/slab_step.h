@@ -48,7 +48,7 @@ __global__ void k_slab_pack_table(int *tab, const int *__restrict__ max_list, co
                                   const int *slow_count) {
     const int n = fs[FS_N_MAX];
     const bool bad = n > XB_TAB_ROWS || *slow_count > 0 || fs[FS_GROW_RETRY];
-    if (threadIdx.x == 0) { tab[0] = bad ? -1 : n; tab[1] = 0; fs[FS_N_OVF] = *slow_count; }
+    if (threadIdx.x == 0) { tab[0] = bad ? -1 : n; tab[1] = 0; fs[FS_N_REDO] = fs[FS_N_OVF]; fs[FS_N_OVF] = *slow_count; }
     if (bad) return;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int m = max_list[i];
@@ -92,7 +92,9 @@ __global__ __launch_bounds__(1024) void k_slab_merge_list(const int *__restrict_
     __syncthreads();
     if (threadIdx.x == 0) fs[FS_N_MAX] = s_n;
 }
-// counters[18..21): voxels relabelled by applied walker results, stuck results, walkers / results lost to a full part.
+// counters[18..22): voxels relabelled by applied walker results, stuck results, walkers / results lost to a full part, one
+// byte per round: this rank carried walkers on in it (summed over the ranks: how many did -- the scheduler sizes the next
+// pass's rounds by it).
 // blk: the block the last round gathered (its walkers are still travelling: xcnt[3], the same number on every rank)
 __global__ void k_slab_pack_counts(long long *xcnt, const int *counters, const char *blk, int nranks, int rank) {
     long long open = 0, mine = 0;
@@ -102,7 +104,7 @@ __global__ void k_slab_pack_counts(long long *xcnt, const int *counters, const c
         if (r == rank) mine = n;
     }
     xcnt[0] = counters[5]; xcnt[1] = (long long)counters[2] + counters[18]; xcnt[2] = counters[3]; xcnt[3] = open; xcnt[4] = counters[1];
-    xcnt[5] = (long long)counters[19] + counters[20]; xcnt[6] = mine; xcnt[7] = 0;
+    xcnt[5] = (long long)counters[19] + counters[20]; xcnt[6] = mine; xcnt[7] = counters[21];
 }
 // a part that ran full: the surplus is lost (those retraces stay parked and are resolved by the path queries)
 __global__ void k_slab_walk_clamp(int *hdr, int *lost, int cap) {
@@ -136,7 +138,10 @@ __global__ void k_slab_walk_collect(GridL g, const char *blk, int own0, int own1
         else atomicAdd(lost, 1);
     }
 }
-__global__ void k_slab_walk_clamp_in(int *n_in) { if (*n_in > XB_WALK_CAP) *n_in = XB_WALK_CAP; }
+__global__ void k_slab_walk_clamp_in(int *n_in, int *rounds, int round) {
+    if (*n_in > XB_WALK_CAP) *n_in = XB_WALK_CAP;
+    if (*n_in > 0 && round < 4) *rounds |= 1 << (8 * round);
+}
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 static int slab_need_xbuf(xb_ctx *c) {
@@ -351,9 +356,20 @@ int xb_slab_assign_trace(xb_ctx *c) {
             const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
             int *redo = (int *)c->stage;
             const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
-            k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
-                                                                          c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, c->opt_trace_chunk,
-                                                                          c->opt_trace_xcd);
+            // (the lean walker in workgroups of eight waves, one brick per pull, its records through LDS -- as on one GPU --
+            // when the index products fit 24 bits; 32-bit table offsets up to 2^27 window voxels)
+            const bool lean = gl.use24 && c->opt_lean && c->opt_trace_group == 8 && c->opt_trace_cache;
+            const int groups = std::max(1, c->opt_trace_grid / 8);
+            if (lean && (long long)g.wlen * g.nyz <= (1LL << 27))
+                k_ng_trace_g<2, 4, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
+                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, c->opt_trace_xcd);
+            else if (lean)
+                k_ng_trace_g<2, 3, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
+                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, c->opt_trace_xcd);
+            else
+                k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
+                                                                              c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, c->opt_trace_chunk,
+                                                                              c->opt_trace_xcd);
             k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, redo, fs + FS_N_OVF, c->labels, c->first, c->max_list,
                                                           fs + FS_N_MAX, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho,
                                                           c->dist_dev, 0);
@@ -415,7 +431,9 @@ int xb_slab_assign_finish(xb_ctx *c, int64_t *n_maxima, int64_t *status) {
     c->n_boxes = h[FS_N_BOXES];
     c->box_voxels = (long long)h[FS_N_CERTAIN] * BRK * BRK * BRK;
     c->n_walk = h[FS_N_WALK];
-    c->stat_ovf_assign += 0;
+    if (c->opt_dbg & 16)
+        fprintf(stderr, "[slab %d] bricks traced %d, with records %d, trajectories redone beyond the table window %d, regions %d\n", c->slab_rank,
+                h[FS_N_WALK], h[FS_N_RECL], h[FS_N_REDO], h[FS_N_BOXES]);
     const int nmax = h[FS_N_MAX];
     c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
     c->buni_valid = true;
@@ -478,6 +496,7 @@ int xb_slab_refine_pass(xb_ctx *c) {
     HIPCHK(hipGetLastError());
     c->slab_stage = 3;
     c->walk_last = -1;
+    c->walk_round = 0;
     return XB_OK;
 }
 
@@ -499,7 +518,7 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last) {
         HIPCHK(hipMemsetAsync(part, 0, 16, c->stream));
         HIPCHK(hipMemsetAsync(n_in, 0, sizeof(int), c->stream));
         k_slab_walk_collect<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, (Walker *)c->wk_in, n_in, c->counters + 20);
-        k_slab_walk_clamp_in<<<1, 1, 0, c->stream>>>(n_in);
+        k_slab_walk_clamp_in<<<1, 1, 0, c->stream>>>(n_in, c->counters + 21, c->walk_round++);
         WalkerIO wio{};
         wio.in = (const Walker *)c->wk_in;
         wio.out = (Walker *)(part + 16); wio.out_count = (int *)part; wio.out_cap = XB_WALK_CAP1;
@@ -535,6 +554,11 @@ int xb_slab_refine_counts(xb_ctx *c, int64_t *local, int64_t *global) {
     long long loc[XB_XCNT], glo[XB_XCNT];
     for (int i = 0; i < XB_XCNT; i++) { loc[i] = h[i]; glo[i] = h[XB_XCNT + i]; }
     c->list_n = (int)loc[0];
+    if (c->opt_dbg & 16) {
+        HIPCHK(hipMemcpyAsync(c->host_ints + 64, c->counters + 15, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[slab %d] edges %lld, retraces redone from rho %d, exported %lld\n", c->slab_rank, loc[0], c->host_ints[64], loc[2]);
+    }
     c->walk_n_out = 0; c->walk_n_res = 0;
     if (loc[6] > 0 && c->walk_last >= 0) {   // walkers still travelling after the rounds: the scheduler's host loop takes them on
         c->walk_n_out = (int)loc[6];

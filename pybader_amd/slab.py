@@ -148,12 +148,15 @@ class SlabRunner:
             comm.selftest_planes(self.be, self.ranges)
 
     def enable_table_window(self, margin=None):
-        """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks
-        everywhere; default margin: 32 planes, nx / 16 on larger grids -- trajectories that leave the window are redone
-        from rho, 1.4 ms of an 8.8 ms trace at 1024^3 with 32 planes, 0.8 with 64).  Returns whether the window is active."""
+        """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks everywhere).
+        Trajectories that leave the window are redone with records derived from rho, a kernel with a long tail: at 512^3 on
+        eight slabs 32 planes leave 5-9 thousand of them per rank (0.15 ms), 64 planes a few hundred (still 0.1 ms), 128
+        none -- for 80 % more records (+0.07 ms).  Default: a quarter of the axis, at least 32 planes, clamped so that a
+        window remains.  Returns whether the window is active."""
         nx, ny, nz = self.shape
         if margin is None:
-            margin = max(32, nx // 16)
+            fit = ((nx - max(b - a for a, b in self.ranges) - 8) // 2) // 8 * 8
+            margin = max(8, min(max(32, nx // 4), fit))
         ok = (self.comm.size > 1 and hasattr(self.be, 'set_table_window') and nx % 8 == 0 and ny % 8 == 0 and nz % 8 == 0
               and all(a % 8 == 0 and b % 8 == 0 for a, b in self.ranges)
               and (self.x_range[1] - self.x_range[0]) + 2 * (margin + 7) // 8 * 8 < nx)
@@ -162,6 +165,7 @@ class SlabRunner:
         if ok:
             self.be.set_table_window(margin)   # walks beyond it derive their records from rho on the spot
         self.windowed = ok
+        self.table_margin = margin if ok else None
         return ok
 
     # ---- the step with its control flow on the device (csrc/slab_step.h): two host waits per assignment + refinement pass ----
@@ -223,7 +227,7 @@ class SlabRunner:
         # walkers; the rank that owns the plane they entered carries them on.  A fixed number of rounds runs without asking
         # the host whether any walker is left (an empty round costs a few small launches); what still travels afterwards
         # (or needs the exact slow path) is finished by the host-driven loop.
-        rounds = int(os.environ.get('XB_SLAB_WALKER_ROUNDS', '3'))
+        rounds = int(os.environ.get('XB_SLAB_WALKER_ROUNDS', 0)) or getattr(self, '_walker_rounds', 3)
         with _Phase(self, 'walkers'):
             if getattr(self, '_walk_layout', None) is None:
                 self._walk_layout = self.be.slab_walk_layout()
@@ -246,6 +250,10 @@ class SlabRunner:
         if glo[4]:      # rare: some retraces went through the exact slow kernel after the sums were taken
             with _Phase(self, 'sums'):
                 changed, = self.comm.sum(int(loc[1]))
+        # (rounds of the next pass: as many as carried a walker on in this one, two more after a pass that left some travelling
+        # -- those went through the host-driven loop below; every rank sees the same sums)
+        used = max([k + 1 for k in range(4) if (int(glo[7]) >> (8 * k)) & 0xff] or [0])
+        self._walker_rounds = min(6, max(1, used) + (2 if loc[3] else 0))
         if glo[2]:
             self.n_fallbacks += 1
         if loc[3] or glo[5]:

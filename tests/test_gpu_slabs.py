@@ -41,6 +41,7 @@ class ThreadComm:
 
     def exchange_planes(self, backend, which, sends, recvs):
         import torch
+        torch.cuda.synchronize()
         tensor = device_views(backend.ctx)[which]
         self.sh.cur[self.rank] = tensor
         self.sh.barrier.wait()
@@ -65,9 +66,11 @@ class ThreadComm:
         return np.concatenate(self.allgather(np.ascontiguousarray(rows, np.int64)))
 
     # the exchange blocks of the device-driven step: device-to-device copies between the contexts of this one card
+    stream_ordered = True      # (this transport waits for the whole card itself, before and after its copies)
+
     def allgather_block(self, backend, which, parts):
         import torch
-        backend.ctx.sync()
+        torch.cuda.synchronize()
         mine = block_view(backend.ctx, which)
         self.sh.cur[self.rank] = mine
         self.sh.barrier.wait()
@@ -79,7 +82,7 @@ class ThreadComm:
 
     def allreduce_block(self, backend):
         import torch
-        backend.ctx.sync()
+        torch.cuda.synchronize()
         mine = block_view(backend.ctx, 5).view(torch.int64)
         self.sh.cur[self.rank] = mine
         self.sh.barrier.wait()
@@ -112,13 +115,17 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
             else:
                 ctx.synth_density(*synth_args)
             ctx.vacuum_assign(tol, 1.0)
+            w0 = ctx.host_waits()
             nb = runner.assign(method)
+            w1 = ctx.host_waits()
             x0, x1 = runner.x_range
             pre = ctx.download_labels(label_dtype)[x0:x1].copy() if keep_pre else np.zeros((0,) + tuple(shape[1:]), label_dtype)
+            w2 = ctx.host_waits()
             log = runner.refine(mode, iters)
+            w3 = ctx.host_waits()
             post = ctx.download_labels(label_dtype)[x0:x1].copy()
             ch, vo = ctx.charge_sum(1.0, nb)
-            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats(), ctx.memory_stats(), runner.n_device_steps)
+            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats(), ctx.memory_stats(), runner.n_device_steps, (w1 - w0, w3 - w2))
             ctx.close()
         except Exception as e:  # noqa: BLE001
             sh.errors.append(repr(e))
@@ -139,6 +146,7 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
     run_slabs.last_slow = [r[9] for r in res]
     run_slabs.last_memory = [r[10] for r in res]
     run_slabs.last_device_steps = [r[11] for r in res]
+    run_slabs.last_host_waits = [r[12] for r in res]
     print('device-driven steps per rank:', run_slabs.last_device_steps)
     return pre, post, res[0][3], res[0][4], ch, vo, max(r[7] for r in res)
 
@@ -401,3 +409,30 @@ def test_a_slab_rank_holds_slab_sized_table_and_scratch():
         assert table == 32 * (32 + 2 * 8) * 256 * 256          # the window: slab + 8 planes each side
         assert scratch <= 12 * (32 + 2 * 32) * 256 * 256 + (80 << 20)
         assert total < 0.55 * one_total, (total, one_total)     # (18 of 62 B/voxel stay full size; 0.45 at 1024^3 on 8 slabs)
+
+
+@pytest.mark.parametrize('n,size,halo,mode,iters', [(4, 128, 8, 'changed', 2), (8, 256, 16, 'all', 2), (2, 128, 6, 'changed', 2)])
+def test_device_driven_step_waits_once_per_assignment_and_once_per_pass(n, size, halo, mode, iters):
+    """The slab step with its control flow on the device (csrc/slab_step.h): same map as one context, ONE wait of the host
+    for the card per assignment and one per refinement pass (the host-driven calls made about fifteen) -- counted inside
+    the library (xb_host_waits), per rank."""
+    shape = (size,) * 3
+    vl = np.divide(synth.CUBIC6, shape)
+    g = {'dist_mat': distance_matrix(vl), 'T_grad': gradient_transform(vl)}
+    args = (synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, g['dist_mat'], g['T_grad'])
+    ctx.synth_density(*args)
+    ctx.vacuum_assign(None, 1.0)
+    nb = ctx.assign('neargrid')
+    ref_log = ctx.refine(mode, iters)
+    want = ctx.download_labels(np.int32)
+    ctx.close()
+    pre, post, log, maxima, ch, vo, fb = run_slabs(n, g, None, 'neargrid', mode, iters, halo, None, shape=shape, synth_args=args,
+                                                   keep_pre=False, margin=None)
+    assert np.array_equal(post, want) and log == ref_log and len(maxima) == nb
+    assert run_slabs.last_device_steps == [1] * n
+    passes = len(log) if mode == 'all' else 1
+    for a, r in run_slabs.last_host_waits:
+        # (a pass whose walkers outlast the blind rounds hands the rest to the host-driven loop: more waits, same result)
+        assert a == 1 and (r == passes or fb), run_slabs.last_host_waits

@@ -437,3 +437,147 @@ def test_comm_watchdog_ends_the_process_when_a_collective_never_returns():
             "    time.sleep(30)\n") % ROOT
     r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=25, text=True)
     assert r.returncode == 86 and 'ncclCommInitRank (test)' in r.stderr and 'did not complete' in r.stderr
+
+
+def test_block_collectives_over_the_host_transport():
+    """The exchange blocks of the device-driven slab step (csrc/slab_step.h) over the product's host-staged transport, with a
+    mock backend whose blocks are numpy arrays: every rank's part reaches every rank, parts may differ in size, and block
+    5's counters are summed into its second half."""
+    import threading
+    import uuid
+    from pybader_amd import comm as pcomm
+
+    n = 3
+    key = 'blocks_' + uuid.uuid4().hex
+    parts = [(0, 40), (40, 8), (48, 100)]          # (offset, bytes) per rank
+    out, errors = [None] * n, []
+
+    class Backend:
+        def __init__(self, rank):
+            self.blocks = {2: np.zeros(148, np.uint8), 5: np.zeros(128, np.uint8)}
+            off, m = parts[rank]
+            self.blocks[2][off:off + m] = rank + 1
+            self.blocks[5][:64] = np.frombuffer((np.arange(8, dtype=np.int64) * (rank + 1)).tobytes(), np.uint8)
+
+        def slab_block_copy(self, which, host, off, to_device):
+            if to_device:
+                self.blocks[which][off:off + host.size] = host
+            else:
+                host[:] = self.blocks[which][off:off + host.size]
+
+    def work(rank):
+        try:
+            store = pcomm.SocketStore(rank, n, key=key, timeout=60.0)
+            hc = pcomm.HostComm(store)
+            be = Backend(rank)
+            hc.allgather_block(be, 2, parts)
+            hc.allreduce_block(be)
+            out[rank] = (be.blocks[2].copy(), np.frombuffer(be.blocks[5].tobytes(), np.int64).copy())
+            store.barrier()
+            store.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    want = np.concatenate([np.full(m, r + 1, np.uint8) for r, (_, m) in enumerate(parts)])
+    for r in range(n):
+        assert np.array_equal(out[r][0], want)
+        assert np.array_equal(out[r][1][:8], np.arange(8) * (r + 1)) and np.array_equal(out[r][1][8:], np.arange(8) * 6)
+
+
+def test_device_driven_step_scheduling_with_a_mock_backend():
+    """The scheduler's side of the device-driven step: call order (masks, blocks 0-3, trace, block 4, finish), the repeat
+    when the region growth asks for its long schedule (status 1), the hand-over to the host-driven calls (status 2), the
+    walker rounds (block 6 / 7 alternately, results from the second gather on) and how the next pass's rounds follow the
+    rounds that carried walkers."""
+    calls = []
+
+    class Comm:
+        rank, size = 0, 2
+
+        def allgather(self, obj):
+            return [obj, obj]
+
+        def sum(self, *v):
+            return [2 * int(x) for x in v]
+
+        def allgather_block(self, be, which, parts):
+            calls.append(('gather', which, tuple(parts[0])))
+
+        def allreduce_block(self, be):
+            calls.append(('reduce',))
+
+        def exchange_planes(self, be, which, sends, recvs):
+            calls.append(('planes', which))
+
+        stream_ordered = True
+
+    class Backend:
+        finishes = [(0, 1), (8, 0)]
+        counts = None
+
+        def set_grid(self, *a):
+            pass
+
+        def set_table_window(self, m):
+            calls.append(('window', m))
+
+        def set_option(self, k, v):
+            calls.append(('option', k, v))
+
+        def slab_supported(self, n):
+            return True
+
+        def slab_block(self, which):
+            return 0, 1000, 100 * which, 10
+
+        def slab_assign_masks(self, rank, n):
+            calls.append(('masks', rank, n))
+
+        def slab_assign_trace(self):
+            calls.append(('trace',))
+
+        def slab_assign_finish(self):
+            calls.append(('finish',))
+            return self.finishes.pop(0)
+
+        def maxima(self):
+            return np.zeros((8, 3), np.int64)
+
+        def slab_refine_pass(self):
+            calls.append(('pass',))
+
+        def slab_walk_layout(self):
+            return [1000, 500, 100, 600, 400]
+
+        def slab_walkers_round(self, src, last):
+            calls.append(('round', src, bool(last)))
+
+        def slab_refine_counts(self):
+            return self.counts
+
+    be = Backend()
+    runner = slab.SlabRunner(be, Comm(), (64, 64, 64), np.zeros((3, 3, 3)), np.eye(3), halo=8)
+    assert runner.enable_table_window() and calls == [('window', 8)]
+    del calls[:]
+    assert runner.assign('neargrid') == 8 and runner.n_device_steps == 1
+    one = [('masks', 0, 2), ('gather', 0, (0, 10)), ('gather', 1, (100, 10)), ('gather', 2, (200, 10)), ('gather', 3, (300, 10)), ('trace',),
+           ('gather', 4, (400, 10)), ('finish',)]
+    assert calls == [('option', 24, 1)] + one + one
+    # a pass whose walkers were carried on in rounds 0 and 1 (bytes of glo[7]), none left: three rounds now, two next time
+    del calls[:]
+    be.counts = (np.array([50, 0, 7, 0, 0, 0, 0, 0x0101]), np.array([100, 0, 14, 0, 0, 0, 0, 0x0201]))
+    assert runner.refine('changed', 2) == [(100, 0), (0, 0)]
+    rounds = [c for c in calls if c[0] in ('gather', 'round')]
+    assert rounds == [('gather', 6, (0, 500)), ('round', 0, False), ('gather', 7, (0, 100)), ('gather', 7, (600, 400)), ('round', 1, False),
+                      ('gather', 6, (0, 100)), ('gather', 6, (600, 400)), ('round', 0, False), ('gather', 7, (0, 100)), ('gather', 7, (600, 400)),
+                      ('round', 1, True)]
+    assert calls[0] == ('planes', 0) and calls[1] == ('pass',) and ('reduce',) in calls and runner._walker_rounds == 2
+    # status 2: this density goes to the host-driven calls, for good
+    be.finishes = [(0, 2)]
+    assert runner._assign_device_step() is None
