@@ -295,7 +295,7 @@ def main():
         ctx.set_option(3, int(os.environ['XB_OPT_DBG']))
     if 'XB_OPT_TPB' in os.environ:
         ctx.set_option(2, int(os.environ['XB_OPT_TPB']))
-    for key in range(7, 24):
+    for key in range(7, 27):
         if f'XB_OPT_{key}' in os.environ:
             ctx.set_option(key, int(os.environ[f'XB_OPT_{key}']))
     if 'XB_OPT_EC_GROUPS' in os.environ:

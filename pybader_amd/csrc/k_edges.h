@@ -931,7 +931,7 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
         for (int iy = -1; iy < 2; iy++) rows[(ix + 1) * 3 + iy + 1] = (tx * g.ny + wrapi(y + iy, g.ny)) * g.nz;
     }
     // One atomicAdd per later listed neighbour, issued together in 10 slots (a voxel rarely has more; the rest is handled
-    // one by one below; an empty slot adds 0 to v's own word, harmless).  The atomics of a workgroup share one CU's
+    // one by one below).  The atomics of a workgroup share one CU's
     // address unit, so 10 instead of one per box position matters.
     const ec_word delta = d == 1 ? 0xFFull : ~0ull;  // +0x100 - 1  |  -1  (the count never borrows: it counts this very neighbour)
     ec_word o[10];
@@ -943,7 +943,8 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
         later &= later - 1;
         const int u = hit ? ec_box_voxel(g, rows, z, j) : v;
         uu[s] = hit ? u : -1;
-        o[s] = atomicAdd(pend + u, hit ? delta : 0ull);
+        o[s] = 0;
+        if (hit) o[s] = atomicAdd(pend + u, delta);   // (predicated: an empty slot issues nothing; -0.15 ms of 3.5 at 512^3)
     }
 #pragma unroll
     for (int s = 0; s < 10; s++) {

@@ -97,8 +97,23 @@ class ThreadComm:
         self.sh.barrier.wait()
 
 
+class ShadowRcclComm(ThreadComm):
+    """ThreadComm whose block exchanges first go through the library's RCCL entry points on a ONE-rank communicator per
+    context (the collectives are identities there: this rank's part from itself, sums of one) -- the calls, pointers and
+    byte ranges of a node run, in the order of a node run -- and then do the real copies between the contexts."""
+
+    def allgather_block(self, backend, which, parts):
+        off, n = parts[self.rank]
+        backend.ctx.comm_allgather_block(which, [off], [n])
+        super().allgather_block(backend, which, parts)
+
+    def allreduce_block(self, backend):
+        backend.ctx.comm_allreduce_block()
+        super().allreduce_block(backend)
+
+
 def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None, synth_args=None, label_dtype=np.int32,
-              keep_pre=True, margin=8):
+              keep_pre=True, margin=8, comm_cls=ThreadComm):
     """rho=None + synth_args=(lattice, atoms, background): every context generates the density on the device"""
     shape = rho.shape if rho is not None else tuple(shape)
     sh = Shared(n)
@@ -107,7 +122,9 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
     def work(rank):
         try:
             ctx = _lib.Context(0)
-            comm = ThreadComm(sh, rank)
+            comm = comm_cls(sh, rank)
+            if comm_cls is ShadowRcclComm:
+                ctx.comm_init(0, 1, ctx.comm_unique_id())
             runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), comm, shape, g['dist_mat'], g['T_grad'], halo=halo)
             win = runner.enable_table_window(margin) if window else False
             if rho is not None:
@@ -436,3 +453,15 @@ def test_device_driven_step_waits_once_per_assignment_and_once_per_pass(n, size,
     for a, r in run_slabs.last_host_waits:
         # (a pass whose walkers outlast the blind rounds hands the rest to the host-driven loop: more waits, same result)
         assert a == 1 and (r == passes or fb), run_slabs.last_host_waits
+
+
+def test_device_driven_step_issues_its_rccl_collectives():
+    """The step's block collectives through xb_comm_allgather_block / xb_comm_allreduce_block (csrc/slab_step.h) with real
+    blocks, in the order of a node run: each of the two contexts owns a one-rank RCCL communicator (two ranks of ONE
+    communicator need two cards), so every collective is an identity and the test transport moves the peers' parts
+    afterwards.  The map must come out as always."""
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    pre, post, log, maxima, ch, vo, fb = run_slabs(2, g, rho, 'neargrid', 'all', 2, 8, None, comm_cls=ShadowRcclComm)
+    assert run_slabs.last_device_steps == [1, 1]
+    assert np.array_equal(pre, g['ng_F'].astype(np.int32)) and np.array_equal(post, g['ng_all_2'].astype(np.int32))
