@@ -95,7 +95,7 @@ SYMBOLS = {
     'xb_slab_assign_finish': (_int, [_vp, _pi64, _pi64]),
     'xb_slab_refine_pass': (_int, [_vp]),
     'xb_slab_walkers_round': (_int, [_vp, _int, _int]),
-    'xb_slab_walk_layout': (_int, [_pi64]),
+    'xb_slab_walk_layout': (_int, [_vp, _pi64]),
     'xb_slab_refine_counts': (_int, [_vp, _pi64, _pi64]),
     'xb_slab_block': (_int, [_vp, _int, C.POINTER(_vp), _pi64, _pi64, _pi64]),
     'xb_slab_block_copy': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
@@ -527,7 +527,7 @@ class Context:
     def slab_walk_layout(self):
         """(part bytes, header + walkers of round 0, header + walkers of later rounds, results offset, results bytes)"""
         out = np.zeros(5, np.int64)
-        check(self.lib.xb_slab_walk_layout(out.ctypes.data_as(_pi64)))
+        check(self.lib.xb_slab_walk_layout(self.h, out.ctypes.data_as(_pi64)))
         return [int(v) for v in out]
 
     def slab_refine_counts(self):

@@ -119,7 +119,7 @@ struct xb_ctx {
     int slab_rank = 0, slab_nranks = 0, slab_stage = 0;
     void *wbuf[2] = {nullptr, nullptr};   // ... blocks 6 / 7: the walkers of a refinement pass and their results, one part per rank
     void *wk_in = nullptr;                // the walkers this rank carries on in a round (+ their count)
-    int wbuf_ranks = 0, walk_last = -1, walk_round = 0;
+    int wbuf_ranks = 0, walk_last = -1, walk_round = 0, wcap = 0;
     int opt_async_comm = 0;    // collectives return without waiting (they are ordered on the context's stream); the device-driven slab step sets it
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
     int opt_lean_mem = 1;      // slabs: table, `list` and `stage` sized by the slab instead of the grid (0: everything full size)

@@ -26,13 +26,13 @@
 #define XB_SLAB_RANKS_MAX 64
 #define XB_XCNT 8                           // counters of a refinement pass (int64): edges, changed, escaped, walkers, overflows
 // blocks 6 / 7: the walkers of a refinement pass (retraces that left their rank's valid planes, k_edges.h) and the results of
-// the ones carried on, one part per rank: [walkers, results, 0, 0][XB_WALK_CAP walkers][XB_WALK_CAP (start voxel, label) pairs].
+// the ones carried on, one part per rank: [walkers, results, 0, 0][cap walkers][cap (start voxel, label) pairs].
 // The exchanges are blind (no count goes through the host), so the parts travel at fixed sizes: the pass itself may export
-// XB_WALK_CAP walkers (2 % of the edge voxels of an eighth of 512^3 is 13 000), the later rounds -- walkers that crossed a whole
-// slab -- XB_WALK_CAP1; what does not fit stays parked and is finished by the host-driven path queries.
-#define XB_WALK_CAP 32768
-#define XB_WALK_CAP1 4096
-#define XB_WALK_PART (16 + (size_t)XB_WALK_CAP * (sizeof(Walker) + 8))
+// `cap` walkers (2 % of the edge voxels of an eighth of 512^3 is 13 000), the later rounds -- walkers that crossed a whole
+// slab -- cap / 8; what does not fit stays parked and is finished by the host-driven path queries.
+// (the number of escapes follows the area of a plane: cap = ny nz / 8, at least 32768; a later round an eighth of it)
+__host__ __device__ __forceinline__ size_t walk_part(int cap) { return 16 + (size_t)cap * (sizeof(Walker) + 8); }
+static inline int walk_cap_for(const Grid &g) { return (int)std::min<long long>(std::max<long long>(32768, (long long)g.nyz / 8), 1 << 20); }
 
 // ---- kernels of the exchanges ------------------------------------------------------------------------------------------
 __global__ void k_slab_flag(const int *fs, int *flags, int rank) { flags[rank] = fs[FS_TIES] != 0; }
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(1024) void k_slab_merge_list(const int *__restrict_
 // byte per round: this rank carried walkers on in it (summed over the ranks: how many did -- the scheduler sizes the next
 // pass's rounds by it).
 // blk: the block the last round gathered (its walkers are still travelling: xcnt[3], the same number on every rank)
-__global__ void k_slab_pack_counts(long long *xcnt, const int *counters, const char *blk, int nranks, int rank) {
+__global__ void k_slab_pack_counts(long long *xcnt, const int *counters, const char *blk, int nranks, int rank, int cap) {
     long long open = 0, mine = 0;
     for (int r = 0; blk && r < nranks; r++) {
-        const int n = min(reinterpret_cast<const int *>(blk + r * XB_WALK_PART)[0], XB_WALK_CAP);
+        const int n = min(reinterpret_cast<const int *>(blk + r * walk_part(cap))[0], cap);
         open += n;
         if (r == rank) mine = n;
     }
@@ -107,15 +107,15 @@ __global__ void k_slab_pack_counts(long long *xcnt, const int *counters, const c
     xcnt[5] = (long long)counters[19] + counters[20]; xcnt[6] = mine; xcnt[7] = counters[21];
 }
 // a part that ran full: the surplus is lost (those retraces stay parked and are resolved by the path queries)
-__global__ void k_slab_walk_clamp(int *hdr, int *lost, int cap) {
+__global__ void k_slab_walk_clamp(int *hdr, int *lost, int cap, int rcap) {
     if (hdr[0] > cap) { atomicAdd(lost, hdr[0] - cap); hdr[0] = cap; }
-    if (hdr[1] > XB_WALK_CAP) { atomicAdd(lost, hdr[1] - XB_WALK_CAP); hdr[1] = XB_WALK_CAP; }
+    if (hdr[1] > rcap) { atomicAdd(lost, hdr[1] - rcap); hdr[1] = rcap; }
 }
 // the results of every rank's part (blockIdx.y), applied by the owner of the start voxel (k_walkers_apply)
-__global__ void k_slab_walk_apply(GridL g, const char *blk, int own0, int own1, int *labels, int8_t *known, int *changed, int *stuck) {
-    const char *part = blk + blockIdx.y * XB_WALK_PART;
-    const int n = min(reinterpret_cast<const int *>(part)[1], XB_WALK_CAP);
-    const int *res = reinterpret_cast<const int *>(part + 16 + (size_t)XB_WALK_CAP * sizeof(Walker));
+__global__ void k_slab_walk_apply(GridL g, const char *blk, int own0, int own1, int *labels, int8_t *known, int *changed, int *stuck, int cap) {
+    const char *part = blk + blockIdx.y * walk_part(cap);
+    const int n = min(reinterpret_cast<const int *>(part)[1], cap);
+    const int *res = reinterpret_cast<const int *>(part + 16 + (size_t)cap * sizeof(Walker));
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const int v = res[2 * t], nv = res[2 * t + 1];
         const int x = v / g.nyz;
@@ -126,20 +126,20 @@ __global__ void k_slab_walk_apply(GridL g, const char *blk, int own0, int own1, 
     }
 }
 // the walkers of every rank's part that arrive on an owned plane -> in[0 .. *n_in)
-__global__ void k_slab_walk_collect(GridL g, const char *blk, int own0, int own1, Walker *in, int *n_in, int *lost) {
-    const char *part = blk + blockIdx.y * XB_WALK_PART;
-    const int n = min(reinterpret_cast<const int *>(part)[0], XB_WALK_CAP);
+__global__ void k_slab_walk_collect(GridL g, const char *blk, int own0, int own1, Walker *in, int *n_in, int *lost, int cap) {
+    const char *part = blk + blockIdx.y * walk_part(cap);
+    const int n = min(reinterpret_cast<const int *>(part)[0], cap);
     const Walker *w = reinterpret_cast<const Walker *>(part + 16);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const int qx = w[t].lq / g.nyz;
         if (qx < own0 || qx >= own1) continue;
         const int k = atomicAdd(n_in, 1);
-        if (k < XB_WALK_CAP) in[k] = w[t];
+        if (k < cap) in[k] = w[t];
         else atomicAdd(lost, 1);
     }
 }
-__global__ void k_slab_walk_clamp_in(int *n_in, int *rounds, int round) {
-    if (*n_in > XB_WALK_CAP) *n_in = XB_WALK_CAP;
+__global__ void k_slab_walk_clamp_in(int *n_in, int *rounds, int round, int cap) {
+    if (*n_in > cap) *n_in = cap;
     if (*n_in > 0 && round < 4) *rounds |= 1 << (8 * round);
 }
 
@@ -155,17 +155,18 @@ static inline int *slab_flags(xb_ctx *c) { return (int *)c->xbuf; }             
 static inline long long *slab_counts(xb_ctx *c) { return (long long *)((char *)c->xbuf + 512); }   // local [0, 8), summed [8, 16)
 static inline int *slab_tables(xb_ctx *c) { return (int *)((char *)c->xbuf + 1024); }
 static int slab_need_wbuf(xb_ctx *c) {
-    const int n = std::max(c->slab_nranks, 1);
-    if (c->wbuf[0] && c->wbuf_ranks >= n) return XB_OK;
+    const int n = std::max(c->slab_nranks, 1), cap = walk_cap_for(c->g);
+    if (c->wbuf[0] && c->wbuf_ranks >= n && c->wcap == cap) return XB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 2; k++) { (void)hipFree(c->wbuf[k]); c->wbuf[k] = nullptr; }
     (void)hipFree(c->wk_in); c->wk_in = nullptr;
     for (int k = 0; k < 2; k++) {
-        HIPCHK(hipMalloc(&c->wbuf[k], (size_t)n * XB_WALK_PART));
-        HIPCHK(hipMemsetAsync(c->wbuf[k], 0, (size_t)n * XB_WALK_PART, c->stream));
+        HIPCHK(hipMalloc(&c->wbuf[k], (size_t)n * walk_part(cap)));
+        HIPCHK(hipMemsetAsync(c->wbuf[k], 0, (size_t)n * walk_part(cap), c->stream));
     }
-    HIPCHK(hipMalloc(&c->wk_in, (size_t)XB_WALK_CAP * sizeof(Walker) + 16));
+    HIPCHK(hipMalloc(&c->wk_in, (size_t)cap * sizeof(Walker) + 16));
     c->wbuf_ranks = n;
+    c->wcap = cap;
     return XB_OK;
 }
 
@@ -247,7 +248,7 @@ int xb_slab_block(xb_ctx *c, int which, void **dev_ptr, int64_t *bytes_total, in
     else if (which == 5) { p = slab_counts(c); total = 2 * XB_XCNT * 8; off = 0; own = XB_XCNT * 8; }
     else if (which == 6 || which == 7) {
         if (int rc = slab_need_wbuf(c)) return rc;
-        p = c->wbuf[which - 6]; total = (int64_t)c->slab_nranks * XB_WALK_PART; off = (int64_t)c->slab_rank * XB_WALK_PART; own = XB_WALK_PART;
+        p = c->wbuf[which - 6]; total = (int64_t)c->slab_nranks * walk_part(c->wcap); off = (int64_t)c->slab_rank * walk_part(c->wcap); own = walk_part(c->wcap);
     }
     else return fail(XB_E_ARG, "xb_slab_block: unknown block %d", which);
     if (dev_ptr) *dev_ptr = p;
@@ -258,13 +259,15 @@ int xb_slab_block(xb_ctx *c, int which, void **dev_ptr, int64_t *bytes_total, in
 }
 // what travels of a part of blocks 6 / 7: [0] bytes of a part, [1] header + walkers of the pass itself (round 0), [2] header +
 // walkers of a later round, [3] offset and [4] bytes of the results
-int xb_slab_walk_layout(int64_t out[5]) {
+int xb_slab_walk_layout(xb_ctx *c, int64_t out[5]) {
+    NEED_GRID_RAW("xb_slab_walk_layout");
     if (!out) return fail(XB_E_ARG, "xb_slab_walk_layout: null argument");
-    out[0] = (int64_t)XB_WALK_PART;
-    out[1] = 16 + (int64_t)XB_WALK_CAP * sizeof(Walker);
-    out[2] = 16 + (int64_t)XB_WALK_CAP1 * sizeof(Walker);
-    out[3] = 16 + (int64_t)XB_WALK_CAP * sizeof(Walker);
-    out[4] = (int64_t)XB_WALK_CAP * 8;
+    const int cap = walk_cap_for(c->g);
+    out[0] = (int64_t)walk_part(cap);
+    out[1] = 16 + (int64_t)cap * sizeof(Walker);
+    out[2] = 16 + (int64_t)(cap / 8) * sizeof(Walker);
+    out[3] = 16 + (int64_t)cap * sizeof(Walker);
+    out[4] = (int64_t)cap * 8;
     return XB_OK;
 }
 // host-staged transports: bytes [off, off + bytes) of a block to / from the host (waits)
@@ -478,12 +481,12 @@ int xb_slab_refine_pass(xb_ctx *c) {
                                    g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
         // the deferred retraces in `stage` (at most one per owned voxel); the walkers go straight to this rank's part of block 6
         int *defer = (int *)c->stage;
-        char *part = (char *)c->wbuf[0] + (size_t)c->slab_rank * XB_WALK_PART;
+        char *part = (char *)c->wbuf[0] + (size_t)c->slab_rank * walk_part(c->wcap);
         HIPCHK(hipMemsetAsync(part, 0, 16, c->stream));
         HIPCHK(hipMemsetAsync(c->counters + 18, 0, 4 * sizeof(int), c->stream));
         WalkerIO wio{};
         wio.out = (Walker *)(part + 16); wio.out_count = (int *)part;
-        wio.out_cap = XB_WALK_CAP;
+        wio.out_cap = c->wcap;
         const unsigned grid = (unsigned)std::min<long long>(nblocks((long long)(g.x1 - g.x0) * g.nyz / 16), 1 << 20);
         k_refine_trace<2, false><<<grid, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, c->counters + 5, c->counters + 2,
                                                               c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev,
@@ -492,7 +495,7 @@ int xb_slab_refine_pass(xb_ctx *c) {
                                                             c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev,
                                                             brec, nullptr, nullptr, 0, slab_regions, wio);
     }
-    k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)((char *)c->wbuf[0] + (size_t)c->slab_rank * XB_WALK_PART), c->counters + 20, XB_WALK_CAP);
+    k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)((char *)c->wbuf[0] + (size_t)c->slab_rank * walk_part(c->wcap)), c->counters + 20, c->wcap, c->wcap);
     HIPCHK(hipGetLastError());
     c->slab_stage = 3;
     c->walk_last = -1;
@@ -511,29 +514,30 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last) {
     const GridL gl = light(g);
     const char *blk = (const char *)c->wbuf[src];
     const dim3 pgrid(8, c->slab_nranks);
-    k_slab_walk_apply<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, c->labels, c->known, c->counters + 18, c->counters + 19);
+    const int cap = c->wcap;
+    k_slab_walk_apply<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, c->labels, c->known, c->counters + 18, c->counters + 19, cap);
     if (!last) {
-        char *part = (char *)c->wbuf[1 - src] + (size_t)c->slab_rank * XB_WALK_PART;
-        int *n_in = (int *)((char *)c->wk_in + (size_t)XB_WALK_CAP * sizeof(Walker));
+        char *part = (char *)c->wbuf[1 - src] + (size_t)c->slab_rank * walk_part(cap);
+        int *n_in = (int *)((char *)c->wk_in + (size_t)cap * sizeof(Walker));
         HIPCHK(hipMemsetAsync(part, 0, 16, c->stream));
         HIPCHK(hipMemsetAsync(n_in, 0, sizeof(int), c->stream));
-        k_slab_walk_collect<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, (Walker *)c->wk_in, n_in, c->counters + 20);
-        k_slab_walk_clamp_in<<<1, 1, 0, c->stream>>>(n_in, c->counters + 21, c->walk_round++);
+        k_slab_walk_collect<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, (Walker *)c->wk_in, n_in, c->counters + 20, cap);
+        k_slab_walk_clamp_in<<<1, 1, 0, c->stream>>>(n_in, c->counters + 21, c->walk_round++, cap);
         WalkerIO wio{};
         wio.in = (const Walker *)c->wk_in;
-        wio.out = (Walker *)(part + 16); wio.out_count = (int *)part; wio.out_cap = XB_WALK_CAP1;
-        wio.res = (int *)(part + 16 + (size_t)XB_WALK_CAP * sizeof(Walker)); wio.res_count = (int *)part + 1;
+        wio.out = (Walker *)(part + 16); wio.out_count = (int *)part; wio.out_cap = cap / 8;
+        wio.res = (int *)(part + 16 + (size_t)cap * sizeof(Walker)); wio.res_count = (int *)part + 1;
         wio.own0 = g.x0; wio.own1 = g.x1;
         const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
         const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && (c->grad_rule == 2 || c->slab_sparse) &&
                                    g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
-        k_refine_trace<2, true, true><<<XB_WALK_CAP / TPB, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, nullptr, 0, n_in, c->counters + 2,
+        k_refine_trace<2, true, true><<<std::min(cap / TPB, 512), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, nullptr, 0, n_in, c->counters + 2,
                                                                               c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho,
                                                                               c->dist_dev, brec, nullptr, nullptr, 0, slab_regions, wio);
-        k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)part, c->counters + 20, XB_WALK_CAP1);
+        k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)part, c->counters + 20, cap / 8, cap);
     } else {
-        k_slab_pack_counts<<<1, 1, 0, c->stream>>>(slab_counts(c), c->counters, blk, c->slab_nranks, c->slab_rank);
+        k_slab_pack_counts<<<1, 1, 0, c->stream>>>(slab_counts(c), c->counters, blk, c->slab_nranks, c->slab_rank, cap);
         c->walk_last = src;
     }
     HIPCHK(hipGetLastError());
@@ -563,7 +567,7 @@ int xb_slab_refine_counts(xb_ctx *c, int64_t *local, int64_t *global) {
     if (loc[6] > 0 && c->walk_last >= 0) {   // walkers still travelling after the rounds: the scheduler's host loop takes them on
         c->walk_n_out = (int)loc[6];
         c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
-        const char *part = (const char *)c->wbuf[c->walk_last] + (size_t)c->slab_rank * XB_WALK_PART;
+        const char *part = (const char *)c->wbuf[c->walk_last] + (size_t)c->slab_rank * walk_part(c->wcap);
         if (int rc = download_pinned(c, c->walk_host.data(), part + 16, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
     }
     const int novf = (int)loc[4];
