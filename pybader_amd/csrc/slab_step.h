@@ -112,7 +112,12 @@ __global__ void k_slab_walk_clamp(int *hdr, int *lost, int cap, int rcap) {
     if (hdr[1] > rcap) { atomicAdd(lost, hdr[1] - rcap); hdr[1] = rcap; }
 }
 // the results of every rank's part (blockIdx.y), applied by the owner of the start voxel (k_walkers_apply)
-__global__ void k_slab_walk_apply(GridL g, const char *blk, int own0, int own1, int *labels, int8_t *known, int *changed, int *stuck, int cap) {
+__global__ void k_slab_walk_apply(GridL g, const char *blk, int own0, int own1, int *labels, int8_t *known, int *changed, int *stuck, int cap,
+                                  int *next_hdr, int *n_in) {
+    if (next_hdr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) {   // (what the round after this kernel counts into)
+        if (threadIdx.x < 4) next_hdr[threadIdx.x] = 0;
+        else *n_in = 0;
+    }
     const char *part = blk + blockIdx.y * walk_part(cap);
     const int n = min(reinterpret_cast<const int *>(part)[1], cap);
     const int *res = reinterpret_cast<const int *>(part + 16 + (size_t)cap * sizeof(Walker));
@@ -470,8 +475,8 @@ int xb_slab_refine_pass(xb_ctx *c) {
     c->buni_valid = false;
     c->walk_n_out = 0; c->walk_n_res = 0; c->walk_out_dev = nullptr;
     c->walk_host.clear(); c->res_host.clear();
-    HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
-    HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters, 0, 5 * sizeof(int), c->stream));           // overflows, changed, escaped ...
+    HIPCHK(hipMemsetAsync(c->counters + 6, 0, 18 * sizeof(int), c->stream));      // ... deferred [15], walker statistics [18..22) (the sweep's own counts [6], [22], [23] are spent)
     {
         ScopedTimer t(c, 3);
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
@@ -483,7 +488,6 @@ int xb_slab_refine_pass(xb_ctx *c) {
         int *defer = (int *)c->stage;
         char *part = (char *)c->wbuf[0] + (size_t)c->slab_rank * walk_part(c->wcap);
         HIPCHK(hipMemsetAsync(part, 0, 16, c->stream));
-        HIPCHK(hipMemsetAsync(c->counters + 18, 0, 4 * sizeof(int), c->stream));
         WalkerIO wio{};
         wio.out = (Walker *)(part + 16); wio.out_count = (int *)part;
         wio.out_cap = c->wcap;
@@ -515,12 +519,11 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last) {
     const char *blk = (const char *)c->wbuf[src];
     const dim3 pgrid(8, c->slab_nranks);
     const int cap = c->wcap;
-    k_slab_walk_apply<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, c->labels, c->known, c->counters + 18, c->counters + 19, cap);
+    char *part = (char *)c->wbuf[1 - src] + (size_t)c->slab_rank * walk_part(cap);
+    int *n_in = (int *)((char *)c->wk_in + (size_t)cap * sizeof(Walker));
+    k_slab_walk_apply<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, c->labels, c->known, c->counters + 18, c->counters + 19, cap,
+                                                    last ? nullptr : (int *)part, n_in);
     if (!last) {
-        char *part = (char *)c->wbuf[1 - src] + (size_t)c->slab_rank * walk_part(cap);
-        int *n_in = (int *)((char *)c->wk_in + (size_t)cap * sizeof(Walker));
-        HIPCHK(hipMemsetAsync(part, 0, 16, c->stream));
-        HIPCHK(hipMemsetAsync(n_in, 0, sizeof(int), c->stream));
         k_slab_walk_collect<<<pgrid, 256, 0, c->stream>>>(gl, blk, g.x0, g.x1, (Walker *)c->wk_in, n_in, c->counters + 20, cap);
         k_slab_walk_clamp_in<<<1, 1, 0, c->stream>>>(n_in, c->counters + 21, c->walk_round++, cap);
         WalkerIO wio{};

@@ -34,6 +34,9 @@ sys.setswitchinterval(2e-5)   # the ranks are threads here: a rank coming back f
 class LockedBackend(slab.GpuBackend):
     """every library call of this rank runs alone on the card; its wall time is booked to the rank"""
 
+    # calls that never touch the card (host-side state of the context): no lock, no device sync, nothing booked
+    HOST_ONLY = {'slab_supported', 'slab_block', 'slab_walk_layout', 'maxima', 'host_waits', 'set_option', 'memory_stats', 'box_stats'}
+
     def __init__(self, ctx, book):
         super().__init__(ctx, 0)
         self.book = book
@@ -41,7 +44,7 @@ class LockedBackend(slab.GpuBackend):
 
     def __getattr__(self, name):
         f = getattr(self.ctx, name)
-        if not callable(f) or name == 'sync':
+        if not callable(f) or name == 'sync' or name in self.HOST_ONLY:
             return f
 
         def call(*a, **k):
