@@ -531,7 +531,10 @@ struct WalkerIO {
 };
 #define XB_WALKER_STUCK (-2147483647 - 1)
 
-template <int K, bool RHO, bool RESUME = false>
+// EXPORT (slabs, device-driven step): the lean instantiation hands a retrace that leaves the valid planes over as a walker
+// itself (it holds the whole state) instead of deferring it to the from-rho instantiation, which walked it again from its
+// start only to export it at the same voxel.
+template <int K, bool RHO, bool RESUME = false, bool EXPORT = false>
 __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__restrict__ G, int *labels,
                                                       int8_t *known, const int *__restrict__ list, int n_host,
                                                       const int *n_dev, int *changed, int *escaped, int *ovf_list,
@@ -651,9 +654,9 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                         else nr.key = key_floor(rho[lq]);
                     }
                     if (!ok_plane) {
-                        result = (RHO || !defer_list) ? -4 : -5;   // (lean kernel on a slab: the from-rho pass redoes and exports it)
+                        result = (RHO || EXPORT || !defer_list) ? -4 : -5;   // (lean kernel on a slab without EXPORT: the from-rho pass redoes and exports it)
                         moving = false;
-                        if (RHO && K == 2 && wio.out) {   // hand the walker over as it arrives at q
+                        if ((RHO || EXPORT) && K == 2 && wio.out) {   // hand the walker over as it arrives at q
                             const int k = atomicAdd(wio.out_count, 1);
                             if (k < wio.out_cap) {
                                 Walker wk;

@@ -492,9 +492,9 @@ int xb_slab_refine_pass(xb_ctx *c) {
         wio.out = (Walker *)(part + 16); wio.out_count = (int *)part;
         wio.out_cap = c->wcap;
         const unsigned grid = (unsigned)std::min<long long>(nblocks((long long)(g.x1 - g.x0) * g.nyz / 16), 1 << 20);
-        k_refine_trace<2, false><<<grid, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, c->counters + 5, c->counters + 2,
+        k_refine_trace<2, false, false, true><<<grid, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, c->counters + 5, c->counters + 2,
                                                               c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev,
-                                                              brec, defer, c->counters + 15, regions_ok, slab_regions, WalkerIO{});
+                                                              brec, defer, c->counters + 15, regions_ok, slab_regions, wio);
         k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, defer, 0, c->counters + 15, c->counters + 2,
                                                             c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev,
                                                             brec, nullptr, nullptr, 0, slab_regions, wio);
