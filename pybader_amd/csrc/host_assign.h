@@ -1,0 +1,637 @@
+// host_assign.h -- host side, part 3: the assignments.  xb_assign_trace / xb_assign_finish (host-driven: slabs without the
+// device-driven step, ongrid, grids that are not whole bricks), assign_neargrid_fused (one GPU, control flow on the
+// device, one host wait) and xb_assign.
+
+// The caller synchronises the stream before the buffer is reused.
+static int upload_pinned(xb_ctx *c, void *dst, const void *src, size_t bytes, size_t slot = 0) {
+    if (!bytes) return XB_OK;
+    if (slot + bytes > c->pin_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const size_t want = std::max<size_t>(2 * (slot + bytes), 1 << 20);
+        char *p = nullptr;
+        HIPCHK(hipHostMalloc(&p, want));
+        if (c->pin && slot) memcpy(p, c->pin, slot);
+        hipHostFree(c->pin);
+        c->pin = p; c->pin_bytes = want;
+    }
+    memcpy(c->pin + slot, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, c->pin + slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return XB_OK;
+}
+// device -> host the same way (waits for the stream)
+static int download_pinned(xb_ctx *c, void *dst, const void *src_dev, size_t bytes) {
+    if (!bytes) return XB_OK;
+    if (bytes > c->pin_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0;
+        const size_t want = std::max<size_t>(2 * bytes, 1 << 20);
+        HIPCHK(hipHostMalloc(&c->pin, want));
+        c->pin_bytes = want;
+    }
+    HIPCHK(hipMemcpyAsync(c->pin, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(dst, c->pin, bytes);
+    return XB_OK;
+}
+static int read_counter(xb_ctx *c, int idx, int *out) {
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c->host_ints[0];
+    return XB_OK;
+}
+
+// run the exact slow kernel over ovf_list[0..n) in chunks
+static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr) {
+    if (!max_count) max_count = c->counters + 0;
+    if (!changed) changed = c->counters + 2;
+    if (!escaped) escaped = c->counters + 3;
+    const int lmax = 1 << 15, chunk = 2048;
+    DevBuf<int> path;
+    HIPCHK(path.alloc((size_t)chunk * lmax));
+    HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));  // err
+    for (int o = 0; o < n; o += chunk) {
+        const int m = std::min(chunk, n - o);
+        k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
+                                                         c->ovf_list + o, m, path.p, lmax, refine, c->first,
+                                                         c->max_list, max_count, c->max_cap,
+                                                         changed, escaped, c->counters + 8, nullptr);
+    }
+    hipError_t e = hipGetLastError();
+    int err = 0;
+    int rc = read_counter(c, 8, &err);   // synchronises the stream: the scratch may go afterwards
+    if (e != hipSuccess) return fail(XB_E_HIP, "k_trace_slow: %s", hipGetErrorString(e));
+    if (rc) return rc;
+    if (err) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", lmax);
+    return XB_OK;
+}
+
+int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
+    NEED_GRID_RAW("xb_assign_trace");
+    if (int rc = need_grad(c)) return rc;
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    // a deferred labels := 0 is dropped when this call writes every owned label without reading any: a neargrid assignment
+    // over trapping regions without vacuum (the halo planes are the peers' to fill before anything reads them)
+    if (c->labels_zero_pending && method == XB_METHOD_NEARGRID && !c->has_vacuum && c->table_prebuilt && c->blab &&
+        g.x0 % 8 == 0 && g.x1 % 8 == 0 && g.x1 - g.x0 < g.nx)
+        c->labels_zero_pending = false;
+    else if (int rc_ = settle_labels(c)) return rc_;
+    const int *box_max = nullptr;   // region id - 1 -> its maximum (set once the regions of this call exist)
+    int *max_count_dev = c->counters + 0;   // where the kernels of this call count the maxima they note
+    bool fast_slab = false;                 // windowed slab on passes A/B: the persistent trace, counts on the device
+    HIPCHK(hipMemsetAsync(c->counters, 0, 16 * sizeof(int), c->stream));
+    if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
+        k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
+        HIPCHK(hipGetLastError());
+    }
+    c->first_clean = false;
+    c->regions_pending = false;
+    if (method == XB_METHOD_NEARGRID) {
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        // the table is a pure function of the resident density, but it is part of the assignment
+        // work: rebuilt on every call, never carried over from a previous assignment
+        if (c->table_prebuilt) c->table_prebuilt = false;   // built by xb_table_build/xb_table_finish just now
+        else {
+            if (table_windowed(c)) return fail(XB_E_STATE, "windowed table: call xb_table_build / xb_table_finish first");
+            if (int rc = ensure_grad(c, true, true, true)) return rc;
+        }
+        c->g.main_ties = 1;   // methods.neargrid's stepping rule for everything the assignment traces
+        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX;
+        {
+            ScopedTimer t(c, 0);
+            const int opt = c->opt_trace;
+            const int tpb = c->opt_trace_tpb;
+            const bool slab_bricks = (g.x0 % 8 == 0) && (g.x1 % 8 == 0);
+            if (c->blab && slab_bricks) {
+                // trapping regions known per brick: fill them in one sweep, trace only the rest
+                const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+                int *walk = c->list + 4 * nbr;  // a free slice of `list` (seed, masks and the two growth buffers come first)
+                c->walk = walk;
+                // (the persistent kernel pays off from ~10^5 list items on: 0.24 vs 0.29 ms with the plain launch for an eighth of
+                // 512^3, 6.9 vs 7.7 ms for half of 1024^3)
+                fast_slab = table_windowed(c) && c->slab_sparse && c->opt_fused &&
+                            (long long)(g.x1 - g.x0) * g.ny * g.nz >= 65536LL * 512;
+                int *walk_count = c->counters + 13;
+                if (fast_slab) {   // the state block of the device-side control flow: list length, cursors, maxima and redo counts
+                    HIPCHK(hipMemsetAsync(c->fs, 0, FS_TOTAL * sizeof(int), c->stream));
+                    walk_count = c->fs + FS_N_WALK;
+                    max_count_dev = c->fs + FS_N_MAX;
+                } else
+                    HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
+                k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, (g.x0 / 8) * c->nbk[1] * c->nbk[2],
+                                                                         (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, walk, walk_count);
+                if (c->has_vacuum) {
+                    k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->blab, c->nbk[1], c->nbk[2],
+                                                                        box_max, c->labels, c->first, c->max_list,
+                                                                        max_count_dev, c->max_cap);
+                } else {
+                    k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(
+                        light(g), c->nbk[0], c->nbk[1], c->nbk[2], (g.x0 / 8) * c->nbk[1] * c->nbk[2],
+                        (g.x1 / 8) * c->nbk[1] * c->nbk[2], c->blab, box_max, c->first, c->max_list,
+                        max_count_dev, c->max_cap);
+                    c->regions_pending = true;
+                }
+                int nwalk = 0;
+                if (fast_slab) {
+                    // the persistent trace of the one-GPU path (per-XCD cursors over the list, its length on the device): no
+                    // host wait before it.  A trajectory that leaves the table window lands on a list (in `stage`) and is
+                    // redone by the kernel that derives missing records from rho.
+                    ScopedTimer tw(c, 6);
+                    int *redo = (int *)c->stage;
+                    const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
+                    k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                                                                                  c->fs, c->labels, c->first, c->max_list, c->max_cap, redo,
+                                                                                  redo_cap, maxsteps, c->has_vacuum ? 1 : 0,
+                                                                                  c->opt_trace_chunk, c->opt_trace_xcd);
+                    k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
+                        light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->fs + FS_N_OVF, c->labels,
+                        c->first, c->max_list, max_count_dev, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                        maxsteps, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
+                } else {
+                if (int rc = read_counter(c, 13, &nwalk)) return rc;
+                c->n_walk = nwalk;
+                }
+                if (nwalk) {
+                    const long long waves = 8LL * nwalk;
+                    ScopedTimer tw(c, 6);
+                    const unsigned nblk = (unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE));
+                    if (table_windowed(c)) {
+                        // the lean kernel first: a trajectory that leaves the table window lands on a list (in `stage`, its
+                        // length stays on the device) and is redone by the kernel that derives missing records from rho
+                        int *redo = (int *)c->stage;
+                        const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
+                        HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
+                        k_ng_trace<2, false><<<nblk, tpb, 0, c->stream>>>(
+                            light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
+                            c->first, c->max_list, c->counters + 0, c->max_cap, redo, c->counters + 15, redo_cap,
+                            maxsteps, opt, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
+                        k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
+                            light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->counters + 15, c->labels,
+                            c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                            maxsteps, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
+                    } else
+                        k_ng_trace<2, false><<<nblk, tpb, 0, c->stream>>>(
+                            light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk, nwalk, c->labels,
+                            c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                            maxsteps, opt, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
+                }
+            } else {
+                const long long waves = (opt & 1)
+                    ? (long long)((g.x1 - g.x0 + 3) / 4) * ((g.ny + 3) / 4) * ((g.nz + 3) / 4)
+                    : (long long)(g.x1 - g.x0) * g.ny * ((g.nz + 63) / 64);
+                (table_windowed(c) ? k_ng_trace<2, true> : k_ng_trace<2, false>)<<<(unsigned)((waves + tpb / XB_WAVE - 1) / (tpb / XB_WAVE)), tpb, 0, c->stream>>>(
+                    light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], nullptr, 0, c->labels,
+                    c->first, c->max_list, c->counters + 0, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
+                    maxsteps, opt, c->rho, c->dist_dev, c->has_vacuum ? 1 : 0);
+            }
+        }
+        HIPCHK(hipGetLastError());
+        int novf = 0;
+        if (fast_slab) {   // one wait: overflows, the list length (xb_assign_finish scans those bricks)
+            HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(c->host_ints + 1, c->fs + FS_N_WALK, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            novf = c->host_ints[0];
+            c->n_walk = c->host_ints[1];
+        } else if (int rc = read_counter(c, 1, &novf)) return rc;
+        if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
+        c->stat_ovf_assign += novf;
+        if (novf > 0) {
+            if (fast_slab) {   // the exact slow kernel counts its maxima in counters[0]: carry the count over
+                HIPCHK(hipMemcpyAsync(c->counters + 0, max_count_dev, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                max_count_dev = c->counters + 0;
+            }
+            if (int rc = run_slow(c, novf, 0)) return rc;
+        }
+        c->g.main_ties = 0;
+    } else if (method == XB_METHOD_ONGRID) {
+        c->zero_outside[0] = -1;   // (the pointer pass writes the labels of every plane, on a slab too)
+        const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
+        // trapping regions of the pointer field (whole 8^3 bricks, one slab, no vacuum), else plain pointer jumping
+        const bool regions = c->opt_boxes && c->opt_bricks && !c->has_vacuum && g.x1 - g.x0 == g.nx && g.nx % BRK == 0 &&
+                             g.ny % BRK == 0 && g.nz % BRK == 0 && g.nx >= 16 && g.ny >= 16 && g.nz >= 16 &&
+                             40LL * nbr_all <= c->N;
+        c->blab = nullptr;
+        c->n_boxes = 0;
+        c->box_voxels = 0;
+        {
+            ScopedTimer t(c, 1);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+            HIPCHK(hipMemsetAsync(c->counters + 9, 0, sizeof(int), c->stream));
+            int *bm = regions ? c->list + nbr_all : nullptr;
+            GridS gs;
+            if (sym_grid(g, gs))
+                k_og_pointer_tiled<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->labels, small, c->has_vacuum ? 1 : 0,
+                                                                       c->boxbuf + BB_SEEDS, c->counters + 9, BB_SEED_CAP, bm);
+            else
+                k_og_pointer_tiled<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, c->has_vacuum ? 1 : 0,
+                                                                      c->boxbuf + BB_SEEDS, c->counters + 9, BB_SEED_CAP, bm);
+        }
+        HIPCHK(hipGetLastError());
+        if (regions) {
+            int ns = 0;
+            if (int rc = read_counter(c, 9, &ns)) return rc;
+            if (ns >= 1 && ns <= XB_BOX_SEEDS_MAX) {
+                std::vector<int> seeds(ns);
+                HIPCHK(hipMemcpyAsync(seeds.data(), c->boxbuf + BB_SEEDS, ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (int rc = table_regions(c, seeds, true, true)) return rc;
+            }
+        }
+        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX;
+        if (c->blab) {
+            const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+            int *walk = c->list + 4 * nbr;
+            c->walk = walk;
+            HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
+            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, c->counters + 13);
+            k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(light(g), c->nbk[0], c->nbk[1], c->nbk[2], 0, nbr, c->blab,
+                                                                          box_max, c->first, c->max_list,
+                                                                          c->counters + 0, c->max_cap);
+            int nwalk = 0;
+            if (int rc = read_counter(c, 13, &nwalk)) return rc;
+            c->n_walk = nwalk;
+            if (nwalk) {
+                HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));
+                k_og_walk<<<8 * nwalk, XB_WAVE, 0, c->stream>>>(light(g), box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                                                               nwalk, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap,
+                                                               1 << 22, c->counters + 8);
+                HIPCHK(hipGetLastError());
+                int err = 0;
+                if (int rc = read_counter(c, 8, &err)) return rc;
+                if (err) return fail(XB_E_STATE, "ongrid pointer chase did not terminate");
+            }
+            c->regions_pending = true;
+        } else {
+            for (int it = 0; it < 64; it++) {
+                HIPCHK(hipMemsetAsync(c->counters + 4, 0, sizeof(int), c->stream));
+                k_og_jump<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->labels, c->counters + 4);
+                HIPCHK(hipGetLastError());
+                int nd = 0;
+                if (int rc = read_counter(c, 4, &nd)) return rc;
+                if (!nd) break;
+                if (it == 63) return fail(XB_E_LIMIT, "ongrid pointer jumping did not converge");
+            }
+            k_note_roots<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap);
+            HIPCHK(hipGetLastError());
+        }
+    } else
+        return fail(XB_E_ARG, "xb_assign: unknown method %d", method);
+    int nmax = 0;
+    HIPCHK(hipMemcpyAsync(c->host_ints, max_count_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    nmax = c->host_ints[0];
+    if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    c->local_max.resize(nmax);
+    c->local_first.resize(nmax);
+    if (nmax) {
+        k_gather_first<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, c->max_aux);
+        HIPCHK(hipGetLastError());
+        if (int rc = download_pinned(c, c->local_max.data(), c->max_list, nmax * sizeof(int))) return rc;
+        if (int rc = download_pinned(c, c->local_first.data(), c->max_aux, nmax * sizeof(int))) return rc;
+    }
+    if (n_local) *n_local = nmax;
+    return XB_OK;
+}
+
+int xb_assign_local_table(xb_ctx *c, int64_t *max_idx, int64_t *first_idx, int64_t capacity) {
+    NEED_GRID("xb_assign_local_table");
+    if ((int64_t)c->local_max.size() > capacity) return fail(XB_E_ARG, "xb_assign_local_table: capacity too small");
+    for (size_t i = 0; i < c->local_max.size(); i++) { max_idx[i] = c->local_max[i]; first_idx[i] = c->local_first[i]; }
+    return XB_OK;
+}
+
+int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global) {
+    NEED_GRID("xb_assign_finish");
+    if (n_global > c->max_cap) return fail(XB_E_LIMIT, "xb_assign_finish: too many maxima");
+    c->maxima_sorted.resize(n_global);
+    for (int64_t i = 0; i < n_global; i++) c->maxima_sorted[i] = (int)max_idx_sorted[i];
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    if (n_global) {
+        if (int rc = upload_pinned(c, c->max_aux, c->maxima_sorted.data(), n_global * sizeof(int))) return rc;
+        k_set_rank<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
+        HIPCHK(hipGetLastError());
+    }
+    c->buni_valid = false; c->regions_labels = false;
+    if (c->regions_pending && c->blab) {
+        if (g.nz % 4 == 0 && g.ny % 8 == 0 && g.x0 % 8 == 0 && g.x1 % 8 == 0 && c->nbk[1] == g.ny / 8)   // whole bricks: one brick-label lookup per 8 rows
+            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
+                light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX),
+                nullptr, nullptr, c->n_boxes);
+        else if (g.nz % 4 == 0)
+            k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
+                                                                    c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
+        else
+            k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
+                                                                   (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
+        if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
+            const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+            int *buni = reinterpret_cast<int *>(c->st);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), c->first, buni, nullptr);
+            if (c->n_walk)
+                k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
+                                                                                c->walk, c->n_walk, nullptr, nullptr, buni);
+            c->buni_valid = true;
+            c->buni_halo_safe = false;
+        } else if (!c->has_vacuum && g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0 && g.x0 % 8 == 0 && g.x1 % 8 == 0) {
+            // a slab: the regions' bricks are uniform on every rank, the owned walk-list bricks are scanned, every other
+            // brick counts as mixed -- right whatever the peers' halo planes bring, and no pass over the labels
+            const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
+            int *buni = reinterpret_cast<int *>(c->st);
+            k_fill<int><<<64, TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), c->first, buni, nullptr);
+            if (c->n_walk)
+                k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
+                                                                                c->walk, c->n_walk, nullptr, nullptr, buni);
+            c->buni_valid = true;
+            c->buni_halo_safe = true;
+        }
+    } else
+        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, nullptr);
+    c->regions_labels = c->regions_pending && c->blab && !c->has_vacuum;   // certain bricks carry their region's label now
+    c->regions_pending = false;
+    HIPCHK(hipGetLastError());
+    if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
+        k_reset_first<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->first_clean = true;
+    return XB_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The single-GPU neargrid assignment with the control flow on the device (k_fused.h): one host wait at the end.
+// Preconditions (checked by the caller): one slab, grid of whole 8^3 bricks, trapping regions enabled.
+// ---------------------------------------------------------------------------------------------------------------
+static bool fused_ok(const xb_ctx *c) {
+    const Grid &g = c->g;
+    return c->opt_fused && c->opt_boxes && c->opt_bricks && g.x0 == 0 && g.x1 == g.nx && !table_windowed(c) &&
+           g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 && 6LL * (c->N / (BRK * BRK * BRK)) <= c->N &&
+           g.nx >= 16 && g.ny >= 16 && g.nz >= 16;
+}
+static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
+
+static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
+    if (int rc = need_grad(c)) return rc;
+    Grid &g = c->g;
+    const GridL gl0 = light(g);
+    const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+    if (int rc = ensure_brick_bytes(c, nbr)) return rc;
+    int *fs = c->fs;
+    // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
+    int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
+    const bool sparse = c->opt_sparse != 0;
+    int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP,
+        *box_max = c->boxbuf + (sparse ? BB_REGMAX : BB_BOXMAX), *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * XB_BOXES_MAX,
+        *box_first = c->boxbuf + (sparse ? BB_REGFIRST : BB_EXT + 4 * XB_BOXES_MAX), *bad = c->boxbuf + BB_BAD;
+    int *bmaxv = walk;   // (free until the walk list is made)
+    int *bpot = c->list + 5 * nbr;   // brick potentials of the region growth (k_grow_parent); buf1 doubles as the parent array
+    const bool chase = sparse && c->opt_chase;
+    c->box_max_tab = box_max;
+    const int stride = XB_BOX_K + 4;
+    HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));
+    if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
+        k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
+        HIPCHK(hipGetLastError());
+    }
+    c->first_clean = false;
+    c->regions_pending = false;
+    c->buni_valid = false; c->regions_labels = false;
+    c->list_valid = false;
+    g.main_ties = 1;   // methods.neargrid's tie test (methods.py:324)
+    const GridL gl = light(g);
+    (void)gl0;
+    {   // brick masks + seeds (+ the full table on the round-1 route, opt_sparse = 0)
+        ScopedTimer t4(c, 4);
+        {
+            ScopedTimer t5(c, 5);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+            GridS gs;
+            const bool sym = sym_grid(g, gs);
+            if (sparse) {
+                // the assignment's tie rule (methods.py:324) is the template argument
+                int mirror = 0;
+                double mu_scale = 0.;
+                if (sym && c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
+                // (an orthogonal lattice has a diagonal T_grad: exact zeros off the diagonal)
+                const bool diag = c->opt_mask_diag && g.T[1] == 0. && g.T[2] == 0. && g.T[3] == 0. && g.T[5] == 0. && g.T[6] == 0. && g.T[7] == 0.;
+                if (sym && diag) k_brick_masks<GridS, 1, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                else if (sym) k_brick_masks<GridS, 1, false><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                else k_brick_masks<Grid, 1, false><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
+            } else if (sym)
+                k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
+                                                                bmask, fs + FS_TIES);
+            else
+                k_grad_field<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
+                                                               bmask, fs + FS_TIES);
+        }
+        c->grad_valid = true;
+        c->grad_rule = 1;
+        c->grad_cover = sparse ? 1 : 0;
+        if (sparse) {
+            // seeds: the bricks that hold exactly one maximum (no cubes, no cap on the number of maxima); they are not
+            // fixed: the kill iteration certifies them like every other brick
+            k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
+            if (chase) {   // provisional labels by one chase along the brick potentials instead of ~6 propagation launches
+                k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
+                k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64);
+                k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
+            } else
+                k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
+        } else {
+            // closed seed cubes around the maxima, then brick growth -- all decided on the device
+            k_box_setup<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
+            const long long wmax = 2LL * XB_BOX_K + 1;
+            k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
+            k_box_pick<<<1, XB_BOXES_MAX, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
+            k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
+        }
+        // the worst-case schedule; after a chase only the kill iteration is left, which dies out within a few bricks of the
+        // dividing surfaces: a short schedule first, and a repeat of the whole assignment with the long one (FS_GROW_RETRY)
+        // for the rare density whose cascade runs deeper
+        const int long_schedule = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
+        const int launches = chase ? std::min(long_schedule, c->grow_kill_launches) : long_schedule;
+        const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
+        for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
+            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, sparse ? 0 : 1);
+        if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
+        k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, sparse ? XB_REGIONS_MAX : XB_BOXES_MAX);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr,
+                                                 sparse ? 0 : 1);
+        HIPCHK(hipGetLastError());
+    }
+    c->blab = c->blab_buf;
+    c->walk = walk;
+    c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
+    const long long own = c->N;
+    {   // region fill / notes, then the walkers of the uncertain bricks
+        ScopedTimer t0(c, 0);
+        if (c->opt_morton) {
+            int bits = 0;
+            while ((1 << bits) < std::max(std::max(nb0, nb1), nb2)) bits++;
+            const unsigned n_codes = 1u << (3 * bits);
+            k_brick_walk_list_morton<<<(n_codes + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nb0, nb1, nb2, n_codes, c->blab, walk,
+                                                                                                  fs + FS_N_WALK, fs + FS_GROW_RETRY);
+        } else
+            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK, fs + FS_GROW_RETRY);
+        if (sparse) {   // pass B: records for the bricks of the walk list only
+            ScopedTimer t7(c, 7);
+            const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            GridS gs;
+            if (sym_grid(g, gs))
+                k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, walk, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
+            else
+                k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, walk, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
+        }
+        if (c->has_vacuum)
+            k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
+                                                                fs + FS_N_MAX, c->max_cap, fs + FS_GROW_RETRY);
+        else {
+            k_note_regions<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, nb1, nb2, fs, box_first, box_max, c->first, c->max_list, fs + FS_N_MAX, c->max_cap);
+            c->regions_pending = true;
+        }
+        {
+            ScopedTimer t6(c, 6);
+            const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+            // the lean walker needs 24-bit index products and nothing else the fused path does not already guarantee (whole-grid
+            // table window, brick-label regions); 32-bit table offsets up to 2^27 voxels
+            const int lean = (gl.use24 && c->opt_lean) ? (c->N <= (1LL << 27) ? 2 : 1) : 0;
+            const int gw = c->opt_trace_group;   // waves per workgroup (1: one-wave workgroups, every wave pulls for itself)
+#define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
+                      maxsteps, c->has_vacuum ? 1 : 0
+            if (gw > 1) {
+                const int groups = std::max(1, c->opt_trace_grid / gw), ch = std::max(8, c->opt_trace_chunk);
+                if (lean && gw == 8 && ch == 8 && c->opt_trace_cache) {   // one brick per pull: its records go through LDS
+                    if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                    else k_ng_trace_g<2, 3><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                } else
+                if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                else if (lean == 1) k_ng_trace_g<2, 1><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                else k_ng_trace_g<2, 0><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+            } else if (lean == 2)
+                k_ng_trace_p<2, 2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+            else if (lean == 1)
+                k_ng_trace_p<2, 1><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+            else
+                k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+#undef XB_TRACE_ARGS
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host)
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
+    int *buni = reinterpret_cast<int *>(c->st);
+    if (c->regions_pending) {
+        if (g.nz % 4 == 0)
+            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                        box_max, fs, fs + FS_SORT_OK);
+        else
+            k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
+        k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+        k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+    } else
+        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
+    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    HIPCHK(hipGetLastError());
+    // the ONE host wait of the assignment: state block + the sorted maxima
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints + FS_COUNT, c->max_aux, XB_SORT_MAX * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int *h = c->host_ints;
+    g.main_ties = 0;
+    if (h[FS_GROW_RETRY]) {   // the short kill schedule did not reach the fixpoint: once more, with the worst-case one from now on
+        c->grow_kill_launches = 1 << 20;
+        c->stat_grow_retries++;
+        c->grad_valid = false;
+        return assign_neargrid_fused(c, n_maxima);
+    }
+    if (h[FS_TIES] == 0) c->grad_rule = 2;
+    c->n_boxes = h[FS_N_BOXES];
+    c->box_voxels = (long long)h[FS_N_CERTAIN] * BRK * BRK * BRK;
+    c->n_walk = h[FS_N_WALK];
+    const int novf = h[FS_N_OVF];
+    int nmax = h[FS_N_MAX];
+    if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
+    if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    c->stat_ovf_assign += novf;
+    if (h[FS_SORT_OK] && novf == 0) {
+        c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+        c->regions_pending = false;
+        c->buni_valid = !c->has_vacuum;   // k_buni_from_regions + k_label_uniform_list ran
+        c->regions_labels = !c->has_vacuum;
+        c->first_clean = true;
+        if (n_maxima) *n_maxima = nmax;
+        return XB_OK;
+    }
+    // rare: trajectories for the exact slow kernel and/or more maxima than the device sort takes
+    if (novf > 0) {
+        g.main_ties = 1;
+        const int rc = run_slow(c, novf, 0, fs + FS_N_MAX);
+        g.main_ties = 0;
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_MAX, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        nmax = c->host_ints[0];
+        if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    }
+    return finish_numbering_on_host(c, nmax, n_maxima);
+}
+
+// maxima table -> host, sort by first voxel, rank + relabel (the tail of the host-driven path)
+static int sort_and_finish(xb_ctx *c, int64_t n, int64_t *n_maxima);
+static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima) {
+    c->local_max.resize(nmax);
+    c->local_first.resize(nmax);
+    if (nmax) {
+        k_gather_first<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, c->max_aux);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->local_max.data(), c->max_list, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->local_first.data(), c->max_aux, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return sort_and_finish(c, nmax, n_maxima);
+}
+
+int xb_assign(xb_ctx *c, int method, int64_t *n_maxima) {
+    NEED_GRID_RAW("xb_assign");
+    if (method == XB_METHOD_NEARGRID && fused_ok(c)) {
+        if (c->has_vacuum) { if (int rc = settle_labels(c)) return rc; }
+        else c->labels_zero_pending = false;   // every label is overwritten, none is read
+        return assign_neargrid_fused(c, n_maxima);
+    }
+    if (method == XB_METHOD_ONGRID && !c->has_vacuum) c->labels_zero_pending = false;   // the pointer pass writes every label
+    int64_t n = 0;
+    if (int rc = xb_assign_trace(c, method, &n)) return rc;
+    return sort_and_finish(c, n, n_maxima);
+}
+static int sort_and_finish(xb_ctx *c, int64_t n, int64_t *n_maxima) {
+    // numbering: rank of the smallest voxel index reaching each maximum (thread_handlers.py:59-65
+    // numbers maxima in the order the C-order scan discovers them)
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return c->local_first[a] < c->local_first[b]; });
+    std::vector<int64_t> sorted(n);
+    for (int i = 0; i < n; i++) sorted[i] = c->local_max[order[i]];
+    if (int rc = xb_assign_finish(c, sorted.data(), n)) return rc;
+    if (n_maxima) *n_maxima = n;
+    return XB_OK;
+}
+
+int xb_get_maxima(xb_ctx *c, int64_t *maxima_out, int64_t capacity) {
+    NEED_GRID("xb_get_maxima");
+    if ((int64_t)c->maxima_sorted.size() > capacity) return fail(XB_E_ARG, "xb_get_maxima: capacity too small");
+    const Grid &g = c->g;
+    for (size_t i = 0; i < c->maxima_sorted.size(); i++) {
+        const int m = c->maxima_sorted[i];
+        const int x = m / g.nyz, r = m - x * g.nyz;
+        maxima_out[3 * i] = x; maxima_out[3 * i + 1] = r / g.nz; maxima_out[3 * i + 2] = r % g.nz;
+    }
+    return XB_OK;
+}
+

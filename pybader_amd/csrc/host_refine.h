@@ -1,0 +1,716 @@
+// host_refine.h -- host side, part 4: the refinement.  Edge sweep, retraces (+ escaped-path queries and walkers of the
+// slab path), edge_check (dependency counters), the fused one-GPU iteration and xb_refine.
+
+// planes [x0-ext, x1+ext) clipped to the grid size; returns start plane (mod nx) and count
+static void plane_range(const Grid &g, int ext, int &xa, int &np) {
+    const int own = g.x1 - g.x0;
+    if (own + 2 * ext >= g.nx) { xa = 0; np = g.nx; }
+    else { xa = ((g.x0 - ext) % g.nx + g.nx) % g.nx; np = own + 2 * ext; }
+}
+
+// the sweep's launches; the edge count stays on the device (counters[5]).  *dilate_owned: the owned edges still have to
+// dilate from the list (k_edge_dilate_list over counters[5] entries)
+static int edge_find_launch(xb_ctx *c, bool *dilate_owned) {
+    const Grid &g = c->g;
+    const bool whole = (g.x1 - g.x0 == g.nx);
+    if (!whole && c->halo < 2) return fail(XB_E_STATE, "xb_edge_find: slab needs a label halo (xb_set_halo)");
+    int xa, np, xb_, npd;
+    // flags need labels one plane further out, the dilation needs flags one plane further out;
+    // a halo that wraps the whole grid makes every plane valid
+    const bool all = whole || (g.x1 - g.x0) + 2 * c->halo >= g.nx;
+    plane_range(g, all ? g.nx : c->halo - 1, xa, np);
+    plane_range(g, all ? g.nx : c->halo - 2, xb_, npd);
+    HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
+    {
+        ScopedTimer t(c, 2);
+        const GridL gl = light(g);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        int *buni = nullptr;
+        if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {  // whole bricks: per-brick label uniformity first
+            buni = reinterpret_cast<int *>(c->st);             // N bytes >= N/512 ints; edge_check reuses st later
+            const int nbr = (int)(c->N / 512), per_plane = (g.ny / 8) * (g.nz / 8);
+            if (!c->buni_valid) {
+                // a slab only scans the bricks its sweep can look at (the swept planes +- one brick)
+                int b_off = 0, count = nbr;
+                if (!all && np + 32 < g.nx) {
+                    const int p0 = ((xa - 8) % g.nx + g.nx) % g.nx;
+                    b_off = (p0 / 8) * per_plane;
+                    count = ((np + 8 + 7 + (p0 % 8)) / 8 + 1) * per_plane;
+                }
+                k_label_uniform<<<(unsigned)count, TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni, b_off, nbr);
+                c->buni_halo_safe = false;
+            }
+            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
+            buni += nbr;   // the sweep reads the 27-brick version
+        }
+        const GradRec *G = c->grad_valid ? c->grad : nullptr;
+        const unsigned char *brec = c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr;
+        if (whole || all) {
+            dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (np + ET_X - 1) / ET_X);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, xa, np, c->list,
+                                                           c->counters + 5, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            if (!whole)
+                k_edge_dilate<<<nblocks((long long)npd * g.nyz), TPB, 0, c->stream>>>(g, c->known, xb_, npd, -2);
+        } else if (buni && g.x0 % ET_X == 0 && g.x1 % ET_X == 0 && g.ny % ET_Y == 0 &&
+                   (g.x1 - g.x0) + 2 * ((c->halo - 1 + ET_X - 1) / ET_X * ET_X) <= g.nx) {
+            // a slab of whole bricks: as on one GPU only the tiles that are not of one label with their surroundings are swept
+            // (`known` preset to 2 on the swept planes).  The owned planes' edges make the list; the halo planes each side
+            // (rounded out to whole tiles: the extra planes lie beyond the ones whose flags anything reads) give a second
+            // list (in `stage`, length on the device) that only serves the dilation (refinement.py:385-404)
+            const int own = g.x1 - g.x0, side4 = (c->halo - 1 + ET_X - 1) / ET_X * ET_X;
+            const int nty = g.ny / ET_Y, ntz = (g.nz + ET_Z - 1) / ET_Z;
+            const int left0 = ((g.x0 - side4) % g.nx + g.nx) % g.nx, right0 = g.x1 % g.nx;
+            auto preset = [&](int p0, int np_) -> int {
+                const int run1 = std::min(np_, g.nx - p0);
+                HIPCHK(hipMemsetAsync(c->known + (size_t)p0 * g.nyz, 2, (size_t)run1 * g.nyz, c->stream));
+                if (np_ > run1) HIPCHK(hipMemsetAsync(c->known, 2, (size_t)(np_ - run1) * g.nyz, c->stream));
+                return XB_OK;
+            };
+            if (int rc = preset(left0, side4 + own + side4)) return rc;
+            const int n_own = (own / ET_X) * nty * ntz, n_halo = 2 * (side4 / ET_X) * nty * ntz;
+            int *tiles_own = (int *)c->stage, *tiles_halo = tiles_own + n_own, *halo_list = tiles_halo + n_halo;
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            HIPCHK(hipMemsetAsync(c->counters + 22, 0, 2 * sizeof(int), c->stream));
+            GridL ga = gl;
+            ga.x0 = 0; ga.x1 = g.nx;    // (lists every edge of the planes it sweeps)
+            k_edge_tile_list<<<(n_own + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_own, c->counters + 22, g.x0 / ET_X, own / ET_X);
+            k_edge_tile_list<<<(n_halo / 2 + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_halo, c->counters + 23, left0 / ET_X, side4 / ET_X);
+            k_edge_tile_list<<<(n_halo / 2 + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_halo, c->counters + 23, right0 / ET_X, side4 / ET_X);
+            k_edge_flag_listed<<<n_own, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, c->counters + 5, small, G, brec,
+                                                            c->has_vacuum ? 0 : 1, tiles_own, c->counters + 22);
+            k_edge_flag_listed<<<n_halo, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, halo_list, c->counters + 6, small, G, brec,
+                                                             c->has_vacuum ? 0 : 1, tiles_halo, c->counters + 23);
+            k_edge_dilate_list<<<2048, TPB, 0, c->stream>>>(gl, c->known, halo_list, 0, c->counters + 6);
+        } else {
+            // a slab: the owned planes (their edges make the list), then the halo planes each side -- their edges go to a
+            // second list (in `stage`, length on the device) that only serves the dilation (refinement.py:385-404)
+            const int own = g.x1 - g.x0, side = c->halo - 1;
+            int *halo_list = (int *)c->stage;
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            GridL ga = gl;
+            ga.x0 = 0; ga.x1 = g.nx;    // (lists every edge of the planes it sweeps)
+            dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (own + ET_X - 1) / ET_X);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, g.x0, own, c->list,
+                                                           c->counters + 5, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            grid.z = (side + ET_X - 1) / ET_X;
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, xa, side, halo_list,
+                                                           c->counters + 6, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, g.x1 % g.nx, side, halo_list,
+                                                           c->counters + 6, small, buni, G, brec, c->has_vacuum ? 0 : 1);
+            k_edge_dilate_list<<<2048, TPB, 0, c->stream>>>(gl, c->known, halo_list, 0, c->counters + 6);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    *dilate_owned = whole || !all;
+    return XB_OK;
+}
+int xb_edge_find(xb_ctx *c, int64_t *edges) {
+    NEED_GRID("xb_edge_find");
+    const Grid &g = c->g;
+    bool dilate_owned = false;
+    if (int rc = edge_find_launch(c, &dilate_owned)) return rc;
+    int n = 0;
+    if (int rc = read_counter(c, 5, &n)) return rc;
+    if (dilate_owned && n) {  // the list holds every owned edge: dilate from it
+        ScopedTimer t(c, 2);
+        k_edge_dilate_list<<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->known, c->list, n, nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    c->list_n = n;           // the edge list stays valid until `known` changes
+    c->list_valid = true;
+    if (edges) *edges = (int64_t)n;
+    return XB_OK;
+}
+
+static int compact(xb_ctx *c, int value, int *n_out) {
+    const Grid &g = c->g;
+    const long long own = (long long)(g.x1 - g.x0) * g.nyz;
+    HIPCHK(hipMemsetAsync(c->counters + 5, 0, sizeof(int), c->stream));
+    k_compact_known16<<<nblocks((own + 16 * CK_CHUNKS - 1) / (16 * CK_CHUNKS)), TPB, 0, c->stream>>>(light(g), c->known, value, c->list,
+                                                                                               c->counters + 5);
+    HIPCHK(hipGetLastError());
+    return read_counter(c, 5, n_out);
+}
+
+// ---- remote path queries (slab scheduler) -------------------------------------------------------
+// A retrace that left the valid planes of its rank was parked (known == -6).  Its path depends on rho
+// only (replicated), so the owner can record it in full; which voxel of the path stops the retrace
+// (the first known == 2 one, refinement.py:294-303) is then asked of the ranks that own those voxels.
+int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_voxels) {
+    NEED_GRID("xb_escaped_paths");
+    c->esc_starts.clear(); c->esc_offsets.assign(1, 0); c->esc_vox.clear(); c->esc_complete.clear();
+    c->g.main_ties = 0;   // retraces follow refinement.py's rule
+    int n = 0;
+    if (int rc = compact(c, -6, &n)) return rc;
+    c->list_valid = false;
+    if (n) {
+        if (max_len < 2 || max_len > (1 << 15)) return fail(XB_E_ARG, "xb_escaped_paths: max_len out of range");
+        const int lmax = (int)max_len, chunk = (int)std::max<int64_t>(256, std::min<int64_t>(8192, (32LL << 20) / max_len));
+        DevBuf<int> bpath, blen;
+        HIPCHK(bpath.alloc((size_t)chunk * lmax));
+        HIPCHK(blen.alloc(3 * (size_t)chunk));   // lengths, first out-of-range indices, offsets
+        int *path = bpath.p, *dlen = blen.p, *packed = nullptr;
+        std::vector<int> starts(n), len(2 * chunk), off(chunk), buf;
+        HIPCHK(hipMemcpyAsync(starts.data(), c->list, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int rc = XB_OK;
+        for (int o = 0; o < n && rc == XB_OK; o += chunk) {
+            const int m = std::min(chunk, n - o);
+            int *dfirst = dlen + m, *doff = dlen + 2 * chunk;
+            k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, c->list + o, m, path,
+                                                             lmax, 2, c->first, c->max_list, c->counters + 0, c->max_cap,
+                                                             c->counters + 2, c->counters + 3, c->counters + 8, dlen);
+            hipError_t e = hipMemcpyAsync(len.data(), dlen, 2 * m * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = fail(XB_E_HIP, "xb_escaped_paths: %s", hipGetErrorString(e)); break; }
+            int total = 0;
+            std::vector<int> alen(m);
+            for (int i = 0; i < m; i++) {
+                alen[i] = std::abs(len[i]);          // negative: cut at max_len
+                off[i] = total;
+                total += 1 + alen[i] - len[m + i];   // start voxel + the part from the first out-of-range voxel on
+            }
+            buf.resize(total);
+            e = hipMalloc(&packed, (size_t)std::max(total, 1) * sizeof(int));
+            if (e == hipSuccess) e = hipMemcpyAsync(doff, off.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dlen, alen.data(), m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                k_path_pack<<<m, 64, 0, c->stream>>>(path, lmax, doff, dlen, dfirst, packed);
+                e = hipMemcpyAsync(buf.data(), packed, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipFree(packed); packed = nullptr;
+            if (e != hipSuccess) { rc = fail(XB_E_HIP, "xb_escaped_paths: %s", hipGetErrorString(e)); break; }
+            for (int i = 0; i < m; i++) {
+                c->esc_starts.push_back(starts[o + i]);
+                const int cnt = 1 + alen[i] - len[m + i];
+                for (int k = 0; k < cnt; k++) c->esc_vox.push_back(buf[off[i] + k]);
+                c->esc_offsets.push_back((int64_t)c->esc_vox.size());
+                c->esc_complete.push_back(len[i] > 0 ? 1 : 0);
+            }
+        }
+        if (rc != XB_OK) return rc;
+    }
+    if (n_paths) *n_paths = (int64_t)c->esc_starts.size();
+    if (n_voxels) *n_voxels = (int64_t)c->esc_vox.size();
+    return XB_OK;
+}
+int xb_escaped_paths_fetch(xb_ctx *c, int64_t *starts, int64_t *offsets, int64_t *voxels, int8_t *complete) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    std::copy(c->esc_starts.begin(), c->esc_starts.end(), starts);
+    std::copy(c->esc_offsets.begin(), c->esc_offsets.end(), offsets);
+    std::copy(c->esc_vox.begin(), c->esc_vox.end(), voxels);
+    std::copy(c->esc_complete.begin(), c->esc_complete.end(), complete);
+    return XB_OK;
+}
+// labels / known at arbitrary voxels (linear indices), and the write-back of retrace results
+static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8_t *kn, bool scatter) {
+    NEED_GRID("xb_gather_voxels");
+    if (n <= 0) return XB_OK;
+    std::vector<int> i32(n);
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= c->N) return fail(XB_E_ARG, "voxel index out of range");
+        i32[k] = (int)idx[k];
+    }
+    DevBuf<int> buf;
+    HIPCHK(buf.alloc(2 * (size_t)n + (size_t)n / 4 + 1));   // indices, labels, known bytes
+    int *d = buf.p;
+    int *dlab = d + n;
+    int8_t *dkn = reinterpret_cast<int8_t *>(d + 2 * n);
+    hipError_t e = hipMemcpyAsync(d, i32.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (scatter) {
+        if (e == hipSuccess) e = hipMemcpyAsync(dlab, lab, n * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dkn, kn, n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) k_scatter_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, dlab, dkn, c->labels, c->known);
+        c->list_valid = false;
+        c->buni_valid = false; c->regions_labels = false;
+        c->zero_outside[0] = -1;
+    } else {
+        if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
+        if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(kn, dkn, n, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(XB_E_HIP, "xb_gather/scatter_voxels: %s", hipGetErrorString(e));
+    return XB_OK;
+}
+int xb_gather_voxels(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *labels_out, int8_t *known_out) {
+    return voxel_io(c, idx, n, labels_out, known_out, false);
+}
+int xb_scatter_voxels(xb_ctx *c, const int64_t *idx, int64_t n, const int32_t *labels_in, const int8_t *known_in) {
+    return voxel_io(c, idx, n, const_cast<int32_t *>(labels_in), const_cast<int8_t *>(known_in), true);
+}
+
+static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *escaped);
+int xb_refine_trace(xb_ctx *c, int64_t *changed, int64_t *escaped) { return refine_trace_impl(c, -2, changed, escaped); }
+int xb_refine_trace_escaped(xb_ctx *c, int64_t *changed, int64_t *escaped) { return refine_trace_impl(c, -6, changed, escaped); }
+static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *escaped) {
+    NEED_GRID("xb_refine_trace");
+    const Grid &g = c->g;
+    c->g.main_ties = 0;
+    int n = 0;
+    if (c->list_valid && flag == -2) n = c->list_n;
+    else if (int rc = compact(c, flag, &n)) return rc;
+    c->list_valid = false;  // the retrace rewrites known
+    c->buni_valid = false;  // ... and may relabel edge voxels; st is also edge_check's scratch
+    c->walk_n_out = 0; c->walk_n_res = 0; c->walk_out_dev = nullptr;
+    c->walk_host.clear(); c->res_host.clear();
+    HIPCHK(hipMemsetAsync(c->counters, 0, 4 * sizeof(int), c->stream));
+    int n_changed = 0, n_escaped = 0;
+    if (n) {
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        Walker *wio_out = nullptr;
+        int wio_cap = 0;
+        if (int rc = ensure_grad(c, false, false, false)) return rc;
+        {
+            ScopedTimer t(c, 3);
+            const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
+            const int regions_ok = brec && c->regions_labels && !c->has_vacuum ? 1 : 0;
+            // slabs: the regions' brick labels stop a retrace when the labels are this assignment's, there is no vacuum and
+            // the density has no tie voxel (the windowed masks are built under the assignment's tie rule only)
+            const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && (c->grad_rule == 2 || c->slab_sparse) &&
+                                       g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
+            // the lean kernel; the retraces whose walk goes on through a voxel without a record (a brick without records,
+            // a voxel outside the table window of a slab) or out of the valid planes of a slab are redone by the from-rho
+            // kernel (their count stays on the device: its grid strides over it).  On a slab that kernel parks the
+            // retraces that leave the valid planes AND exports them as walkers (xb_walkers_*).
+            const bool slab = g.vlen < g.nx;
+            int *defer = (int *)c->stage;
+            WalkerIO wio{};
+            if (flag == -2 && slab) {
+                const size_t off = (((size_t)n * sizeof(int)) + 255) & ~(size_t)255;
+                if (off + sizeof(Walker) <= c->stage_bytes) {
+                    HIPCHK(hipMemsetAsync(c->counters + 16, 0, sizeof(int), c->stream));
+                    wio.out = (Walker *)((char *)c->stage + off); wio.out_count = c->counters + 16;
+                    wio.out_cap = (int)std::min<size_t>((c->stage_bytes - off) / sizeof(Walker), 1u << 30);
+                    c->walk_out_dev = wio.out;
+                }
+            }
+            HIPCHK(hipMemsetAsync(c->counters + 15, 0, sizeof(int), c->stream));
+            k_refine_trace<2, false><<<nblocks(n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, c->list, n, nullptr,
+                                                                        c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                        c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, defer,
+                                                                        c->counters + 15, regions_ok, slab_regions, WalkerIO{});
+            if (brec || slab || table_windowed(c))
+                k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, defer, 0, c->counters + 15,
+                                                                    c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                    c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0,
+                                                                    slab_regions, wio);
+            wio_out = wio.out; wio_cap = wio.out_cap;
+        }
+        HIPCHK(hipGetLastError());
+        // one wait for everything the kernels counted: overflows [1], changed [2], escaped [3], exported walkers [16]
+        HIPCHK(hipMemcpyAsync(c->host_ints, c->counters, 17 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const int novf = c->host_ints[1];
+        n_changed = c->host_ints[2]; n_escaped = c->host_ints[3];
+        if (wio_out) {
+            c->walk_n_out = std::min(c->host_ints[16], wio_cap);
+            c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
+            if (int rc = download_pinned(c, c->walk_host.data(), wio_out, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
+        }
+        if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
+        c->stat_ovf_refine += novf;
+        if (novf > 0) {
+            if (int rc = run_slow(c, novf, 1)) return rc;
+            HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            n_changed = c->host_ints[0]; n_escaped = c->host_ints[1];
+        }
+    }
+    if (changed) *changed = n_changed;
+    if (escaped) *escaped = n_escaped;
+    return XB_OK;
+}
+
+// ---- walkers: retraces that left this rank's valid planes, carried on by the rank that owns the plane they entered ----
+static int ensure_walker_bufs(xb_ctx *c, int64_t n) {
+    if (c->walk_cap >= n) return XB_OK;
+    (void)hipFree(c->walk_in); (void)hipFree(c->walk_out2); (void)hipFree(c->walk_res);
+    c->walk_in = c->walk_out2 = c->walk_res = nullptr; c->walk_cap = 0;
+    const size_t cap = (size_t)n + n / 2 + 4096;
+    HIPCHK(hipMalloc(&c->walk_in, cap * sizeof(Walker)));
+    HIPCHK(hipMalloc(&c->walk_out2, cap * sizeof(Walker)));
+    HIPCHK(hipMalloc(&c->walk_res, cap * 2 * sizeof(int)));
+    c->walk_cap = (long long)cap;
+    return XB_OK;
+}
+int xb_walkers_count(xb_ctx *c, int64_t *n_walkers, int64_t *n_results) {
+    NEED_GRID("xb_walkers_count");
+    if (n_walkers) *n_walkers = c->walk_n_out;
+    if (n_results) *n_results = c->walk_n_res;
+    return XB_OK;
+}
+int xb_walkers_fetch(xb_ctx *c, int64_t *walkers, int64_t *results) {
+    NEED_GRID("xb_walkers_fetch");
+    if (walkers && c->walk_n_out) memcpy(walkers, c->walk_host.data(), (size_t)c->walk_n_out * sizeof(Walker));
+    if (results && c->walk_n_res) memcpy(results, c->res_host.data(), (size_t)c->walk_n_res * sizeof(int64_t));
+    return XB_OK;
+}
+// `walkers`: n records of XB_WALKER_WORDS int64 (every rank's exports, any order).  The ones that arrive on a plane this
+// rank owns are carried on with this rank's labels / known: results = (start voxel, final label) pairs, the others
+// that leave the valid planes again are exported anew (xb_walkers_count / xb_walkers_fetch).
+int xb_walkers_continue(xb_ctx *c, const int64_t *walkers, int64_t n) {
+    NEED_GRID("xb_walkers_continue");
+    if (n < 0 || (n && !walkers)) return fail(XB_E_ARG, "xb_walkers_continue: bad arguments");
+    if (c->g.vlen >= c->g.nx) return fail(XB_E_STATE, "xb_walkers_continue: every plane is valid on this rank (no slab halo)");
+    const Grid &g = c->g;
+    c->walk_n_out = 0; c->walk_n_res = 0;
+    c->walk_host.clear(); c->res_host.clear();
+    if (!n) return XB_OK;
+    if (n > (1 << 28)) return fail(XB_E_LIMIT, "xb_walkers_continue: too many walkers");
+    c->g.main_ties = 0;
+    if (int rc = ensure_grad(c, false, false, false)) return rc;
+    const size_t bytes = (size_t)n * sizeof(Walker);
+    if (int rc = ensure_walker_bufs(c, n)) return rc;
+    if (int rc = upload_pinned(c, c->walk_in, walkers, bytes)) return rc;
+    HIPCHK(hipMemsetAsync(c->counters + 16, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters + 1, 0, 3 * sizeof(int), c->stream));
+    WalkerIO wio{};
+    wio.in = (const Walker *)c->walk_in;
+    wio.out = (Walker *)c->walk_out2; wio.out_count = c->counters + 16; wio.out_cap = (int)n;
+    wio.res = (int *)c->walk_res; wio.res_count = c->counters + 17;
+    wio.own0 = g.x0; wio.own1 = g.x1;
+    const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
+    const int *slab_regions = (table_windowed(c) && c->blab && c->regions_labels && !c->has_vacuum && (c->grad_rule == 2 || c->slab_sparse) &&
+                               g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) ? c->blab : nullptr;
+    const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+    k_refine_trace<2, true, true><<<nblocks((int)n), TPB, 0, c->stream>>>(light(g), c->grad, c->labels, c->known, nullptr, (int)n, nullptr,
+                                                                         c->counters + 2, c->counters + 3, c->ovf_list, c->counters + 1,
+                                                                         c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, nullptr, nullptr, 0,
+                                                                         slab_regions, wio);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 16, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->walk_n_out = c->host_ints[0]; c->walk_n_res = c->host_ints[1];
+    c->walk_out_dev = wio.out;
+    c->walk_host.resize((size_t)c->walk_n_out * (sizeof(Walker) / 8));
+    std::vector<int> pairs(2 * (size_t)c->walk_n_res);
+    if (int rc = download_pinned(c, c->walk_host.data(), wio.out, (size_t)c->walk_n_out * sizeof(Walker))) return rc;
+    if (int rc = download_pinned(c, pairs.data(), wio.res, pairs.size() * sizeof(int))) return rc;
+    c->res_host.resize(c->walk_n_res);
+    for (int i = 0; i < c->walk_n_res; i++)
+        c->res_host[i] = (int64_t)(uint32_t)pairs[2 * i] | ((int64_t)pairs[2 * i + 1] << 32);
+    return XB_OK;
+}
+// `results`: n pairs (voxel | label << 32), every rank's.  The pairs whose voxel this rank owns are applied as the retrace
+// would have (refinement.py:288-291); stuck ones (the exact slow path is needed) stay parked for xb_escaped_paths.
+int xb_walkers_apply(xb_ctx *c, const int64_t *results, int64_t n, int64_t *changed, int64_t *stuck) {
+    NEED_GRID("xb_walkers_apply");
+    if (changed) *changed = 0;
+    if (stuck) *stuck = 0;
+    if (n < 0 || (n && !results)) return fail(XB_E_ARG, "xb_walkers_apply: bad arguments");
+    if (!n) return XB_OK;
+    if (n > (1 << 28)) return fail(XB_E_LIMIT, "xb_walkers_apply: too many results");
+    const Grid &g = c->g;
+    std::vector<int> pairs(2 * (size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t v = results[i] & 0xffffffffLL;
+        if (v >= c->N) return fail(XB_E_ARG, "xb_walkers_apply: voxel out of range");
+        pairs[2 * i] = (int)v; pairs[2 * i + 1] = (int)(results[i] >> 32);
+    }
+    if (int rc = ensure_walker_bufs(c, n)) return rc;
+    int *d = (int *)c->walk_res;    // (the results of the last xb_walkers_continue were fetched to the host already)
+    if (int rc = upload_pinned(c, d, pairs.data(), pairs.size() * sizeof(int))) return rc;
+    HIPCHK(hipMemsetAsync(c->counters + 18, 0, 2 * sizeof(int), c->stream));
+    k_walkers_apply<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(light(g), d, (int)n, g.x0, g.x1, c->labels, c->known,
+                                                                      c->counters + 18, c->counters + 19);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 18, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->list_valid = false; c->buni_valid = false;
+    if (changed) *changed = c->host_ints[0];
+    if (stuck) *stuck = c->host_ints[1];
+    return XB_OK;
+}
+
+// edge_check on the listed voxels c->list[0..n) (all flagged -2 in `known`): the greedy resolution by dependency
+// counters (k_edges.h), then apply / restore / ring / finish.  `cls`: per list entry the edge&maximum class computed
+// elsewhere (slabs: by the owner of the voxel), or null to derive it here.  Only entries within `near_np` planes
+// from plane `near_xa` re-classify their boxes (slabs: the boxes that can touch this rank's valid planes), new
+// edges are counted in the linear index range [count_lo, count_hi) (slabs: the owned planes).
+static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, int near_np, long long count_lo,
+                              long long count_hi, int64_t *checked, int64_t *edges) {
+    const Grid &g = c->g;
+    if (checked) *checked = 0;
+    if (edges) *edges = 0;
+    if (!n) return XB_OK;
+    {
+        // counters + classes for the whole list, round 1 over the whole list, then the dependency chains are
+        // chased asynchronously by a small grid of workgroups; queue overflows seed another launch.  Scratch: two
+        // seed / overflow lists of N ints in the staging buffer, 16 bits per voxel for the counters (only
+        // 'changed' refinement needs them).
+        // (the seed / overflow lists: in `stage` when it is grid sized, else in a buffer of their own -- at most every listed
+        // voxel is queued at once)
+        int cap = (int)std::min<long long>(c->N, 1LL << 30);
+        int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
+        if (c->stage_bytes < 8 * (size_t)c->N) {
+            cap = (int)std::min<long long>(c->N, std::max<long long>(2LL * n + 65536, 1 << 20));
+            if (c->ec_buf_cap < 2LL * cap) {
+                hipFree(c->ec_buf); c->ec_buf = nullptr; c->ec_buf_cap = 0;
+                HIPCHK(hipMalloc(&c->ec_buf, 2 * (size_t)cap * sizeof(int)));
+                c->ec_buf_cap = 2LL * cap;
+            }
+            buf[0] = c->ec_buf; buf[1] = c->ec_buf + cap;
+        }
+        if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 8 * (size_t)c->N + 16));
+        ec_word *pend_w = c->ec_pend;
+        HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+        if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, pend_w);
+        else k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, pend_w);
+        k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
+                                                                                         c->counters + 6, cap);
+        HIPCHK(hipGetLastError());
+        int n_seeds = 0;
+        if (int rc = read_counter(c, 6, &n_seeds)) return rc;
+        for (int pass = 0; n_seeds > 0; pass++) {
+            if (n_seeds > cap) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
+            if (pass > 256) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
+            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+            const int groups = (int)std::min<long long>(std::max(1, n_seeds / 64), c->opt_ec_groups);
+            k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->known, pend_w, buf[pass & 1], n_seeds, buf[1 - (pass & 1)],
+                                                                   c->counters + 6, cap, c->opt_ec_qcap);
+            HIPCHK(hipGetLastError());
+            const int before = n_seeds;
+            if (int rc = read_counter(c, 6, &n_seeds)) return rc;
+            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d seeds, %d overflowed (%d groups)\n", pass, before, n_seeds, groups);
+        }
+    }
+    HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+    k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st, c->counters + 6);
+    {
+        int undecided = 0;
+        if (int rc = read_counter(c, 6, &undecided)) return rc;
+        if (undecided) return fail(XB_E_STATE, "xb_edge_check: %d edge voxels left undecided", undecided);
+    }
+    if (near_np < g.nx) k_ec_keep_near<<<nblocks(n), TPB, 0, c->stream>>>(g, c->list, n, c->st, near_xa, near_np);
+    HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
+    const int new_cap = (int)std::min<long long>(c->list_cap - n, 1LL << 30);   // the rest of `list` behind the compacted edges
+    HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
+    k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1,
+                                                  c->list + n, c->counters + 7, new_cap);
+    k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
+    {   // -1 ring around the new edges (-3): from their list, or by a full-grid sweep if the list did not fit
+        int n_new = 0;
+        if (int rc = read_counter(c, 7, &n_new)) return rc;
+        if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
+        else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new, nullptr);
+    }
+    k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64,
+                                                                                                      count_lo, count_hi);
+    HIPCHK(hipGetLastError());
+    unsigned long long r[2];
+    HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (edges) *edges = (int64_t)r[0];
+    if (checked) *checked = (int64_t)(r[1] + r[0]);  // refinement.py:479 + 504
+    return XB_OK;
+}
+
+int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
+    NEED_GRID("xb_edge_check");
+    const Grid &g = c->g;
+    c->list_valid = false;
+    c->buni_valid = false;
+    if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: one slab only; slabs use xb_edge_check_local + xb_edge_check_global");
+    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
+    int n = 0;
+    if (int rc = compact(c, -2, &n)) return rc;
+    return edge_check_resolve(c, n, nullptr, 0, g.nx, 0, c->N, checked, edges);
+}
+
+// ---- 'changed' refinement across slabs ------------------------------------------------------------------------
+// refinement.edge_check is ONE lexicographic greedy scan of the whole grid (refinement.py:420-427): whether a changed
+// voxel is processed depends on its C-order earlier changed neighbours, in chains that run through slab boundaries.
+// The chains only involve the changed voxels themselves (a few 10^5 at 512^3) and one class bit each, so every rank
+// resolves the GLOBAL list: (1) each rank lists its owned changed voxels with their class (xb_edge_check_local);
+// (2) the scheduler all-gathers the lists; (3) each rank flags the whole list in its full-size `known`, resolves it
+// with the same dependency-counter kernels as one GPU, and applies the boxes that touch its own valid planes
+// (xb_edge_check_global).  Needs label AND known halos refreshed beforehand.
+int xb_edge_check_local(xb_ctx *c, int64_t *n_out) {
+    NEED_GRID("xb_edge_check_local");
+    c->list_valid = false;
+    int n = 0;
+    if (int rc = compact(c, -2, &n)) return rc;   // owned planes only
+    if (n) {
+        k_ec_class<<<nblocks(n), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, c->list, n, c->st);
+        HIPCHK(hipGetLastError());
+    }
+    c->ec_local_n = n;
+    if (n_out) *n_out = n;
+    return XB_OK;
+}
+int xb_edge_check_local_fetch(xb_ctx *c, int64_t *idx_out, int8_t *cls_out) {
+    NEED_GRID("xb_edge_check_local_fetch");
+    const int n = c->ec_local_n;
+    if (!n) return XB_OK;
+    std::vector<int> tmp(n);
+    HIPCHK(hipMemcpyAsync(tmp.data(), c->list, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cls_out, c->st, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) idx_out[i] = tmp[i];
+    return XB_OK;
+}
+int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64_t n, int64_t *checked, int64_t *edges) {
+    NEED_GRID("xb_edge_check_global");
+    const Grid &g = c->g;
+    c->list_valid = false;
+    c->buni_valid = false;
+    if (checked) *checked = 0;
+    if (edges) *edges = 0;
+    if (n < 0 || n > c->N) return fail(XB_E_ARG, "xb_edge_check_global: bad list length");
+    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
+    if (c->halo < 3 && g.vlen < g.nx) return fail(XB_E_STATE, "xb_edge_check_global: needs a halo of at least 3 planes");
+    if (!n) return XB_OK;
+    std::vector<int> i32(n);
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= c->N) return fail(XB_E_ARG, "xb_edge_check_global: voxel index out of range");
+        i32[k] = (int)idx[k];
+    }
+    // planes outside this rank's valid range hold stale flags: neutralise them, then flag the whole global list
+    if (g.vlen < g.nx) {
+        const int a = g.vx0 + g.vlen;   // invalid planes: [a, a + nx - vlen) modulo nx
+        const int len = g.nx - g.vlen, first = a % g.nx, run1 = std::min(len, g.nx - first);
+        HIPCHK(hipMemsetAsync(c->known + (size_t)first * g.nyz, 2, (size_t)run1 * g.nyz, c->stream));
+        if (len > run1) HIPCHK(hipMemsetAsync(c->known, 2, (size_t)(len - run1) * g.nyz, c->stream));
+    }
+    int8_t *dcls = c->st + (c->N - n);   // the tail of `st` (its head receives the decisions of k_ec_collect)
+    if (2 * n > c->N || 2 * n > c->list_cap) return fail(XB_E_LIMIT, "xb_edge_check_global: list longer than half the grid / the list buffer");
+    if (int rc = upload_pinned(c, c->list, i32.data(), n * sizeof(int))) return rc;
+    if (int rc = upload_pinned(c, dcls, cls, n, (n * sizeof(int) + 255) & ~(size_t)255)) return rc;
+    k_scatter_byte<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->known, c->list, (int)n, (int8_t)-2);
+    HIPCHK(hipGetLastError());
+    // a processed voxel re-classifies its box (one plane each side) and a new edge among those rings its own box
+    // (one more plane): voxels within two planes of the known-valid range [vx0, vx0 + vlen) can reach it
+    int near_xa = 0, near_np = g.nx;
+    if (g.vlen + 4 < g.nx) { near_xa = (g.vx0 - 2 + g.nx) % g.nx; near_np = g.vlen + 4; }
+    const int rc = edge_check_resolve(c, (int)n, dcls, near_xa, near_np, (long long)g.x0 * g.nyz, (long long)g.x1 * g.nyz, checked, edges);
+    return rc;   // (host vectors outlive the copies: edge_check_resolve waits on the stream)
+}
+
+// The retraces of a refinement need the gradient-field table anyway; built before the first edge sweep it also
+// lets edge_find read "not a maximum" off the tabulated ongrid successor instead of a 27-point density test
+// per edge voxel (2.0 -> 0.9 ms at 512^3 after an ongrid assignment).
+int xb_prepare_refine(xb_ctx *c) {
+    NEED_GRID("xb_prepare_refine");
+    return ensure_grad(c, false, false, false);
+}
+
+// edge_find + retrace of one refinement iteration on one slab with ONE host wait: the edge count stays on the
+// device (the list kernels stride over it), the counters come back together at the end.
+static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
+    const Grid &g = c->g;
+    int *fs = c->fs;
+    c->g.main_ties = 0;
+    const GridL gl = light(g);
+    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 5 * sizeof(int), c->stream));   // edges, changed, escaped, overflows, deferred
+    {
+        ScopedTimer t(c, 2);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        int *buni = nullptr;
+        if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {
+            buni = reinterpret_cast<int *>(c->st);
+            if (!c->buni_valid)
+                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni, 0, (int)(c->N / 512));
+            const int nbr = (int)(c->N / 512);
+            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
+            buni += nbr;
+        }
+        const unsigned char *brec = c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr;
+        if (buni) {
+            // flags preset to "known", then only the tiles that are not of one non-vacuum label with their surroundings
+            const int ntiles = ((g.nz + ET_Z - 1) / ET_Z) * (g.ny / ET_Y) * (g.nx / ET_X);
+            int *tiles = (int *)c->stage;
+            HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
+            HIPCHK(hipMemsetAsync(fs + FS_N_TILES, 0, sizeof(int), c->stream));
+            k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES, 0, g.nx / ET_X);
+            k_edge_flag_listed<<<ntiles, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
+                                                           c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1, tiles, fs + FS_N_TILES);
+        } else {
+            dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (g.nx + ET_X - 1) / ET_X);
+            k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, 0, g.nx, c->list, fs + FS_N_EDGES, small, buni,
+                                                           c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1);
+        }
+        k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
+    }
+    c->list_valid = false;
+    c->buni_valid = false;
+    {
+        ScopedTimer t(c, 3);
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        k_refine_trace<2, false><<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, fs + FS_N_EDGES,
+                                                              fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
+                                                              c->ovf_cap, maxsteps, c->rho, c->dist_dev,
+                                                              c->grad_cover == 1 ? c->brick_rec : nullptr, (int *)c->stage, fs + FS_R_DEFER,
+                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0, nullptr, WalkerIO{});
+        if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
+            k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
+                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
+                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, WalkerIO{});
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *edges = c->host_ints[0];
+    *changed = c->host_ints[1];
+    const int novf = c->host_ints[3];
+    c->stat_deferred += c->host_ints[4];
+    if (c->host_ints[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", c->host_ints[2]);
+    if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
+    c->stat_ovf_refine += novf;
+    if (novf > 0) {
+        if (int rc = run_slow(c, novf, 1, nullptr, fs + FS_CHANGED, fs + FS_ESCAPED)) return rc;
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_CHANGED, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *changed = c->host_ints[0];
+    }
+    return XB_OK;
+}
+
+int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
+    NEED_GRID("xb_refine");
+    if (n_iters) *n_iters = 0;
+    if (iters == 0) return XB_OK;  // thread_handlers.py:146-147
+    if (int rc = xb_prepare_refine(c)) return rc;
+    int64_t edges = 0, changed = 0, esc = 0, checked = 0;
+    const bool fused = c->opt_fused && c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
+    int64_t k = 0;
+    auto put = [&](int64_t e, int64_t ch) {
+        if (log && 2 * k + 1 < log_capacity) { log[2 * k] = e; log[2 * k + 1] = ch; }
+        k++;
+        if (n_iters) *n_iters = k;
+    };
+    if (fused) {
+        if (int rc = refine_iteration_fused(c, &edges, &changed)) return rc;
+        if (edges == 0) return XB_OK;  // thread_handlers.py:151-153 (no edge: the retrace had nothing to do)
+    } else {
+        if (int rc = xb_edge_find(c, &edges)) return rc;
+        if (edges == 0) return XB_OK;  // thread_handlers.py:151-153
+        if (int rc = xb_refine_trace(c, &changed, &esc)) return rc;
+        if (esc) return fail(XB_E_STATE, "xb_refine: %lld traces left the valid slab", (long long)esc);
+    }
+    put(edges, changed);
+    for (int64_t it = 2; iters < 0 || it <= iters; it++) {  // thread_handlers.py:194-236
+        if (fused && mode != XB_REFINE_ALL && changed == 0) {
+            // edge_check re-classifies the boxes of the voxels still flagged -2, i.e. the CHANGED ones
+            // (refinement.py:425-427): none is left, so it reports 0 edges and the retrace has no work
+            put(0, 0);
+            break;
+        }
+        if (fused && mode == XB_REFINE_ALL) {
+            if (int rc = refine_iteration_fused(c, &edges, &changed)) return rc;
+            put(edges, changed);
+            if (changed == 0) break;
+            continue;
+        }
+        if (mode == XB_REFINE_ALL) {
+            if (int rc = xb_edge_find(c, &edges)) return rc;
+        } else {
+            if (int rc = xb_edge_check(c, &checked, &edges)) return rc;
+        }
+        if (int rc = xb_refine_trace(c, &changed, &esc)) return rc;
+        if (esc) return fail(XB_E_STATE, "xb_refine: %lld traces left the valid slab", (long long)esc);
+        put(edges, changed);
+        if (changed == 0) break;
+    }
+    return XB_OK;
+}
