@@ -126,6 +126,7 @@ struct xb_ctx {
     void *wk_in = nullptr;                // the walkers this rank carries on in a round (+ their count)
     int wbuf_ranks = 0, walk_last = -1, walk_round = 0, wcap = 0;
     int opt_async_comm = 0;    // collectives return without waiting (they are ordered on the context's stream); the device-driven slab step sets it
+    int opt_tile_dilate = 1;   // the dilation of the edge sweep tile by tile (k_edge_dilate_tiles) instead of from the edge list (tests compare)
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
     int opt_lean_mem = 1;      // slabs: table, `list` and `stage` sized by the slab instead of the grid (0: everything full size)
     int opt_trace_cache = 1;   // group trace: the own brick's records in LDS (k_ng_trace_g, LEAN 3 / 4)
@@ -300,6 +301,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 21) c->opt_trace_cache = value != 0;
     else if (key == 22) c->opt_lean_mem = value != 0;   // (before xb_set_grid)
     else if (key == 24) c->opt_async_comm = value != 0;
+    else if (key == 25) c->opt_tile_dilate = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
     else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)

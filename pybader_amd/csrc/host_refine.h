@@ -607,6 +607,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         ScopedTimer t(c, 2);
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         int *buni = nullptr;
+        int ntiles_listed = 0;
         if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {
             buni = reinterpret_cast<int *>(c->st);
             if (!c->buni_valid)
@@ -619,6 +620,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         if (buni) {
             // flags preset to "known", then only the tiles that are not of one non-vacuum label with their surroundings
             const int ntiles = ((g.nz + ET_Z - 1) / ET_Z) * (g.ny / ET_Y) * (g.nx / ET_X);
+            ntiles_listed = ntiles;
             int *tiles = (int *)c->stage;
             HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
             HIPCHK(hipMemsetAsync(fs + FS_N_TILES, 0, sizeof(int), c->stream));
@@ -630,7 +632,8 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
             k_edge_flag_tiled<<<grid, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, 0, g.nx, c->list, fs + FS_N_EDGES, small, buni,
                                                            c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1);
         }
-        k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
+        if (buni && c->opt_tile_dilate && g.nz % ET_Z == 0) k_edge_dilate_tiles<<<std::min(ntiles_listed, 4096), TPB, 0, c->stream>>>(gl, c->known, (const int *)c->stage, fs + FS_N_TILES);
+        else k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
     }
     c->list_valid = false;
     c->buni_valid = false;

@@ -320,3 +320,36 @@ def test_mirror_prefilter_and_lean_walker_do_not_change_the_map(shape, lattice, 
     assert res[0][5] == res[2][5] and res[1][5] == res[3][5]          # the walker does not touch the regions
     assert res[0][5] == res[4][5]                                     # nor does the diagonal form of T_grad . grad
     print('certified voxels with / without the mirror prefilter:', res[0][5][1], res[1][5][1])
+
+
+@pytest.mark.parametrize('shape,lattice,noise,tol', [((256, 256, 256), synth.CUBIC6, 0.0, None), ((128, 160, 200), ORTHO, 0.0, None),
+                                                     ((128, 128, 128), synth.TRICLINIC, 0.0, 0.02), ((96, 96, 96), synth.CUBIC6, 3e-2, None),
+                                                     ((64, 64, 64), synth.CUBIC6, 0.0, 0.05)])
+def test_tile_wise_dilation_leaves_the_same_flags(shape, lattice, noise, tol):
+    """k_edge_dilate_tiles (the dilation of refinement.py:385-404 from LDS tiles of the flags, option 25) against
+    k_edge_dilate_list (27 byte gathers per edge voxel): the same `known` array after the first refinement iteration, the
+    same log and map after three -- smooth, rough, with vacuum (uniform vacuum tiles are on the list too), a z extent that
+    is not a whole number of tiles."""
+    ctx = _lib.Context(0)
+    dm, tg = matrices(shape, lattice)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(lattice, synth.ATOMS8, synth.BACKGROUND)
+    if noise:
+        rho = ctx.download_density()
+        rho = np.ascontiguousarray(rho + noise * np.random.default_rng(7).random(shape))
+        ctx.upload_density(rho)
+    res = []
+    for tiled in (1, 0):
+        ctx.set_option(25, tiled)
+        ctx.set_option(6, 1)
+        ctx.vacuum_assign(tol, 1.0)
+        n = ctx.assign('neargrid')
+        log1 = ctx.refine('all', 1)
+        known1 = ctx.download_known()
+        log = ctx.refine('all', 2)
+        res.append((n, log1, known1, log, ctx.download_labels(np.int32)))
+    ctx.close()
+    a, b = res
+    assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    print('first iteration:', a[1], 'near-edge voxels', int((a[2] == -1).sum()))
