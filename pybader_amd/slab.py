@@ -147,6 +147,13 @@ class SlabRunner:
             self.be.sync()
             comm.selftest_planes(self.be, self.ranges)
 
+    @property
+    def maxima(self):
+        """linear voxel indices of the maxima in basin order (fetched from the library on first use: not part of a step)"""
+        if getattr(self, '_maxima', None) is None:
+            self._maxima = (np.ravel_multi_index(tuple(self.be.maxima().T), self.shape) if self.n_maxima else np.zeros(0, np.int64))
+        return self._maxima
+
     def enable_table_window(self, margin=None):
         """Build the gradient-field table only for the owned slab +- margin planes (needs whole 8^3 bricks everywhere).
         Trajectories that leave the window are redone with records derived from rho, a kernel with a long tail: at 512^3 on
@@ -211,7 +218,7 @@ class SlabRunner:
                 n, status = self.be.slab_assign_finish()
             if status == 0:
                 self.n_maxima = n
-                self.maxima = np.ravel_multi_index(tuple(self.be.maxima().T), self.shape) if n else np.zeros(0, np.int64)
+                self._maxima = None       # (the sorted maxima stay in the library until somebody asks: `maxima`)
                 return n
             if status == 2:
                 return None
@@ -266,7 +273,7 @@ class SlabRunner:
         if self.comm.size == 1 and hasattr(self.be, 'assign'):
             # one GPU: the library's own xb_assign (control flow on the device, one host wait)
             self.n_maxima = int(self.be.assign(method))
-            self.maxima = np.ravel_multi_index(tuple(self.be.maxima().T), self.shape) if self.n_maxima else np.zeros(0, np.int64)
+            self._maxima = None
             return self.n_maxima
         self._stepped = False
         if method == 'neargrid' and self._device_step():
@@ -305,7 +312,7 @@ class SlabRunner:
         with _Phase(self, 'assign_finish'):
             self.be.assign_finish(maxima)
         self.n_maxima = int(maxima.shape[0])
-        self.maxima = maxima
+        self._maxima = maxima
         return self.n_maxima
 
     def _gather_rows(self, rows):
