@@ -326,7 +326,7 @@ def main():
         n_basins, log = step()
     fence()
     dt = comm.max_float(time.perf_counter() - t0)       # max over ranks
-    host_waits = (ctx.host_waits() - waits0 - 1) / args.steps   # waits of this rank for its card inside library calls (less the fence's)
+    host_waits = (ctx.host_waits() - waits0 - 2) / args.steps   # waits of this rank for its card inside library calls (less the fence's two)
 
     nvox = float(np.prod(shape))
     # N > 1: where a slab step spends its time, from two EXTRA steps with a device sync around every scheduler phase
