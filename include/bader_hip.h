@@ -261,6 +261,9 @@ int xb_slow_path_stats(xb_ctx *c, int64_t *assign_total, int64_t *refine_total);
 /* retraces redone by the from-rho kernel since the context was created (their walk went on through a brick whose
  * records the sparse table does not hold) */
 int xb_deferred_stats(xb_ctx *c, int64_t *refine_total);
+/* region growth: assignments repeated because the scheduled kill launches (option 17; 6 after a chase) did not reach the
+ * fixpoint, and the schedule this context uses now (raised to the worst case by the first repeat) */
+int xb_growth_stats(xb_ctx *c, int64_t *retries, int64_t *kill_launches);
 
 /* ---- multi-GPU transport: RCCL over xGMI, one process per GPU (no PyTorch) ------------------------------------
  * Replaces nothing in the reference -- its thread blocks share one address space (thread_handlers.py:28-58,

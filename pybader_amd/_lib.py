@@ -80,6 +80,7 @@ SYMBOLS = {
     'xb_box_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_slow_path_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_deferred_stats': (_int, [_vp, _pi64]),
+    'xb_growth_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_comm_unique_id': (_int, [_vp]),
     'xb_comm_init': (_int, [_vp, _int, _int, _vp]),
     'xb_comm_destroy': (_int, [_vp]),
@@ -594,6 +595,12 @@ class Context:
     def slow_path_stats(self):
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_slow_path_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def growth_stats(self):
+        """(assignments repeated with the long kill schedule, kill launches scheduled now)"""
+        a, b = C.c_int64(), C.c_int64()
+        check(self.lib.xb_growth_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def deferred_stats(self):

@@ -308,6 +308,12 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
 }
+int xb_growth_stats(xb_ctx *c, int64_t *retries, int64_t *kill_launches) {
+    if (!c) return fail(XB_E_ARG, "null ctx");
+    if (retries) *retries = c->stat_grow_retries;
+    if (kill_launches) *kill_launches = c->grow_kill_launches;
+    return XB_OK;
+}
 int xb_deferred_stats(xb_ctx *c, int64_t *refine_total) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (refine_total) *refine_total = c->stat_deferred;

@@ -353,3 +353,27 @@ def test_tile_wise_dilation_leaves_the_same_flags(shape, lattice, noise, tol):
     assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3]
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
     print('first iteration:', a[1], 'near-edge voxels', int((a[2] == -1).sum()))
+
+
+def test_growth_that_outlasts_its_schedule_is_repeated_with_the_long_one():
+    """After the chase the kill iteration is given 6 launches; a cascade that runs deeper is noticed on the device, everything
+    downstream is skipped and the assignment is repeated with the worst-case schedule (which the context then keeps).
+    Forced here with a schedule of ONE launch: same map, same maxima, one repeat."""
+    shape = (192, 192, 192)
+    ctx = _lib.Context(0)
+    dm, tg = matrices(shape, synth.CUBIC6)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    ctx.vacuum_assign(None, 1.0)
+    n0 = ctx.assign('neargrid')
+    want, boxes = ctx.download_labels(np.int32), ctx.box_stats()
+    assert ctx.growth_stats() == (0, 6)
+    ctx.set_option(17, 1)
+    ctx.set_option(6, 1)
+    ctx.vacuum_assign(None, 1.0)
+    n1 = ctx.assign('neargrid')
+    assert ctx.growth_stats()[0] == 1 and ctx.growth_stats()[1] > 6
+    assert n1 == n0 and np.array_equal(ctx.download_labels(np.int32), want) and ctx.box_stats() == boxes
+    log = ctx.refine('changed', 2)
+    assert log[0][0] > 0
+    ctx.close()

@@ -113,7 +113,7 @@ class ShadowRcclComm(ThreadComm):
 
 
 def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None, synth_args=None, label_dtype=np.int32,
-              keep_pre=True, margin=8, comm_cls=ThreadComm):
+              keep_pre=True, margin=8, comm_cls=ThreadComm, options=()):
     """rho=None + synth_args=(lattice, atoms, background): every context generates the density on the device"""
     shape = rho.shape if rho is not None else tuple(shape)
     sh = Shared(n)
@@ -123,6 +123,8 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
         try:
             ctx = _lib.Context(0)
             comm = comm_cls(sh, rank)
+            for key, value in options:
+                ctx.set_option(key, value)
             if comm_cls is ShadowRcclComm:
                 ctx.comm_init(0, 1, ctx.comm_unique_id())
             runner = slab.SlabRunner(slab.GpuBackend(ctx, 0), comm, shape, g['dist_mat'], g['T_grad'], halo=halo)
@@ -142,7 +144,7 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
             w3 = ctx.host_waits()
             post = ctx.download_labels(label_dtype)[x0:x1].copy()
             ch, vo = ctx.charge_sum(1.0, nb)
-            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats(), ctx.memory_stats(), runner.n_device_steps, (w1 - w0, w3 - w2))
+            res[rank] = (x0, pre, post, log, runner.maxima, ch, vo, runner.n_fallbacks, win, ctx.slow_path_stats(), ctx.memory_stats(), runner.n_device_steps, (w1 - w0, w3 - w2), ctx.growth_stats(), bool(getattr(runner, '_step_declined', False)))
             ctx.close()
         except Exception as e:  # noqa: BLE001
             sh.errors.append(repr(e))
@@ -164,6 +166,8 @@ def run_slabs(n, g, rho, method, mode, iters, halo, tol, window=True, shape=None
     run_slabs.last_memory = [r[10] for r in res]
     run_slabs.last_device_steps = [r[11] for r in res]
     run_slabs.last_host_waits = [r[12] for r in res]
+    run_slabs.last_growth = [r[13] for r in res]
+    run_slabs.last_declined = [r[14] for r in res]
     print('device-driven steps per rank:', run_slabs.last_device_steps)
     return pre, post, res[0][3], res[0][4], ch, vo, max(r[7] for r in res)
 
@@ -465,3 +469,38 @@ def test_device_driven_step_issues_its_rccl_collectives():
     pre, post, log, maxima, ch, vo, fb = run_slabs(2, g, rho, 'neargrid', 'all', 2, 8, None, comm_cls=ShadowRcclComm)
     assert run_slabs.last_device_steps == [1, 1]
     assert np.array_equal(pre, g['ng_F'].astype(np.int32)) and np.array_equal(post, g['ng_all_2'].astype(np.int32))
+
+
+def test_device_driven_step_repeats_when_the_growth_outlasts_its_schedule():
+    """Status 1 of xb_slab_assign_finish: the kill launches scheduled after the chase (forced to ONE here) did not reach the
+    fixpoint -- every rank sees the same verdict (the growth is replicated), nothing downstream ran, the step is repeated
+    from pass A with the worst-case schedule.  Same map as always, one repeat per rank, two waits for the assignment."""
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    pre, post, log, maxima, ch, vo, fb = run_slabs(4, g, rho, 'neargrid', 'changed', 2, 8, None, options=((17, 1),))
+    assert run_slabs.last_device_steps == [1] * 4 and all(r == 1 for r, _ in run_slabs.last_growth)
+    assert [a for a, _ in run_slabs.last_host_waits] == [2] * 4
+    assert np.array_equal(pre, g['ng_F'].astype(np.int32)) and np.array_equal(post, g['ng_changed_2'].astype(np.int32))
+
+
+def test_device_driven_step_hands_a_density_with_thousands_of_maxima_to_the_host_driven_calls():
+    """Status 2 of xb_slab_assign_finish: a rank's maxima table does not fit the exchange block (1024 rows) -- every rank sees
+    it in the gathered tables, declines the numbering, and the scheduler repeats the assignment with the host-driven calls
+    (and stays with them for this density).  The map equals the one-context map."""
+    shape = (96, 96, 96)
+    vl = np.divide(synth.CUBIC6, shape)
+    g = {'dist_mat': distance_matrix(vl), 'T_grad': gradient_transform(vl)}
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, g['dist_mat'], g['T_grad'])
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    rho = np.ascontiguousarray(ctx.download_density() + 3e-2 * np.random.default_rng(11).random(shape))
+    ctx.upload_density(rho)
+    ctx.vacuum_assign(None, 1.0)
+    nb = ctx.assign('neargrid')
+    ref_log = ctx.refine('changed', 2)
+    want = ctx.download_labels(np.int32)
+    ctx.close()
+    assert nb > 2048
+    pre, post, log, maxima, ch, vo, fb = run_slabs(2, g, rho, 'neargrid', 'changed', 2, 8, None, keep_pre=False)
+    assert run_slabs.last_declined == [True, True] and run_slabs.last_device_steps == [0, 0]
+    assert np.array_equal(post, want) and log == ref_log and len(maxima) == nb
