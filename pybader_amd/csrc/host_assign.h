@@ -394,7 +394,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     c->box_max_tab = box_max;
     const int stride = XB_BOX_K + 4;
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
-    HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));
+    if (!sparse) HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));   // (the seed cubes' shell scans only)
     if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
         k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
         HIPCHK(hipGetLastError());
@@ -461,7 +461,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, sparse ? 0 : 1);
         if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
-        k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, sparse ? XB_REGIONS_MAX : XB_BOXES_MAX);
+        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, sparse ? XB_REGIONS_MAX : XB_BOXES_MAX);
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr,
                                                  sparse ? 0 : 1);
         HIPCHK(hipGetLastError());

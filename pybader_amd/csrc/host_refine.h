@@ -602,7 +602,8 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
     int *fs = c->fs;
     c->g.main_ties = 0;
     const GridL gl = light(g);
-    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 5 * sizeof(int), c->stream));   // edges, changed, escaped, overflows, deferred
+    static_assert(FS_N_TILES == FS_N_EDGES + 5, "one memset clears the refinement's counters");
+    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 6 * sizeof(int), c->stream));   // edges, changed, escaped, overflows, deferred, listed tiles
     {
         ScopedTimer t(c, 2);
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
@@ -623,7 +624,6 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
             ntiles_listed = ntiles;
             int *tiles = (int *)c->stage;
             HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
-            HIPCHK(hipMemsetAsync(fs + FS_N_TILES, 0, sizeof(int), c->stream));
             k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES, 0, g.nx / ET_X);
             k_edge_flag_listed<<<ntiles, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
                                                            c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1, tiles, fs + FS_N_TILES);

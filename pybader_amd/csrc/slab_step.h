@@ -328,7 +328,7 @@ int xb_slab_assign_trace(xb_ctx *c) {
         for (int l = 0; l < launches; l++)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
         if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
-        k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
+        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
         HIPCHK(hipGetLastError());
     }
