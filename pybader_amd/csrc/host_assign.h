@@ -391,6 +391,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     int *bmaxv = walk;   // (free until the walk list is made)
     int *bpot = c->list + 5 * nbr;   // brick potentials of the region growth (k_grow_parent); buf1 doubles as the parent array
     const bool chase = sparse && c->opt_chase;
+    int *bres = nullptr;   // per walk-list brick: the one maximum all its voxels ended on (k_ng_trace_g), for the edge sweep's uniformity
     c->box_max_tab = box_max;
     const int stride = XB_BOX_K + 4;
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
@@ -508,8 +509,10 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             if (gw > 1) {
                 const int groups = std::max(1, c->opt_trace_grid / gw), ch = std::max(8, c->opt_trace_chunk);
                 if (lean && gw == 8 && ch == 8 && c->opt_trace_cache) {   // one brick per pull: its records go through LDS
-                    if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
-                    else k_ng_trace_g<2, 3><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                    // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
+                    if (!c->has_vacuum) bres = c->list + 6 * nbr;
+                    if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
+                    else k_ng_trace_g<2, 3><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
                 } else
                 if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
                 else if (lean == 1) k_ng_trace_g<2, 1><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
@@ -534,7 +537,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         else
             k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
         k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
-        k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+        if (bres) k_buni_from_walk<<<256, 256, 0, c->stream>>>(walk, fs + FS_N_WALK, bres, c->first, buni, fs + FS_SORT_OK);
+        else k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
     } else
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
     k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);

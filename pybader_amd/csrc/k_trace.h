@@ -329,7 +329,7 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // trapping region ends with -2 like an undecidable one -- its start voxel goes to `ovf_list`, here the list of the
 // trajectories the caller redoes with records derived from rho (k_ng_trace_list)
 template <bool OFF32, bool CACHE, bool WINDOW = false>
-__device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+__device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
                                              int *labels, int *first, int *max_list, int *max_count, int max_cap,
                                              int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum,
@@ -409,6 +409,7 @@ __device__ __forceinline__ void ng_walk_lean(const GridL &g, const GradRec *__re
         const int k = atomicAdd(ovf_count, 1);
         if (k < ovf_cap) ovf_list[k] = v;
     }
+    return result;
 }
 // lane -> voxel of the 4x4x4 eighth `sub` of brick b (z fastest: 4 lanes per 128-B table line)
 __device__ __forceinline__ void brick_sub_voxel(int b, int sub, int lane, int nb1, int nb2, int &sx, int &sy, int &sz) {
@@ -537,9 +538,15 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                                                        const int *__restrict__ blab, int nb1, int nb2,
                                                        const int *__restrict__ walk, int *fs, int *labels, int *first,
                                                        int *max_list, int max_cap, int *ovf_list, int ovf_cap, int maxsteps,
-                                                       int has_vacuum, int CH, int xcd_split) {
+                                                       int has_vacuum, int CH, int xcd_split, int *__restrict__ bres = nullptr) {
     __shared__ int s_base, s_next;
+    // CACHE + bres: did every voxel of the brick in work end on ONE maximum?  (the edge sweep's per-brick uniformity without a
+    // pass over the labels.)  Per eighth the result of its lane 0, and a flag any lane raises whose result differs from it --
+    // plain LDS stores and loads in the wave's program order: no atomics (1024 of them on one address per brick cost 0.2 ms
+    // at 512^3), no cross-lane operations.
+    __shared__ int s_w[8], s_mixed;
     constexpr bool CACHE = LEAN >= 3;
+    int prev_brick = -1;
     __shared__ GradRec s_rec[CACHE ? 512 : 1];
     const int n_items = fs[FS_N_WALK] * 8;
     const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
@@ -551,6 +558,16 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
         for (;;) {
             __syncthreads();   // the previous chunk's readers are done with s_base / s_next
             if (threadIdx.x == 0) {
+                if (CACHE && bres) {
+                    if (prev_brick >= 0) {
+                        int r0 = s_mixed ? -1 : s_w[0];
+#pragma unroll
+                        for (int k = 1; k < 8; k++) r0 = (s_w[k] == r0) ? r0 : -1;
+                        bres[prev_brick] = r0 >= 0 ? r0 : (-2147483647 - 1);
+                    }
+                    prev_brick = -1;   // (written: a pull that finds its range empty must not write it again)
+                    s_mixed = 0;
+                }
                 s_base = beg + atomicAdd(&fs[FS_CURSOR0 + q * FS_CURSOR_STRIDE], CH);
                 s_next = 0;
             }
@@ -560,6 +577,7 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
             const int stop = min(base + CH, end);
             if (CACHE) {   // (CH == 8, base a multiple of 8: one brick) thread t copies the record of voxel t of the brick
                 const int b = walk[base >> 3];
+                prev_brick = b;
                 const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
                 const int t = threadIdx.x;
                 const int lt = lin24(g, b0 * 8 + (t >> 6), b1 * 8 + ((t >> 3) & 7), b2 * 8 + (t & 7));
@@ -573,13 +591,28 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 if (item >= stop) break;
                 int sx, sy, sz;
                 brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
-                if (LEAN)
-                    ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                if (LEAN) {
+                    const int res = ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                                                 max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0, s_rec);
+                    if (CACHE && bres) {
+                        volatile int *w = s_w;
+                        if (lane == 0) w[item & 7] = res;
+                        if (w[item & 7] != res) *(volatile int *)&s_mixed = 1;   // (same wave: the store above is older in its LDS queue)
+                    }
+                }
                 else
                     ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                            max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
             }
+        }
+    }
+    if (CACHE && bres) {   // the last brick this workgroup walked
+        __syncthreads();
+        if (threadIdx.x == 0 && prev_brick >= 0) {
+            int r0 = s_mixed ? -1 : s_w[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) r0 = (s_w[k] == r0) ? r0 : -1;
+            bres[prev_brick] = r0 >= 0 ? r0 : (-2147483647 - 1);
         }
     }
 }

@@ -377,3 +377,26 @@ def test_growth_that_outlasts_its_schedule_is_repeated_with_the_long_one():
     log = ctx.refine('changed', 2)
     assert log[0][0] > 0
     ctx.close()
+
+
+def test_brick_uniformity_left_by_the_walkers_equals_the_label_scan():
+    """The group trace leaves, per walk-list brick, the one maximum all its 512 voxels ended on (LDS min / max of the
+    walkers' results), which replaces k_label_uniform_list's pass over the labels for the edge sweep.  Checked where it
+    shows: the edge sweep's flags -- `known` after the first refinement iteration must equal the flags of a run whose
+    uniformity came from the label scan (the one-wave trace kernel, option 15 = 1, keeps the scan)."""
+    shape = (192, 192, 192)
+    ctx = _lib.Context(0)
+    dm, tg = matrices(shape, synth.TRICLINIC)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.TRICLINIC, synth.ATOMS8, synth.BACKGROUND)
+    res = []
+    for group in (8, 1):
+        ctx.set_option(15, group)
+        ctx.set_option(6, 1)
+        ctx.vacuum_assign(None, 1.0)
+        n = ctx.assign('neargrid')
+        log = ctx.refine('all', 1)
+        res.append((n, log, ctx.download_known(), ctx.download_labels(np.int32)))
+    ctx.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
