@@ -504,3 +504,41 @@ def test_device_driven_step_hands_a_density_with_thousands_of_maxima_to_the_host
     pre, post, log, maxima, ch, vo, fb = run_slabs(2, g, rho, 'neargrid', 'changed', 2, 8, None, keep_pre=False)
     assert run_slabs.last_declined == [True, True] and run_slabs.last_device_steps == [0, 0]
     assert np.array_equal(post, want) and log == ref_log and len(maxima) == nb
+
+
+@pytest.mark.parametrize('seed', [7, 11, 23])
+def test_random_decompositions_equal_one_context(seed):
+    """A seeded spread of decompositions -- 2 / 4 / 8 slabs, three lattices, halos 3-16, table margins 8-32 and the default,
+    every refinement mode, smooth densities and densities with noise far below the basin depths -- through the scheduler
+    (the device-driven step wherever it applies, the host-driven calls where it declines) against one context: same map,
+    same refinement log, same number of basins."""
+    hexa = np.array([[6.0, 0.0, 0.0], [-3.0, 5.196152422706632, 0.0], [0.0, 0.0, 7.0]])
+    rng = np.random.default_rng(seed)
+    stepped = 0
+    for _ in range(6):
+        n = int(rng.choice([2, 4, 8]))
+        shape = (max(int(rng.choice([64, 128, 192])), 16 * n), int(rng.choice([64, 80, 96])), int(rng.choice([64, 96, 128])))
+        lat = [synth.CUBIC6, synth.TRICLINIC, hexa][int(rng.integers(3))]
+        noise = float(rng.choice([0.0, 1e-7, 1e-6, 3e-6]))
+        halo = int(rng.choice([3, 4, 6, 8, 16]))
+        margin = rng.choice([None, 8, 16, 32])
+        mode, iters = [('changed', 2), ('all', 2), ('changed', -1), ('all', -1)][int(rng.integers(4))]
+        vl = np.divide(lat, shape)
+        g = {'dist_mat': distance_matrix(vl), 'T_grad': gradient_transform(vl)}
+        ctx = _lib.Context(0)
+        ctx.set_grid(shape, g['dist_mat'], g['T_grad'])
+        ctx.synth_density(lat, synth.ATOMS8, synth.BACKGROUND)
+        rho = ctx.download_density()
+        if noise:
+            rho = np.ascontiguousarray(rho + noise * np.random.default_rng(1).random(shape))
+            ctx.upload_density(rho)
+        ctx.vacuum_assign(None, 1.0)
+        nb = ctx.assign('neargrid')
+        ref_log = ctx.refine(mode, iters)
+        want = ctx.download_labels(np.int32)
+        ctx.close()
+        pre, post, log, maxima, ch, vo, fb = run_slabs(n, g, rho, 'neargrid', mode, iters, halo, None, keep_pre=False,
+                                                       margin=None if margin is None else int(margin))
+        assert np.array_equal(post, want) and log == ref_log and len(maxima) == nb, (n, shape, noise, halo, margin, mode, iters)
+        stepped += run_slabs.last_device_steps[0]
+    assert stepped >= 2     # (the device-driven step took its share of the cases)
