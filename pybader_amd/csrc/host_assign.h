@@ -54,7 +54,7 @@ static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int 
         k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
                                                          c->ovf_list + o, m, path.p, lmax, refine, c->first,
                                                          c->max_list, max_count, c->max_cap,
-                                                         changed, escaped, c->counters + 8, nullptr);
+                                                         changed, escaped, c->counters + 8, nullptr, c->has_vacuum ? 1 : 0);
     }
     hipError_t e = hipGetLastError();
     int err = 0;

@@ -644,7 +644,7 @@ __global__ void k_scatter_voxels(const int *__restrict__ idx, int n, const int *
 __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
                              int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
                              int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err,
-                             int *lens) {
+                             int *lens, int has_vacuum = 1) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int v = list[t];
@@ -701,7 +701,10 @@ __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels
         if (nv != vol_num) { labels[v] = nv; known[v] = -2; atomicAdd(changed, 1); }
         else known[v] = -1;
     } else {
-        if (result != v && labels[result] == -1) result = -1;
+        // the vacuum rule (methods.py:449-452) -- only with vacuum: without it `labels` is write-only during an assignment
+        // (a deferred labels := 0 was dropped, the regions' labels come later), and the label of the maximum's voxel may
+        // be whatever an earlier owner of the memory left there
+        if (has_vacuum && result != v && labels[result] == -1) result = -1;
         labels[v] = result;
         if (result >= 0) note_maximum(result, v, first, max_list, max_count, max_cap);
     }

@@ -107,3 +107,31 @@ def test_atom_map_and_per_atom_charges_through_the_drop_in(name):
             np.testing.assert_allclose(b.atoms_volume, g[tag + '_atoms_volume'], rtol=1e-6, atol=0)
             # the per-basin sums are the reference's too, permuted by the numbering: compare as multisets
             np.testing.assert_allclose(np.sort(b.bader_charge), np.sort(g[tag + '_bader_charge']), rtol=1e-6, atol=1e-12)
+
+
+def test_slow_path_does_not_read_labels_nobody_wrote():
+    """Found by a random soak against the oracle: without vacuum the assignment drops the deferred `labels := 0` (it writes
+    every label and reads none) -- but the exact slow kernel applied the vacuum rule (`labels[maximum] == -1`,
+    methods.py:449-452) unconditionally and read the label of a maximum nobody had written yet: whatever the memory held,
+    e.g. the -1 of a closed context's vacuum.  Here the label array is poisoned with -1 on purpose; a noisy density sends
+    a thousand trajectories to the slow kernel; the map must still be the oracle's own-trajectory map."""
+    import oracle
+    from pybader_amd import synth
+    from pybader_amd.interface import distance_matrix, gradient_transform
+    from rough_common import own_map, rank_labels
+    shape = (96, 48, 16)
+    vl = np.divide(synth.TRICLINIC, shape)
+    dm, tg = distance_matrix(vl), gradient_transform(vl)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.TRICLINIC, synth.ATOMS8, synth.BACKGROUND)
+    rho = np.ascontiguousarray(ctx.download_density() + 1e-6 * np.random.default_rng(72).random(shape))
+    ctx.upload_density(rho)
+    ctx.upload_labels(np.full(shape, -1, np.int32))
+    ctx.vacuum_assign(None, 1.0)
+    n = ctx.assign('neargrid')
+    got = ctx.download_labels(np.int64)
+    assert ctx.slow_path_stats()[0] > 100          # the path under test ran
+    ctx.close()
+    lab, maxima = rank_labels(own_map(rho, np.zeros(shape, np.int32), dm, tg, main_ties=True))
+    assert n == len(maxima) and np.array_equal(got, lab)
