@@ -51,7 +51,7 @@ def _enc(obj, out):
     elif isinstance(obj, (bytes, bytearray)):
         out.append(b'b' + struct.pack('<Q', len(obj)) + bytes(obj))
     elif isinstance(obj, np.ndarray):
-        a = np.ascontiguousarray(obj)
+        a = np.asarray(obj, order='C')     # (ascontiguousarray would turn a 0-d array into shape (1,))
         if a.dtype.str not in _DTYPES:
             raise TypeError(f'comm: dtype {a.dtype} does not travel')
         ds = a.dtype.str.encode()
@@ -108,8 +108,11 @@ def _dec(buf, pos):
         if any(d < 0 for d in shape):
             raise ValueError('comm: bad shape in a frame')
         dt = np.dtype(ds)
-        n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize if nd else dt.itemsize
-        if n > len(buf) - pos:
+        count = 1
+        for d in shape:                    # Python ints: a crafted shape cannot wrap the product
+            count *= int(d)
+        n = count * dt.itemsize
+        if n < 0 or n > len(buf) - pos:
             raise ValueError('comm: truncated frame')
         return np.frombuffer(buf, dt, count=n // dt.itemsize, offset=pos).reshape(shape).copy(), pos + n
     if tag in (b'l', b't'):
@@ -137,7 +140,10 @@ def _dec(buf, pos):
 
 
 def decode(buf):
-    obj, pos = _dec(memoryview(buf), 0)
+    try:
+        obj, pos = _dec(memoryview(buf), 0)
+    except struct.error as e:              # a frame that ends inside a fixed-size field
+        raise ValueError(f'comm: truncated frame ({e})') from None
     if pos != len(buf):
         raise ValueError('comm: trailing bytes in a frame')
     return obj
@@ -208,14 +214,26 @@ class SocketStore:
                 os.unlink(path)              # a stale file of an earlier run with the same key
             except FileNotFoundError:
                 pass
-            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+            # written under a private name (O_EXCL | O_NOFOLLOW, 0600) and moved into place: a reader sees the whole line or
+            # no file, never an empty one
+            tmp = f'{path}.{os.getpid()}.{secrets.token_hex(4)}.tmp'
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
             with os.fdopen(fd, 'w') as f:
                 f.write(f'{srv.getsockname()[1]} {token}\n')
+            os.replace(tmp, path)
             self._path = path
             slots = [None] * self.size
             while any(s is None for s in slots[1:]):
-                conn, _ = srv.accept()
-                conn.settimeout(min(timeout, 10.0))
+                left = deadline - time.monotonic()     # one deadline for the whole rendezvous, as on the clients' side
+                if left <= 0:
+                    srv.close()
+                    raise TimeoutError(f'rank 0: {sum(s is None for s in slots[1:])} of {self.size - 1} ranks did not join through {path}')
+                srv.settimeout(left)
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                conn.settimeout(min(timeout, 2.0))     # (a silent stranger holds the loop for two seconds at most)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 try:                         # fixed-size raw hello, authenticated before anything is decoded
                     hello = _recv_exact(conn, HELLO_BYTES)
@@ -568,12 +586,14 @@ class RcclComm(HostComm):
     def allgather_block(self, backend, which, parts):
         if not self.device:
             return super().allgather_block(backend, which, parts)
-        self.ctx.comm_allgather_block(which, [p[0] for p in parts], [p[1] for p in parts])
+        with self._guard('block allgather'):     # (the first collective on a communicator connects lazily: it can block on the host)
+            self.ctx.comm_allgather_block(which, [p[0] for p in parts], [p[1] for p in parts])
 
     def allreduce_block(self, backend):
         if not self.device:
             return super().allreduce_block(backend)
-        self.ctx.comm_allreduce_block()
+        with self._guard('block allreduce'):
+            self.ctx.comm_allreduce_block()
 
     def share_brick_masks(self, backend, chunks):
         ctx = self.ctx

@@ -172,6 +172,9 @@ struct xb_ctx {
     char *pin = nullptr;       // pinned staging for the small host arrays a step uploads (pageable copies pin pages on the fly)
     size_t pin_bytes = 0;
     std::vector<int> maxima_sorted;  // global, label order
+    int label_wire = 4;        // bytes per label that hold EVERY resident label (1 / 2 / 4): what the narrowed halo may travel in.
+                               // Follows whoever wrote the labels last: an assignment (dtype_calc(-n_maxima)), an upload (its dtype),
+                               // volume_assign (the largest atom index); planes or voxels written from outside make it 4
     std::vector<int> local_max, local_first;
     bool first_clean = false;
     int list_n = 0;            // entries of `list` that hold the owned known == -2 voxels ...
@@ -182,6 +185,8 @@ struct xb_ctx {
     long long n_alloc = 0;
 };
 
+// utils.dtype_calc(-n) as a byte width (utils.py:25-37): the narrowest signed type for labels 0..n-1 and -1
+static inline int label_wire_for(long long n) { return 2 * n <= 255 ? 1 : (2 * n <= 65535 ? 2 : 4); }
 static inline unsigned nblocks(long long n) { return (unsigned)((n + TPB - 1) / TPB); }
 static GridL light(const Grid &g) {
     GridL l;

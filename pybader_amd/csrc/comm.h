@@ -169,8 +169,9 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
     // Label planes travel in the narrowest signed type that holds every label (the reference's own dtype_calc(-n_maxima),
     // thread_handlers.py:70-74: int8 for every BASELINE configuration -- a quarter of the int32 bytes per halo): packed into
     // the staging buffer before the group, widened back behind it, all on the context's stream.
-    const size_t n_lab = c->maxima_sorted.size();
-    const int wire = (which == 0 && c->opt_narrow_halo && n_lab >= 1) ? (2 * n_lab <= 255 ? 1 : (2 * n_lab <= 65535 ? 2 : 4)) : (int)es;
+    // (the width follows whoever wrote the resident labels last -- xb_ctx::label_wire -- not the last assignment's basin count:
+    // an uploaded map with more basins than the assignment before it must not be truncated)
+    const int wire = (which == 0 && c->opt_narrow_halo) ? c->label_wire : (int)es;
     size_t total = 0;
     for (int i = 0; i < n_send; i++) total += (size_t)(send_xb[i] - send_xa[i]) * g.nyz;
     for (int i = 0; i < n_recv; i++) total += (size_t)(recv_xb[i] - recv_xa[i]) * g.nyz;

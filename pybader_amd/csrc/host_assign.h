@@ -307,6 +307,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     if (n_global > c->max_cap) return fail(XB_E_LIMIT, "xb_assign_finish: too many maxima");
     c->maxima_sorted.resize(n_global);
     for (int64_t i = 0; i < n_global; i++) c->maxima_sorted[i] = (int)max_idx_sorted[i];
+    c->label_wire = label_wire_for(n_global);
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     if (n_global) {
@@ -566,6 +567,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     c->stat_ovf_assign += novf;
     if (h[FS_SORT_OK] && novf == 0) {
         c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+        c->label_wire = label_wire_for(nmax);
         c->regions_pending = false;
         c->buni_valid = !c->has_vacuum;   // k_buni_from_regions + k_label_uniform_list ran
         c->regions_labels = !c->has_vacuum;

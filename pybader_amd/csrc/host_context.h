@@ -171,6 +171,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     c->table_stage = 0;
     c->has_grid = true;
     c->maxima_sorted.clear();
+    c->label_wire = 4;
     if (!c->first_clean) {
         k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, N);
         HIPCHK(hipGetLastError());
@@ -414,6 +415,7 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     c->buni_valid = false; c->regions_labels = false;
     const size_t sz = dtype_size(dtype);
     if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
+    c->label_wire = sz >= 4 ? 4 : (int)sz;   // what the caller's own dtype holds, the narrowed halo holds
     if (dtype == XB_I32) {
         if (int rc = staged_h2d(c, c->labels, labels_host, c->N * 4)) return rc;
     } else {
@@ -474,6 +476,7 @@ int xb_download_known(xb_ctx *c, int8_t *known_host) {
 int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac_charge, double *vac_volume) {
     NEED_GRID_RAW("xb_vacuum_assign");
     c->buni_valid = false; c->regions_labels = false;
+    c->label_wire = 1;   // every valid plane holds 0 / -1 from here on
     c->labels_zero_pending = false;
     if (vac_tol != vac_tol) {
         // vacuum_tol=None reaches the reference's sweep as NaN (interface.py:459): `rho <= NaN` is never

@@ -224,6 +224,7 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         c->list_valid = false;
         c->buni_valid = false; c->regions_labels = false;
         c->zero_outside[0] = -1;
+        c->label_wire = 4;
     } else {
         if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
         if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);

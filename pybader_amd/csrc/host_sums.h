@@ -40,7 +40,9 @@ int xb_volume_assign(xb_ctx *c, const int64_t *swap, int64_t n_swap) {
     if (n_swap <= 0) return XB_OK;
     if (n_swap > c->max_cap) return fail(XB_E_LIMIT, "xb_volume_assign: swap table too long");
     std::vector<int> s(n_swap);
-    for (int64_t i = 0; i < n_swap; i++) s[i] = (int)swap[i];
+    long long top = 0;
+    for (int64_t i = 0; i < n_swap; i++) { s[i] = (int)swap[i]; top = std::max<long long>(top, std::llabs((long long)swap[i]) + 1); }
+    c->label_wire = label_wire_for(top);
     const Grid &g = c->g;
     const long long own = (long long)(g.x1 - g.x0) * g.nyz;
     HIPCHK(hipMemcpyAsync(c->max_aux, s.data(), n_swap * sizeof(int), hipMemcpyHostToDevice, c->stream));

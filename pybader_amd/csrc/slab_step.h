@@ -444,6 +444,7 @@ int xb_slab_assign_finish(xb_ctx *c, int64_t *n_maxima, int64_t *status) {
                 h[FS_N_WALK], h[FS_N_RECL], h[FS_N_REDO], h[FS_N_BOXES]);
     const int nmax = h[FS_N_MAX];
     c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+    c->label_wire = label_wire_for(nmax);
     c->buni_valid = true;
     c->buni_halo_safe = true;
     c->regions_labels = true;

@@ -73,7 +73,9 @@ def release_labels(ctx):
 def track_labels(ctx, volumes):
     """the device labels equal `volumes` (just uploaded from it / downloaded into it)"""
     release_labels(ctx)
-    if ctx.pinned_density is not None and isinstance(volumes, np.ndarray) and volumes.flags.c_contiguous:
+    # (a view of a writeable array is not tracked: a write through its base would leave the device copy stale unnoticed)
+    if (ctx.pinned_density is not None and isinstance(volumes, np.ndarray) and volumes.flags.c_contiguous
+            and not (isinstance(volumes.base, np.ndarray) and volumes.base.flags.writeable)):
         ctx._labels_host, ctx._labels_was_writeable = volumes, bool(volumes.flags.writeable)
         volumes.flags.writeable = False
         ctx.resident_labels = _lab_identity(volumes)

@@ -473,6 +473,11 @@ CASES = {
                       modes=(('changed', 2), ('all', -1))),
     'c256_cubic': dict(shape=(256, 256, 256), lattice=synth.CUBIC6, full_maps=False, do_F=True,
                        modes=(('changed', 2),)),
+    # round 4: the headline size itself (BASELINE configs 3 and 5), hashes only
+    'c512_cubic': dict(shape=(512, 512, 512), lattice=synth.CUBIC6, full_maps=False, do_F=True,
+                       modes=(('changed', 2),)),
+    'c1024_cubic': dict(shape=(1024, 1024, 1024), lattice=synth.CUBIC6, full_maps=False, do_F=False,
+                        modes=(('changed', 2),)),
 }
 
 ROUGH = {

@@ -337,15 +337,27 @@ def test_rccl_transport_through_the_c_abi_single_rank():
     ctx.set_option(19, 1)
     for narrow, width in ((1, 1), (0, 4)):
         ctx.set_option(18, narrow)
-        ctx.upload_labels(before)
+        ctx.upload_labels(before.astype(np.int8))   # (the wire width follows the uploaded dtype: bader_calc hands refine its int8 map)
         sent0 = ctx.comm_bytes_sent()
         ctx.comm_exchange_planes(0, [(0, 3, 7), (0, 60, 62)], [(0, 40, 44), (0, 10, 12)])
         want = before.copy()
         want[40:44], want[10:12] = before[3:7], before[60:62]
         assert np.array_equal(ctx.download_labels(np.int32), want)
         assert ctx.comm_bytes_sent() - sent0 == 6 * nyz * width
-    ctx.set_option(19, 0)
+    # the wire width follows whoever wrote the labels last, not the last assignment's basin count -- a map with
+    # more basins than the 8-basin assignment above, uploaded for a standalone refine, must cross the halo untruncated
     ctx.set_option(18, 1)
+    many = (before.astype(np.int64) * 37 + (np.arange(before.size).reshape(before.shape) % 29)).astype(np.int32)   # labels 0..287
+    assert many.max() > 127
+    for up, width in ((many.astype(np.int16), 2), (many, 4)):
+        ctx.upload_labels(up)
+        sent0 = ctx.comm_bytes_sent()
+        ctx.comm_exchange_planes(0, [(0, 3, 7), (0, 60, 62)], [(0, 40, 44), (0, 10, 12)])
+        want = many.copy()
+        want[40:44], want[10:12] = many[3:7], many[60:62]
+        assert np.array_equal(ctx.download_labels(np.int32), want)
+        assert ctx.comm_bytes_sent() - sent0 == 6 * nyz * width
+    ctx.set_option(19, 0)
     # RcclComm.gather_rows through the device collectives (one rank: what comes back is what went in): the single
     # collective for short contributions, the second one for long ones
     from pybader_amd import comm as pcomm

@@ -360,8 +360,14 @@ def test_wire_codec_roundtrip_and_rejects_garbage():
     good = pcomm.encode(obj)
     for bad in (b'', b'Z', b'i\x00', good + b'x', good[:-3], b'l' + struct.pack('<Q', 1 << 60),
                 b'a\x03<f8\x01' + struct.pack('<q', 1 << 40), b'a\x03<c8\x01' + struct.pack('<q', 0), b's' + struct.pack('<Q', 99) + b'abc'):
-        with pytest.raises((ValueError, struct.error)):
+        with pytest.raises(ValueError):      # (also a frame that ends inside a fixed-size field: struct.error is re-raised)
             pcomm.decode(bad)
+    # a 0-d array keeps its shape; a crafted shape whose int64 product wraps is refused, not sliced
+    z = pcomm.decode(pcomm.encode(np.array(5.0)))
+    assert z.shape == () and float(z) == 5.0
+    wrap = b'a\x03<i8\x02' + struct.pack('<2q', 1 << 62, 4)          # 2^64 elements: wraps to 0 in int64
+    with pytest.raises(ValueError):
+        pcomm.decode(wrap)
     for unsendable in (object(), {1: {2, 3}}, np.zeros(2, np.complex128), np.array(['a'], dtype=object)):
         with pytest.raises(TypeError):
             pcomm.encode(unsendable)
