@@ -189,7 +189,8 @@ class Context:
     # -- residency --------------------------------------------------------------------------
     def set_grid(self, shape, dist_mat, T_grad, x_range=None):
         shape = tuple(int(s) for s in shape)
-        self.drop_label_token()     # (a new grid: no host array equals the device labels any more)
+        if shape != getattr(self, 'shape', None):
+            self.drop_label_token()     # (another grid: no host array equals the device labels any more)
         x0, x1 = (0, shape[0]) if x_range is None else x_range
         sh = np.array(shape, dtype=np.int64)
         dm, tg = _f64(dist_mat).reshape(27), _f64(T_grad).reshape(9)

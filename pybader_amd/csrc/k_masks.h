@@ -25,6 +25,9 @@
 // and mirrored for negative d.  The thresholds below are 2e-12: a superset of the exact intervals in the two slivers
 // of width 1e-12, equal everywhere else (soundness only needs a superset).
 #define BM_EPS 2e-12
+#ifndef BM_STAGE
+#define BM_STAGE 1   // 0: round 3's staging (kept for A/B runs of the two builds)
+#endif
 #ifdef XB_DEBUG_COUNT
 __device__ unsigned long long xb_dbg[16];
 #endif
@@ -37,15 +40,47 @@ __device__ unsigned long long xb_dbg[16];
 //           x-face either -- there wave 3 skips the gradient altogether (only the maximum test is left).
 // A border wave needs the ongrid face test on its own faces only, and a field that points the same way across the tile
 // leaves one of the two border waves without any face to test.
+#ifndef BM_LAYOUT
+#define BM_LAYOUT 1   // 0: round 3's column order and row stride (kept for A/B runs of the two builds)
+#endif
 #ifndef BM_ROW
+#if BM_LAYOUT
+// Round 4: the 9 ds_read_b64 of a voxel are served per 32-lane half, bank pair = (address / 8) mod 32 = (35 ty + tz) mod 32
+// at a row stride of 35 doubles.  The order below keeps the four wave classes and arranges every half so that its 32 columns
+// fall on distinct bank pairs (waves 0 and 1: both halves; waves 2 and 3: one half, two columns per pair at most in the
+// other) -- 10 LDS cycles per read of the workgroup where 8 is the floor and round 3's order took 20 (its conflict cycles
+// were three times the cycles the reads themselves needed: profiles/r3_final_pmc_sq_512_neargrid.txt).  A linear layout cannot
+// do better with these classes: the low-side columns want an odd stride, the deep ones a stride of 4 mod 8
+// (scratch analysis).
+#define BM_ROW 35
+#else
 #define BM_ROW 38   // row length of the LDS tile in doubles (34 are used): with the column order below the 9 reads per voxel
 #endif              // meet fewer bank conflicts at a stride of 38 or 39 -- worth 2 % of the kernel (0.918 -> 0.90 ms): LDS time hides behind the VALU work
+#endif
 __device__ __forceinline__ void bm_second_layer(int i, int &yy, int &zz) {   // i = 0..19: the ring y, z in 1..6 with y or z in {1, 6}
     if (i < 6) { yy = 1; zz = 1 + i; }            // y == 1, z 1..6   (i == 0 is (1,1))
     else if (i < 12) { yy = 6; zz = i - 5; }      // y == 6, z 1..6
     else if (i < 16) { yy = i - 10; zz = 1; }     // z == 1, y 2..5
     else { yy = i - 14; zz = 6; }                 // z == 6, y 2..5
 }
+#if BM_LAYOUT
+// thread -> column, (ty << 5) | tz.  Waves as above: 0 the low-side border columns (+ the mixed corners, + (1,5) of each brick),
+// 1 the high-side ones (+ (1,1), (1,2), (1,4)), 2 the other second-layer columns, 3 the deep ones.
+__device__ const unsigned char bm_column_tab[TPB] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31,
+    37, 32, 64, 96, 128, 160, 192, 224, 45, 40, 72, 104, 136, 168, 200, 232, 53, 48, 80, 112, 144, 176, 208, 240, 61, 56, 88, 120, 152, 184, 216, 248,
+    225, 226, 227, 228, 229, 230, 231, 71, 233, 234, 235, 236, 237, 238, 239, 79, 241, 242, 243, 244, 245, 246, 247, 87, 249, 250, 251, 252, 253, 254, 255, 95,
+    39, 103, 135, 167, 199, 33, 34, 36, 47, 111, 143, 175, 207, 41, 42, 44, 55, 119, 151, 183, 215, 49, 50, 52, 63, 127, 159, 191, 223, 57, 58, 60,
+    195, 129, 197, 65, 198, 97, 194, 35, 203, 137, 205, 73, 206, 105, 202, 43, 211, 145, 213, 81, 214, 113, 210, 51, 219, 153, 221, 89, 222, 121, 218, 59,
+    166, 102, 161, 134, 70, 196, 38, 193, 174, 110, 169, 142, 78, 204, 46, 201, 182, 118, 177, 150, 86, 212, 54, 209, 190, 126, 185, 158, 94, 220, 62, 217,
+    98, 130, 132, 133, 162, 163, 164, 165, 106, 138, 140, 141, 170, 171, 172, 173, 114, 146, 148, 149, 178, 179, 180, 181, 122, 154, 156, 157, 186, 187, 188, 189,
+    66, 67, 68, 69, 99, 100, 101, 131, 74, 75, 76, 77, 107, 108, 109, 139, 82, 83, 84, 85, 115, 116, 117, 147, 90, 91, 92, 93, 123, 124, 125, 155,
+};
+__device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
+    const int c = bm_column_tab[t];
+    ty = c >> 5; tz = c & 31;
+}
+#else
 __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
     int bz, yy, zz;
     if (t < 60) {            // wave 0: per brick 13 low-side columns + 2 mixed corners
@@ -75,6 +110,7 @@ __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
     }
     ty = yy; tz = bz * 8 + zz;
 }
+#endif
 
 // v_max_f64 without the canonicalisation fmax() adds for operands that come straight from memory (no NaNs in a density)
 __device__ __forceinline__ double max_raw(double a, double b) {
@@ -281,6 +317,69 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
     }
 }
 
+// (SMALL: a grid so small that the tile's halo wraps more than once -- true modulo instead of the two unsigned minima)
+template <bool SMALL, typename GT>
+__device__ __forceinline__ void bm_stage(const GT &g, const double *__restrict__ rho, double (&tile)[GT_X + 2][GT_Y + 2][BM_ROW], unsigned *s_bmax,
+                                         int x0, int y0, int z0, int mirror) {
+    {   // Staging of the haloed 10 x 10 x 34 tile, every load of a wave in flight before the first wait.
+        // Round 4: the address of a row is ONE scalar addition.  (Round 3 derived every row's (x, y) -- a division, two wraps, two
+        // multiplications -- on the scalar unit and predicated every load by `lane < 34` with an exec branch of its own: ~30 SALU
+        // instructions in front of each of the 25 loads of a wave, 750 of the ~1000 SALU instructions a wave issued per tile,
+        // on a scalar unit the boolean algebra of the x-walk needs as well.)  Wave w stages the x-planes w, w + 4 (and w + 8
+        // for w < 2) of the tile, ten rows each: the plane's byte offset is one scalar (its periodic wrap included), the ten
+        // row offsets of the y halo are computed once per wave, the z wrap once per lane; lanes beyond the 34 doubles of a row
+        // repeat lane 33's address (no exec change).  32-bit byte offsets inside a plane: planes up to 2^29 voxels.
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
+        const int lz = min(lane, GT_Z + 1);
+        int Z = z0 + lz - 1;
+        unsigned Yw[GT_Y + 2];   // byte offsets of the rows inside a plane (scalars)
+        Z = SMALL ? ((Z % g.nz) + g.nz) % g.nz : wrap_u(Z, g.nz);
+        const unsigned zoff = (unsigned)Z * 8u;   // the lane's byte offset inside a row: scalar row base + 32-bit lane offset
+#pragma unroll
+        for (int ey = 0; ey < GT_Y + 2; ey++) {
+            int Y = y0 + ey - 1;
+            if (SMALL) Y = ((Y % g.ny) + g.ny) % g.ny;
+            else if (ey == 0 || ey == GT_Y + 1) Y = wrap_u(Y, g.ny);
+            Yw[ey] = (unsigned)(Y * g.nz) * 8u;   // (interior rows of the tile never wrap: whole-brick grids; a partial tile's rows beyond the grid are not read)
+        }
+        constexpr int PL = (GT_X + 2 + 3) / 4;   // x-planes per wave (the last one only for the waves that have it)
+        double val[PL][GT_Y + 2];
+#pragma unroll
+        for (int j = 0; j < PL; j++) {
+            const int ex = wv + 4 * j;
+            if (ex < GT_X + 2) {   // wave uniform
+                int X = x0 + ex - 1;
+                X = SMALL ? ((X % g.nx) + g.nx) % g.nx : wrap_u(X, g.nx);
+                const char *plane = reinterpret_cast<const char *>(rho + (size_t)X * g.nyz);   // scalar
+#pragma unroll
+                for (int ey = 0; ey < GT_Y + 2; ey++) val[j][ey] = *reinterpret_cast<const double *>(plane + Yw[ey] + zoff);
+            } else {
+#pragma unroll
+                for (int ey = 0; ey < GT_Y + 2; ey++) val[j][ey] = 0.;
+            }
+        }
+        if (lane < GT_Z + 2) {
+#pragma unroll
+            for (int j = 0; j < PL; j++) {
+                const int ex = wv + 4 * j;
+                if (ex < GT_X + 2) {
+#pragma unroll
+                    for (int ey = 0; ey < GT_Y + 2; ey++) tile[ex][ey][lane] = val[j][ey];
+                }
+            }
+        }
+        if (mirror) {
+            unsigned hi = 0;
+#pragma unroll
+            for (int j = 0; j < PL; j++)
+#pragma unroll
+                for (int ey = 0; ey < GT_Y + 2; ey++) hi = max(hi, (unsigned)__double2hiint(val[j][ey]) & 0x7fffffffu);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) hi = max(hi, (unsigned)__shfl_xor((int)hi, o));
+            if (lane == 0) atomicMax(s_bmax, hi);
+        }
+    }
+}
 template <typename GT, int MT, bool DIAG>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
                                                      int *__restrict__ bmaxv, int *tie_count, int xbase, double mu_scale, int mirror,
@@ -293,6 +392,7 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; s_pot[threadIdx.x] = -2147483647 - 1; }
     if (threadIdx.x == 0) s_bmax = 0;
     __syncthreads();
+#if BM_STAGE == 0
     {   // row-wise staging, every load of a wave in flight before the first wait (see k_grad_field)
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
         int Z = z0 + lane - 1;
@@ -327,6 +427,10 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
             if (lane == 0) atomicMax(&s_bmax, hi);
         }
     }
+#else
+    if (small & 1) bm_stage<true>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
+    else bm_stage<false>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
+#endif
     __syncthreads();
     // mu: see bm_mirror; the double whose high word is s_bmax + 1 bounds every |rho| of the tile from above
     const double mu = mirror ? __hiloint2double((int)min(s_bmax + 1u, 0x7ff00000u), 0) * mu_scale : 0.;
@@ -393,39 +497,65 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
 // goes through LDS, every thread derives two records (k_grad_field's arithmetic).  The brick list is either the walk
 // list (`walk`, length *n_list on the device) or, with walk == nullptr, every brick whose brick_rec flag is already
 // set (a rebuild under the other tie rule).
+// Round 4: (i) everything about a thread's four halo elements and two voxels that does not depend on the brick -- their
+// offsets from the brick's corner in the density, in the tile and in the table -- is computed ONCE per thread, before the loop
+// over the bricks; a brick whose halo does not touch the faces of the grid (all but a few per cent) then stages its tile with
+// one addition per load.  Round 3 redid the divisions and products per element and brick: 65 quarter-rate integer
+// multiplications per thread and brick, about a third of the kernel's VALU cycles.  (ii) The tile rows are 24 doubles apart:
+// the 32 lanes of a half wave (4 rows of 8 voxels) then fall on 32 distinct bank pairs for every (ix, iy, iz) of the scan,
+// whether the compiler reads them with ds_read_b64 or pairs them into ds_read2_b64 (16-lane groups, banks of 16 doubles);
+// at a stride of 10 every read met a two-way conflict.  Measured: 0.333 -> 0.319 ms at 512^3.  Tried on top and dropped: the halo of the
+// NEXT brick fetched into registers under the scan of the current one (0.336-0.348 ms: the kernel moves 48 B per voxel at
+// 3.4 TB/s and is 50-60 % VALU busy -- no single latency to hide), one x-plane of the scan at a time (same registers).
+#define BR_ROW 24
 template <typename GT>
-__global__ __launch_bounds__(TPB) void k_brick_records(GT g, const double *__restrict__ rho, GradRec *__restrict__ G,
+__global__ __launch_bounds__(TPB, 4) void k_brick_records(GT g, const double *__restrict__ rho, GradRec *__restrict__ G,
                                                        const int *__restrict__ walk, const int *n_list, int nbr, int nb1, int nb2,
                                                        unsigned char *brick_rec, int small) {
-    __shared__ double tile[10][10][10];
+    __shared__ double tile[10][10][BR_ROW];
     const int n = walk ? *n_list : nbr;
+    int goff[4], loff[4];   // halo element e = threadIdx.x + j * TPB of the 10^3 tile: offset from the corner voxel (no wrap), slot in the tile
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int e = threadIdx.x + j * TPB;
+        const int ex = e / 100, ey = (e / 10) % 10, ez = e % 10;
+        goff[j] = (ex * g.ny + ey) * g.nz + ez;
+        loff[j] = (ex * 10 + ey) * BR_ROW + ez;
+    }
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
         const int b = walk ? walk[item] : item;
         if (!walk && !(brick_rec[b] & 1)) continue;   // uniform per block
         const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
         const int x0 = b0 * 8, y0 = b1 * 8, z0 = b2 * 8;
+        // the haloed brick lies inside the grid: no periodic wrap anywhere (block uniform)
+        const bool inner = !(small & 1) && x0 >= 1 && x0 + 8 < g.nx && y0 >= 1 && y0 + 8 < g.ny && z0 >= 1 && z0 + 8 < g.nz;
         __syncthreads();   // the previous turn's readers are done with the tile
         {
             double val[4];
+            if (inner) {
+                const double *corner = rho + ((size_t)(x0 - 1) * g.ny + (y0 - 1)) * g.nz + (z0 - 1);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int e = threadIdx.x + j * TPB;
-                const int ex = e / 100, ey = (e / 10) % 10, ez = e % 10;
-                int X = x0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
-                if (small & 1) {
-                    X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
-                } else {
-                    X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+                for (int j = 0; j < 4; j++) val[j] = (threadIdx.x + j * TPB < 1000) ? corner[goff[j]] : 0.;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = threadIdx.x + j * TPB;
+                    const int ex = e / 100, ey = (e / 10) % 10, ez = e % 10;
+                    int X = x0 + ex - 1, Y = y0 + ey - 1, Z = z0 + ez - 1;
+                    if (small & 1) {
+                        X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
+                    } else {
+                        X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny); Z = wrap_u(Z, g.nz);
+                    }
+                    val[j] = e < 1000 ? rho[(X * g.ny + Y) * g.nz + Z] : 0.;
                 }
-                val[j] = e < 1000 ? rho[(X * g.ny + Y) * g.nz + Z] : 0.;
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int e = threadIdx.x + j * TPB;
-                if (e < 1000) (&tile[0][0][0])[e] = val[j];
-            }
+            for (int j = 0; j < 4; j++)
+                if (threadIdx.x + j * TPB < 1000) (&tile[0][0][0])[loff[j]] = val[j];
         }
         __syncthreads();
+        const int vbase = (x0 * g.ny + y0) * g.nz + z0;
 #pragma unroll 1
         for (int j = 0; j < 2; j++) {
             const int l = threadIdx.x + j * TPB;
@@ -434,7 +564,7 @@ __global__ __launch_bounds__(TPB) void k_brick_records(GT g, const double *__res
             double max_val = c;
             int og = XB_OG_SELF;
 #pragma unroll
-            for (int ix = 0; ix < 3; ix++)
+            for (int ix = 0; ix < 3; ix++) {
 #pragma unroll
                 for (int iy = 0; iy < 3; iy++)
 #pragma unroll
@@ -445,6 +575,7 @@ __global__ __launch_bounds__(TPB) void k_brick_records(GT g, const double *__res
                         og = (w > max_val) ? ix * 9 + iy * 3 + iz : og;
                         max_val = fmax(max_val, w);
                     }
+            }
             GradRec o;
             double d0, d1, d2;
             int code;
@@ -460,7 +591,7 @@ __global__ __launch_bounds__(TPB) void k_brick_records(GT g, const double *__res
                 code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
             }
             o.key = pack_key(c, code, og);
-            G[rec_slot(g, ((x0 + tx) * g.ny + (y0 + ty)) * g.nz + z0 + tz)] = o;
+            G[rec_slot(g, vbase + (tx * g.ny + ty) * g.nz + tz)] = o;
         }
         if (threadIdx.x == 0) brick_rec[b] |= 1;
     }
