@@ -76,9 +76,9 @@ static int edge_find_launch(xb_ctx *c, bool *dilate_owned) {
             k_edge_tile_list<<<(n_own + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_own, c->counters + 22, g.x0 / ET_X, own / ET_X);
             k_edge_tile_list<<<(n_halo / 2 + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_halo, c->counters + 23, left0 / ET_X, side4 / ET_X);
             k_edge_tile_list<<<(n_halo / 2 + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles_halo, c->counters + 23, right0 / ET_X, side4 / ET_X);
-            k_edge_flag_listed<<<n_own, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, c->counters + 5, small, G, brec,
+            k_edge_flag_listed<<<std::min(n_own, 2048), TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, c->counters + 5, small, G, brec,
                                                             c->has_vacuum ? 0 : 1, tiles_own, c->counters + 22);
-            k_edge_flag_listed<<<n_halo, TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, halo_list, c->counters + 6, small, G, brec,
+            k_edge_flag_listed<<<std::min(n_halo, 2048), TPB, 0, c->stream>>>(ga, c->rho, c->labels, c->known, halo_list, c->counters + 6, small, G, brec,
                                                              c->has_vacuum ? 0 : 1, tiles_halo, c->counters + 23);
             k_edge_dilate_list<<<2048, TPB, 0, c->stream>>>(gl, c->known, halo_list, 0, c->counters + 6);
         } else {
@@ -626,7 +626,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
             int *tiles = (int *)c->stage;
             HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
             k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES, 0, g.nx / ET_X);
-            k_edge_flag_listed<<<ntiles, TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
+            k_edge_flag_listed<<<std::min(ntiles, 2048), TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
                                                            c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1, tiles, fs + FS_N_TILES);
         } else {
             dim3 grid((g.nz + ET_Z - 1) / ET_Z, (g.ny + ET_Y - 1) / ET_Y, (g.nx + ET_X - 1) / ET_X);
@@ -641,11 +641,13 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
     {
         ScopedTimer t(c, 3);
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
+        const int regions_ok = c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0;
+        int *defer = (int *)c->stage;
         k_refine_trace<2, false><<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, fs + FS_N_EDGES,
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
-                                                              c->ovf_cap, maxsteps, c->rho, c->dist_dev,
-                                                              c->grad_cover == 1 ? c->brick_rec : nullptr, (int *)c->stage, fs + FS_R_DEFER,
-                                                              c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0, nullptr, WalkerIO{});
+                                                              c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, defer, fs + FS_R_DEFER,
+                                                              regions_ok, nullptr, WalkerIO{});
         if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
             k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
                                                                fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,

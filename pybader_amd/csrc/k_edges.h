@@ -153,6 +153,9 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known
 // neighbourhoods, and the block appends its owned edge voxels to the edge list with ONE atomic
 // (the list length is the edge count edge_find returns).  rho is only read for the few voxels
 // that have a foreign neighbour (the is_max test, refinement.py:374-375).
+#ifndef EDGE_P2_NEW
+#define EDGE_P2_NEW 1
+#endif
 #define ET_X 4
 #define ET_Y 8
 #define ET_Z 64
@@ -161,23 +164,26 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
                                           int8_t *__restrict__ known, int xa, int nplanes, int *__restrict__ list,
                                           int *list_count, int small, const int *__restrict__ buni,
                                           const GradRec *__restrict__ G, const unsigned char *__restrict__ brick_rec,
-                                          int no_vacuum, int tx0, int y0, int z0) {
+                                          int no_vacuum, int tx0, int y0, int z0, int salt = 0) {
+    // (salt: always 0, but opaque to the compiler when the caller loops over tiles -- everything derived from the thread index
+    // then counts as loop variant, and the ~60 LDS row addresses are not carried in registers across iterations)
+    const int tid = (int)threadIdx.x + salt;
     __shared__ int tile[ET_X + 2][ET_Y + 2][ET_Z + 2];
     if (buni) {
         // `buni` here is buni3 (k_buni3): a brick entry says that the brick and all its 26 neighbours carry one
         // label, so the bricks the tile itself lies in (1-2 in x, one in y, ET_Z/8 in z) settle the tile plus
         // its one-voxel halo: no voxel of it has a foreign neighbour
         __shared__ int s_lab, s_mixed;
-        if (threadIdx.x == 0) { s_lab = XB_MIXED; s_mixed = 0; }
+        if (tid == 0) { s_lab = XB_MIXED; s_mixed = 0; }
         __syncthreads();
         const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
         int X0 = xa + tx0, X1 = xa + min(tx0 + ET_X, nplanes) - 1;
         if (X0 >= g.nx) X0 -= g.nx;
         if (X1 >= g.nx) X1 -= g.nx;
         const int bxa = X0 >> 3, bxb = X1 >> 3, nbz = min(ET_Z / 8, nb2 - (z0 >> 3));
-        if ((int)threadIdx.x < 2 * nbz) {
-            const int bx = (threadIdx.x & 1) ? bxb : bxa;
-            const int l = buni[(bx * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + (threadIdx.x >> 1)];
+        if ((int)tid < 2 * nbz) {
+            const int bx = (tid & 1) ? bxb : bxa;
+            const int l = buni[(bx * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + (tid >> 1)];
             if (l == XB_MIXED) s_mixed = 1;
             else {
                 const int old = atomicCAS(&s_lab, XB_MIXED, l);
@@ -188,8 +194,8 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
         if (!s_mixed) {
             const int8_t o = (s_lab == -1) ? 0 : 2;  // vacuum stays 0 (refinement.py:342-343), else "known"
             if ((g.nz & 15) == 0 && z0 + ET_Z <= g.nz) {   // 16-byte stores: 32 rows of 64 flags, 4 threads per row
-                if (threadIdx.x < 128) {
-                    const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
+                if (tid < 128) {
+                    const int row = tid >> 2, seg = tid & 3;
                     const int xr = tx0 + (row >> 3), y = y0 + (row & 7);
                     if (xr < nplanes && y < g.ny) {
                         int x = xa + xr;
@@ -200,7 +206,7 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
                 }
                 return;
             }
-            const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+            const int tz = tid & 63, tyb = tid >> 6;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int xr = tx0 + (k >> 1), y = y0 + tyb + ((k & 1) << 2), z = z0 + tz;
@@ -213,34 +219,43 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
             return;
         }
     }
+    // the brick bytes (records exist / holds a maximum) of the bricks under the tile's voxels, per x-plane of the tile and
+    // 8-voxel run of z: pass 2 asks them per edge candidate (round 3: a dependent global byte load in front of every candidate)
+    __shared__ unsigned char s_binfo[ET_X][ET_Z / 8];
     {
-        // row-wise staging with every load of a wave in flight before the first wait (see k_grad_field): a
-        // wave takes whole z-rows (64 aligned labels per row, x/y wrap is wave-uniform scalar work); the two
-        // halo labels of each row are fetched by the first 2*rows threads
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
+        // Row-wise staging, every load of a wave in flight before the first wait.  Round 4 (as in k_brick_masks): a row's address
+        // is one scalar addition -- wave w stages rows y0-1+ey of all six x-planes for its own two or three ey (3, 3, 2, 2),
+        // plane bases and row offsets are scalars computed once, the z wrap once per lane.  Round 3 derived (x, y) of each of a
+        // wave's 15 rows on the scalar unit: a division, three wraps, two products and the `small` branch per row.
+        const int wv = __builtin_amdgcn_readfirstlane(tid / XB_WAVE), lane = tid % XB_WAVE;
         constexpr int NROW = (ET_X + 2) * (ET_Y + 2);
-        constexpr int ROWS = NROW / (TPB / XB_WAVE);
-        static_assert(ROWS * (TPB / XB_WAVE) == NROW && ET_Z == XB_WAVE && 2 * NROW <= TPB, "tile shape");
+        static_assert(ET_Z == XB_WAVE && 2 * NROW <= TPB && TPB / XB_WAVE == 4 && ET_Y + 2 == 10, "tile shape");
         int Zc = z0 + lane;
         if (small) Zc %= g.nz;
         else Zc = wrap_u(Zc, g.nz);
-        int val[ROWS];
+        const int ey0 = wv < 2 ? 3 * wv : 2 * wv + 2, ney = wv < 2 ? 3 : 2;   // rows 0-2, 3-5, 6-7, 8-9
+        int yoff[3];
 #pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const int r = wv + k * (TPB / XB_WAVE);
-            const int ex = r / (ET_Y + 2), ey = r - ex * (ET_Y + 2);
-            int X = xa + tx0 + ex - 1, Y = y0 + ey - 1;
-            if (small) {
-                X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny;
-            } else {
-                X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny);
-            }
-            val[k] = labels[(X * g.ny + Y) * g.nz + Zc];
+        for (int j = 0; j < 3; j++) {
+            int Y = y0 + ey0 + j - 1;
+            if (small) Y = ((Y % g.ny) + g.ny) % g.ny;
+            else Y = wrap_u(Y, g.ny);
+            yoff[j] = Y * g.nz;
+        }
+        int val[ET_X + 2][3];
+#pragma unroll
+        for (int ex = 0; ex < ET_X + 2; ex++) {
+            int X = xa + tx0 + ex - 1;
+            if (small) X = ((X % g.nx) + g.nx) % g.nx;
+            else { X = wrap_u(X, g.nx); X = wrap_u(X, g.nx); }
+            const int *plane = labels + (size_t)X * g.nyz;
+#pragma unroll
+            for (int j = 0; j < 3; j++) val[ex][j] = (j < ney) ? plane[yoff[j] + Zc] : 0;
         }
         int hv = 0;
-        const int hr = threadIdx.x >> 1, hside = threadIdx.x & 1;
+        const int hr = tid >> 1, hside = tid & 1;
         const int hex = hr / (ET_Y + 2), hey = hr - hex * (ET_Y + 2);
-        if (threadIdx.x < 2 * NROW) {
+        if (tid < 2 * NROW) {
             int X = xa + tx0 + hex - 1, Y = y0 + hey - 1, Z = hside ? z0 + ET_Z : z0 - 1;
             if (small) {
                 X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny; Z = ((Z % g.nz) + g.nz) % g.nz;
@@ -249,16 +264,22 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
             }
             hv = labels[(X * g.ny + Y) * g.nz + Z];
         }
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const int r = wv + k * (TPB / XB_WAVE);
-            const int ex = r / (ET_Y + 2), ey = r - ex * (ET_Y + 2);
-            tile[ex][ey][lane + 1] = val[k];
+        if (tid >= TPB - ET_X * (ET_Z / 8)) {   // the last 32 threads: one brick byte each
+            const int i = tid - (TPB - ET_X * (ET_Z / 8)), tx = i / (ET_Z / 8), zb = i % (ET_Z / 8);
+            int x = xa + tx0 + tx;
+            if (x >= g.nx) x -= g.nx;
+            const int nb1 = (g.ny + 7) >> 3, nb2 = (g.nz + 7) >> 3, bz = (z0 >> 3) + zb;
+            s_binfo[tx][zb] = (brick_rec && bz < nb2 && y0 < g.ny) ? brick_rec[((x >> 3) * nb1 + (y0 >> 3)) * nb2 + bz] : (unsigned char)1;
         }
-        if (threadIdx.x < 2 * NROW) tile[hex][hey][hside ? ET_Z + 1 : 0] = hv;
+#pragma unroll
+        for (int ex = 0; ex < ET_X + 2; ex++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (j < ney) tile[ex][ey0 + j][lane + 1] = val[ex][j];
+        if (tid < 2 * NROW) tile[hex][hey][hside ? ET_Z + 1 : 0] = hv;
     }
     __syncthreads();
-    const int tz = threadIdx.x & 63, tyb = threadIdx.x >> 6;
+    const int tz = tid & 63, tyb = tid >> 6;
     // "some non-vacuum neighbour carries another label" (refinement.py:357-372) is separable: with vacuum (-1) read as
     // the largest unsigned value, it holds iff the unsigned minimum of the 27 labels is below the voxel's own label or
     // their signed maximum above it.  Minima / maxima along z per (x, y) row, then over y for the thread's two y
@@ -296,6 +317,74 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
             }
         }
     }
+#if EDGE_P2_NEW
+    // pass 2: refinement.py:374-383, an edge unless it is a 26-neighbour maximum.  Round 4: the brick byte comes from LDS, and
+    // the table keys the candidates need are gathered TOGETHER (one 8-byte load per candidate, all in flight) -- round 3 walked
+    // the candidates one by one, a brick byte and then a record per candidate: up to eight times two dependent loads per
+    // thread, the reason the sweep of a listed tile took ~25 us.
+    unsigned edges = 0, full = 0;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {   // the thread's voxels four at a time (the keys of eight at once cost the kernel its occupancy)
+        if (!((cand >> (4 * h)) & 15u)) continue;
+        unsigned pend = 0;
+        double key[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = 4 * h + q;
+            key[q] = 0.;
+            if ((cand >> k) & 1u) {
+                const int tx = 2 * h + (q >> 1), ty = tyb + ((q & 1) << 2);
+                const int binfo = s_binfo[tx][tz >> 3];
+                if (brick_rec && no_vacuum && !(binfo & 2)) {
+                    // no voxel of this brick is a 26-neighbour maximum: each has a strictly denser neighbour
+                    // (weighted > rho(v) implies rho(n) > rho(v)), and without vacuum no neighbour is skipped
+                    edges |= 1u << k;
+                } else {
+                    int x = xa + tx0 + tx;
+                    if (x >= g.nx) x -= g.nx;
+                    if (G && plane_in_window(g, x) && (binfo & 1)) {  // (slabs: a window of planes; sparse table: flagged bricks)
+                        key[q] = G[rec_slot(g, (x * g.ny + y0 + ty) * g.nz + z0 + tz)].key;
+                        pend |= 1u << q;
+                    } else
+                        full |= 1u << k;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if ((pend >> q) & 1u) {
+                // the table knows the best distance-weighted neighbour of v; if there is one (and it is not vacuum) that
+                // neighbour is denser than v: not a maximum.  (weighted > rho(v) implies rho(n) > rho(v); the converse can
+                // fail by rounding, so "no such neighbour" still takes the full test)
+                const int k = 4 * h + q, tx = 2 * h + (q >> 1), ty = tyb + ((q & 1) << 2);
+                const int og = key_og(key[q]);
+                if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) edges |= 1u << k;
+                else full |= 1u << k;
+            }
+    }
+#pragma unroll 1
+    for (unsigned m = full; m; m &= m - 1) {   // rare: the full 27-point density test
+        const int k = __ffs(m) - 1;
+        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
+        int x = xa + tx0 + tx;
+        if (x >= g.nx) x -= g.nx;
+        const int y = y0 + ty, z = z0 + tz;
+        const int v = (x * g.ny + y) * g.nz + z;
+        bool is_max = true;
+        const double c = rho[v];
+        for (int dx = -1; dx < 2; dx++) {
+            const int X = wrapi(x + dx, g.nx);
+            for (int dy = -1; dy < 2; dy++) {
+                const int Y = wrapi(y + dy, g.ny);
+                for (int dz = -1; dz < 2; dz++) {
+                    const int Z = wrapi(z + dz, g.nz);
+                    if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 && rho[(X * g.ny + Y) * g.nz + Z] > c) is_max = false;
+                }
+            }
+        }
+        if (!is_max) edges |= 1u << k;
+    }
+#else
     // pass 2 (a loop, not unrolled: it runs for the edge candidates only and its loads must not cost registers for
     // all 8 voxels at once): refinement.py:374-383, an edge unless it is a 26-neighbour maximum
     unsigned edges = 0;
@@ -339,6 +428,7 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
         }
         if (!is_max) edges |= 1u << k;
     }
+#endif
     // pass 3: the flags, and the owned edge voxels for the list
     int vidx[8];
     int cnt = 0;
@@ -358,7 +448,7 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
     int total;
     const int off = block_scan_excl(cnt, total);
     __shared__ int base_s;
-    if (threadIdx.x == 0) base_s = total ? atomicAdd(list_count, total) : 0;
+    if (tid == 0) base_s = total ? atomicAdd(list_count, total) : 0;
     __syncthreads();
     int w = base_s + off;
 #pragma unroll
@@ -471,21 +561,29 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
                                                           int small, const GradRec *__restrict__ G,
                                                           const unsigned char *__restrict__ brick_rec, int no_vacuum,
                                                           const int *__restrict__ tiles, const int *n_tiles) {
-    // one tile per workgroup, the grid covers every tile: a loop over the list would make the compiler keep the ~60 LDS
-    // row addresses of edge_tile in registers across iterations (177 VGPRs, 2 waves per SIMD instead of 4)
-    if ((int)blockIdx.x >= *n_tiles) return;
+    // Round 4: a fixed grid strides over the listed tiles.  (Round 3 launched one workgroup per tile of the GRID and let the
+    // unlisted ones return: five sixths of 65 536 workgroups at 512^3, each holding a slot of a compute unit for the ~2 us
+    // it takes to start, read the list length and leave -- half of the kernel's 0.27 ms.  A loop used to cost the kernel its
+    // occupancy, the compiler kept edge_tile's ~60 LDS row addresses alive across iterations; the staging by planes has none.)
+    const int n = *n_tiles;
     const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = g.ny / ET_Y;
-    const unsigned entry = (unsigned)tiles[blockIdx.x];
-    const int t = (int)(entry & 0x7fffffffu);
-    const int tx0 = (t / (ntz * nty)) * ET_X, y0 = ((t / ntz) % nty) * ET_Y, z0 = (t % ntz) * ET_Z;
-    if (entry & 0x80000000u) {   // uniform vacuum: flags 0
-        for (int i = threadIdx.x; i < ET_X * ET_Y * ET_Z; i += TPB) {
-            const int z = z0 + (i % ET_Z), y = y0 + (i / ET_Z) % ET_Y, x = tx0 + i / (ET_Z * ET_Y);
-            if (z < g.nz) known[(x * g.ny + y) * g.nz + z] = 0;
+#pragma unroll 1
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        const unsigned entry = (unsigned)tiles[item];
+        const int t = (int)(entry & 0x7fffffffu);
+        const int tx0 = (t / (ntz * nty)) * ET_X, y0 = ((t / ntz) % nty) * ET_Y, z0 = (t % ntz) * ET_Z;
+        if (entry & 0x80000000u) {   // uniform vacuum: flags 0
+            for (int i = threadIdx.x; i < ET_X * ET_Y * ET_Z; i += TPB) {
+                const int z = z0 + (i % ET_Z), y = y0 + (i / ET_Z) % ET_Y, x = tx0 + i / (ET_Z * ET_Y);
+                if (z < g.nz) known[(x * g.ny + y) * g.nz + z] = 0;
+            }
+            continue;
         }
-        return;
+        __syncthreads();   // the previous tile's readers are done with the staged labels
+        int salt = 0;
+        asm volatile("" : "+v"(salt));
+        edge_tile(g, rho, labels, known, 0, g.nx, list, list_count, small, nullptr, G, brick_rec, no_vacuum, tx0, y0, z0, salt);
     }
-    edge_tile(g, rho, labels, known, 0, g.nx, list, list_count, small, nullptr, G, brick_rec, no_vacuum, tx0, y0, z0);
 }
 
 // compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block
@@ -595,6 +693,11 @@ struct WalkerIO {
 };
 #define XB_WALKER_STUCK (-2147483647 - 1)
 
+// Tried in round 4 and dropped: the retraces of one GPU in PHASES -- a first launch gives every retrace a few steps and hands the
+// ones still moving over as walkers (80 B each, segmented buffers, wave-aggregated slot counters), a second launch packs the
+// survivors into full waves, a third finishes the rest.  Lane use rises from 29 of 64 as intended, but the kernel is not bound
+// by its wave-steps: 0.52 ms in one launch against 0.76 (budget 8) ... 1.05 ms (budgets 2 + 4) in phases at 512^3 -- every
+// hand-over is a record the next launch has to gather again, and idle lanes cost a latency-bound kernel nothing.
 // EXPORT (slabs, device-driven step): the lean instantiation hands a retrace that leaves the valid planes over as a walker
 // itself (it holds the whole state) instead of deferring it to the from-rho instantiation, which walked it again from its
 // start only to export it at the same voxel.

@@ -1,10 +1,13 @@
 """Size-independent properties at BASELINE.json's full sizes (no CPU oracle can follow there):
 conservation, maxima consistency, idempotence of refinement, translation invariance of the
 partition, and N-slab == 1-GPU."""
+import hashlib
+
 import numpy as np
 import pytest
 
 import torch  # noqa: F401  (before the library: see conftest)
+from conftest import load_golden
 from pybader_amd import _lib, synth
 from pybader_amd.interface import distance_matrix, gradient_transform
 
@@ -55,6 +58,25 @@ def test_full_size_invariants(size, method):
         assert log[0][1] > 0
         # a second full refinement pass from the refined map must not re-flag unchanged interior
         assert int((after != lab).sum()) >= log[0][1]
+    if size == 512:
+        # the headline size against the REFERENCE itself (round 4): tests/golden/c512_cubic.npz holds what pybader's own
+        # bader_calc / refine return on this very density (make_golden.py, hashes of the int8 maps, logs, maxima, charges)
+        g = load_golden('c512_cubic')
+        assert tuple(int(x) for x in g['shape']) == shape
+
+        def sha(a):
+            return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        if method == 'neargrid':
+            assert np.array_equal(maxima, g['ng_bader_max'])
+            assert sha(lab.astype(np.int8)) == str(g['ng_F_sha256'])
+            assert sha(after.astype(np.int8)) == str(g['ng_changed_2_sha256'])
+            np.testing.assert_allclose(ch * float(g['voxel_volume']), g['ng_bader_charge'], rtol=1e-9)
+            np.testing.assert_allclose(vo * float(g['voxel_volume']), g['ng_bader_volume'], rtol=1e-9)
+        else:
+            assert np.array_equal(maxima, g['og_bader_max'])
+            assert sha(lab.astype(np.int8)) == str(g['og_main_sha256'])
+            assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['og_ngrefine_changed_2_log'])
+            assert sha(after.astype(np.int8)) == str(g['og_ngrefine_changed_2_sha256'])
     ctx.close()
 
 
