@@ -370,8 +370,8 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
 // ---------------------------------------------------------------------------------------------------------------
 static bool fused_ok(const xb_ctx *c) {
     const Grid &g = c->g;
+    // (round 4: any grid of at least 16 voxels per axis -- the brick lattice is ceil(n / 8), k_brick_masks PART)
     return c->opt_fused && c->opt_boxes && c->opt_bricks && g.x0 == 0 && g.x1 == g.nx && !table_windowed(c) &&
-           g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 && 6LL * (c->N / (BRK * BRK * BRK)) <= c->N &&
            g.nx >= 16 && g.ny >= 16 && g.nz >= 16;
 }
 static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
@@ -380,7 +380,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     if (int rc = need_grad(c)) return rc;
     Grid &g = c->g;
     const GridL gl0 = light(g);
-    const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+    const int nb0 = (g.nx + BRK - 1) / BRK, nb1 = (g.ny + BRK - 1) / BRK, nb2 = (g.nz + BRK - 1) / BRK, nbr = nb0 * nb1 * nb2;
+    const bool part = g.nx % BRK || g.ny % BRK || g.nz % BRK;   // the grid cuts its last bricks
     if (int rc = ensure_brick_bytes(c, nbr)) return rc;
     int *fs = c->fs;
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
@@ -395,6 +396,17 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     int *bres = nullptr;   // per walk-list brick: the one maximum all its voxels ended on (k_ng_trace_g), for the edge sweep's uniformity
     c->box_max_tab = box_max;
     const int stride = XB_BOX_K + 4;
+    // (debug switch 32: wait after every stage and say so -- finds the kernel that does not come back)
+    auto stage_done = [&](const char *what) {
+        if (c->opt_dbg & 32) {
+            const hipError_t e = (hipStreamSynchronize)(c->stream);
+            int h16[16] = {0};
+            (void)hipMemcpy(h16, fs, sizeof h16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[assign] %s: %s  seeds %d regions %d certain %d walk %d maxima %d ovf %d err %d\n", what, hipGetErrorString(e), h16[FS_N_SEEDS],
+                    h16[FS_N_BOXES], h16[FS_N_CERTAIN], h16[FS_N_WALK], h16[FS_N_MAX], h16[FS_N_OVF], h16[FS_ERR]);
+            fflush(stderr);
+        }
+    };
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
     if (!sparse) HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));   // (the seed cubes' shell scans only)
     if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
@@ -423,6 +435,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                 if (sym && c->opt_mirror) mirror_prefilter(g, mirror, mu_scale);
                 // (an orthogonal lattice has a diagonal T_grad: exact zeros off the diagonal)
                 const bool diag = c->opt_mask_diag && g.T[1] == 0. && g.T[2] == 0. && g.T[3] == 0. && g.T[5] == 0. && g.T[6] == 0. && g.T[7] == 0.;
+                if (part) {
+                    if (sym && diag) k_brick_masks<GridS, 1, true, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                    else if (sym) k_brick_masks<GridS, 1, false, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
+                    else k_brick_masks<Grid, 1, false, true><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
+                } else
                 if (sym && diag) k_brick_masks<GridS, 1, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
                 else if (sym) k_brick_masks<GridS, 1, false><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
                 else k_brick_masks<Grid, 1, false><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
@@ -433,6 +450,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                 k_grad_field<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
                                                                bmask, fs + FS_TIES);
         }
+        stage_done("brick masks");
         c->grad_valid = true;
         c->grad_rule = 1;
         c->grad_cover = sparse ? 1 : 0;
@@ -467,6 +485,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr,
                                                  sparse ? 0 : 1);
         HIPCHK(hipGetLastError());
+        stage_done("region growth");
     }
     c->blab = c->blab_buf;
     c->walk = walk;
@@ -491,6 +510,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             else
                 k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, walk, fs + FS_N_WALK, nbr, nb1, nb2, c->brick_rec, small);
         }
+        stage_done("walk list + records");
         if (c->has_vacuum)
             k_fill_certain<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->blab, nb1, nb2, box_max, c->labels, c->first, c->max_list,
                                                                 fs + FS_N_MAX, c->max_cap, fs + FS_GROW_RETRY);
@@ -507,15 +527,20 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             const int gw = c->opt_trace_group;   // waves per workgroup (1: one-wave workgroups, every wave pulls for itself)
 #define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
                       maxsteps, c->has_vacuum ? 1 : 0
-            if (gw > 1) {
-                const int groups = std::max(1, c->opt_trace_grid / gw), ch = std::max(8, c->opt_trace_chunk);
-                if (lean && gw == 8 && ch == 8 && c->opt_trace_cache) {   // one brick per pull: its records go through LDS
+            if (gw > 1 || part) {
+                const int groups = std::max(1, c->opt_trace_grid / (part ? 8 : gw)), ch = part ? 8 : std::max(8, c->opt_trace_chunk);
+                if (lean && (part || (gw == 8 && ch == 8 && c->opt_trace_cache))) {   // one brick per pull: its records go through LDS
                     // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
                     if (!c->has_vacuum) bres = c->list + 6 * nbr;
+                    if (part) {
+                        if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
+                        else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
+                    } else
                     if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
                     else k_ng_trace_g<2, 3><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
                 } else
-                if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
+                if (part) k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);   // (the generic walker tests every start voxel)
+                else if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
                 else if (lean == 1) k_ng_trace_g<2, 1><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
                 else k_ng_trace_g<2, 0><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
             } else if (lean == 2)
@@ -527,6 +552,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
 #undef XB_TRACE_ARGS
         }
         HIPCHK(hipGetLastError());
+        stage_done("trace");
     }
     // numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host)
     k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
@@ -544,6 +570,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
     k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
+    stage_done("numbering + relabel");
     // the ONE host wait of the assignment: state block + the sorted maxima
     HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->host_ints + FS_COUNT, c->max_aux, XB_SORT_MAX * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -26,9 +26,12 @@ static int edge_find_launch(xb_ctx *c, bool *dilate_owned) {
         const GridL gl = light(g);
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         int *buni = nullptr;
-        if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {  // whole bricks: per-brick label uniformity first
-            buni = reinterpret_cast<int *>(c->st);             // N bytes >= N/512 ints; edge_check reuses st later
-            const int nbr = (int)(c->N / 512), per_plane = (g.ny / 8) * (g.nz / 8);
+        // per-brick label uniformity first: grids of whole bricks (slabs), any grid of at least 16 voxels per axis on one slab
+        // (the brick lattice is ceil(n / 8); a brick the grid cuts counts its voxels inside the grid)
+        if ((g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) || (whole && g.nx >= 16 && g.ny >= 16 && g.nz >= 16)) {
+            buni = reinterpret_cast<int *>(c->st);             // N bytes >= 2 nbr ints; edge_check reuses st later
+            const int nb0 = (g.nx + 7) / 8, nb1 = (g.ny + 7) / 8, nb2 = (g.nz + 7) / 8;
+            const int nbr = nb0 * nb1 * nb2, per_plane = nb1 * nb2;
             if (!c->buni_valid) {
                 // a slab only scans the bricks its sweep can look at (the swept planes +- one brick)
                 int b_off = 0, count = nbr;
@@ -37,10 +40,10 @@ static int edge_find_launch(xb_ctx *c, bool *dilate_owned) {
                     b_off = (p0 / 8) * per_plane;
                     count = ((np + 8 + 7 + (p0 % 8)) / 8 + 1) * per_plane;
                 }
-                k_label_uniform<<<(unsigned)count, TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni, b_off, nbr);
+                k_label_uniform<<<(unsigned)count, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, buni, b_off, nbr);
                 c->buni_halo_safe = false;
             }
-            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
+            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
             buni += nbr;   // the sweep reads the 27-brick version
         }
         const GradRec *G = c->grad_valid ? c->grad : nullptr;
@@ -610,22 +613,22 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         int *buni = nullptr;
         int ntiles_listed = 0;
-        if (g.nx % 8 == 0 && g.ny % 8 == 0 && g.nz % 8 == 0) {
+        if (g.nx >= 16 && g.ny >= 16 && g.nz >= 16) {   // (any such grid: the brick lattice is ceil(n / 8))
+            const int nb0 = (g.nx + 7) / 8, nb1 = (g.ny + 7) / 8, nb2 = (g.nz + 7) / 8, nbr = nb0 * nb1 * nb2;
             buni = reinterpret_cast<int *>(c->st);
             if (!c->buni_valid)
-                k_label_uniform<<<(unsigned)(c->N / 512), TPB, 0, c->stream>>>(gl, c->labels, g.ny / 8, g.nz / 8, buni, 0, (int)(c->N / 512));
-            const int nbr = (int)(c->N / 512);
-            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(g.nx / 8, g.ny / 8, g.nz / 8, buni, buni + nbr);
+                k_label_uniform<<<(unsigned)nbr, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, buni, 0, nbr);
+            k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
             buni += nbr;
         }
         const unsigned char *brec = c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr;
         if (buni) {
             // flags preset to "known", then only the tiles that are not of one non-vacuum label with their surroundings
-            const int ntiles = ((g.nz + ET_Z - 1) / ET_Z) * (g.ny / ET_Y) * (g.nx / ET_X);
+            const int ntiles = ((g.nz + ET_Z - 1) / ET_Z) * ((g.ny + ET_Y - 1) / ET_Y) * ((g.nx + ET_X - 1) / ET_X);
             ntiles_listed = ntiles;
             int *tiles = (int *)c->stage;
             HIPCHK(hipMemsetAsync(c->known, 2, (size_t)c->N, c->stream));
-            k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES, 0, g.nx / ET_X);
+            k_edge_tile_list<<<(ntiles + TPB - 1) / TPB, TPB, 0, c->stream>>>(gl, buni, tiles, fs + FS_N_TILES, 0, (g.nx + ET_X - 1) / ET_X);
             k_edge_flag_listed<<<std::min(ntiles, 2048), TPB, 0, c->stream>>>(gl, c->rho, c->labels, c->known, c->list, fs + FS_N_EDGES, small,
                                                            c->grad_valid ? c->grad : nullptr, brec, c->has_vacuum ? 0 : 1, tiles, fs + FS_N_TILES);
         } else {

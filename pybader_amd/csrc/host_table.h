@@ -44,24 +44,23 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
     const Grid &g = c->g;
     if (c->grad_valid && !force && !boxes && c->grad_cover == 1 && c->brick_rec) {
         // records exist for the flagged bricks only, under the other tie rule: redo exactly those
-        const int nbr = (g.nx / BRK) * (g.ny / BRK) * (g.nz / BRK);
+        const int nb1r = (g.ny + BRK - 1) / BRK, nb2r = (g.nz + BRK - 1) / BRK, nbr = ((g.nx + BRK - 1) / BRK) * nb1r * nb2r;
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         ScopedTimer t(c, 4);
         GridS gs;
         if (sym_grid(g, gs))
-            k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, nullptr, nullptr, nbr, g.ny / BRK, g.nz / BRK, c->brick_rec, small);
+            k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, nullptr, nullptr, nbr, nb1r, nb2r, c->brick_rec, small);
         else
-            k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, nullptr, nullptr, nbr, g.ny / BRK, g.nz / BRK, c->brick_rec, small);
+            k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, nullptr, nullptr, nbr, nb1r, nb2r, c->brick_rec, small);
         HIPCHK(hipGetLastError());
         c->grad_rule = main_rule ? 1 : 0;
         return XB_OK;
     }
-    if (!force && !boxes && c->opt_sparse && !table_windowed(c) && g.x0 == 0 && g.x1 == g.nx && g.nx % BRK == 0 && g.ny % BRK == 0 &&
-        g.nz % BRK == 0 && g.nx >= 16 && g.ny >= 16 && g.nz >= 16) {
+    if (!force && !boxes && c->opt_sparse && !table_windowed(c) && g.x0 == 0 && g.x1 == g.nx && g.nx >= 16 && g.ny >= 16 && g.nz >= 16) {
         // a refinement without a table from an assignment (ongrid, uploaded labels): retraces only run near label
         // boundaries, so only the bricks whose 27-brick surroundings are not of one label get records (k_masks.h);
         // a retrace that walks on through a brick without records is redone by the from-rho kernel
-        const int nb0 = g.nx / BRK, nb1 = g.ny / BRK, nb2 = g.nz / BRK, nbr = nb0 * nb1 * nb2;
+        const int nb0 = (g.nx + BRK - 1) / BRK, nb1 = (g.ny + BRK - 1) / BRK, nb2 = (g.nz + BRK - 1) / BRK, nbr = nb0 * nb1 * nb2;
         if (int rc = ensure_brick_bytes(c, nbr)) return rc;
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         ScopedTimer t(c, 4);

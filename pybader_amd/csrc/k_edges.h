@@ -58,8 +58,11 @@ __global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__res
     const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
     int lo = 2147483647, hi = XB_MIXED;
     for (int t = threadIdx.x; t < 512; t += TPB) {
-        const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
-        lo = min(lo, l); hi = max(hi, l);
+        const int x = b0 * 8 + t / 64, y = b1 * 8 + (t / 8) % 8, z = b2 * 8 + t % 8;
+        if (x < g.nx && y < g.ny && z < g.nz) {   // (a brick the grid cuts: its voxels inside the grid)
+            const int l = labels[(x * g.ny + y) * g.nz + z];
+            lo = min(lo, l); hi = max(hi, l);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
     if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
@@ -116,8 +119,11 @@ __global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int t = lane + k * XB_WAVE;
-            const int l = labels[((b0 * 8 + t / 64) * g.ny + b1 * 8 + (t / 8) % 8) * g.nz + b2 * 8 + t % 8];
-            lo = min(lo, l); hi = max(hi, l);
+            const int x = b0 * 8 + t / 64, y = b1 * 8 + (t / 8) % 8, z = b2 * 8 + t % 8;
+            if (x < g.nx && y < g.ny && z < g.nz) {
+                const int l = labels[(x * g.ny + y) * g.nz + z];
+                lo = min(lo, l); hi = max(hi, l);
+            }
         }
         for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
         if (lane == 0) buni[b] = (lo == hi) ? lo : XB_MIXED;
@@ -176,7 +182,7 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
         __shared__ int s_lab, s_mixed;
         if (tid == 0) { s_lab = XB_MIXED; s_mixed = 0; }
         __syncthreads();
-        const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        const int nb1 = (g.ny + 7) >> 3, nb2 = (g.nz + 7) >> 3;
         int X0 = xa + tx0, X1 = xa + min(tx0 + ET_X, nplanes) - 1;
         if (X0 >= g.nx) X0 -= g.nx;
         if (X1 >= g.nx) X1 -= g.nx;
@@ -397,7 +403,7 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
         const int y = y0 + ty, z = z0 + tz;
         const int v = (x * g.ny + y) * g.nz + z;
         bool is_max = true, decided = false;
-        const int binfo = brick_rec ? brick_rec[((x >> 3) * (g.ny >> 3) + (y >> 3)) * (g.nz >> 3) + (z >> 3)] : 1;
+        const int binfo = brick_rec ? brick_rec[((x >> 3) * ((g.ny + 7) >> 3) + (y >> 3)) * ((g.nz + 7) >> 3) + (z >> 3)] : 1;
         if (brick_rec && no_vacuum && !(binfo & 2)) {
             // no voxel of this brick is a 26-neighbour maximum: each has a strictly denser neighbour
             // (weighted > rho(v) implies rho(n) > rho(v)), and without vacuum no neighbour is skipped
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_tiles(GridL g, int8_t *know
     constexpr int ROW = ET_Z + 8;   // a row of flags in LDS: the tile's 64 bytes at offset 4, the halo bytes at 3 and 68
     __shared__ __attribute__((aligned(16))) int8_t s[(ET_X + 2) * (ET_Y + 2) * ROW];
     static_assert(ET_X * ET_Y * (ET_Z / 8) == TPB && (ET_X + 2) * (ET_Y + 2) * 4 <= TPB, "one 8-voxel chunk per thread");
-    const int ntz = g.nz / ET_Z, nty = g.ny / ET_Y, n = *n_tiles;
+    const int ntz = g.nz / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y, n = *n_tiles;
   for (int item = blockIdx.x; item < n; item += gridDim.x) {   // (uniform per block)
     const int t = (int)((unsigned)tiles[item] & 0x7fffffffu);
     const int tx0 = (t / (ntz * nty)) * ET_X, y0 = ((t / ntz) % nty) * ET_Y, z0 = (t % ntz) * ET_Z;
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_tiles(GridL g, int8_t *know
     // the chunk: bytes 4..7 of word 0, 0..3 of word 1; a byte with a clear sign bit (known >= 0) and `near` becomes 0xFF
     unsigned long long old = (c0 >> 32) | (c1 << 32), near = (n0 >> 32) | (n1 << 32);
     const unsigned long long hit = near & ~old & 0x8080808080808080ull;
-    if (hit) {
+    if (hit && tx0 + ex < g.nx && y0 + ey < g.ny) {   // (a tile the grid cuts in x or y: its rows inside the grid)
         const unsigned long long fill = (hit >> 7) * 0xFFull;
         *reinterpret_cast<unsigned long long *>(known + ((size_t)(tx0 + ex) * g.ny + y0 + ey) * g.nz + z0 + 8 * ch) = old | fill;
     }
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
 // its halo planes separately)
 __global__ __launch_bounds__(TPB) void k_edge_tile_list(GridL g, const int *__restrict__ buni3, int *tiles, int *n_tiles, int tx_lo,
                                                         int tx_n) {
-    const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = g.ny / ET_Y, ntx = g.nx / ET_X;
+    const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y, ntx = (g.nx + ET_X - 1) / ET_X;
     const int i = blockIdx.x * TPB + threadIdx.x;
     bool hit = false;
     unsigned entry = 0;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(TPB) void k_edge_tile_list(GridL g, const int *__re
         if (tx >= ntx) tx -= ntx;
         const int tz = i % ntz, ty = (i / ntz) % nty;
         const int t = (tx * nty + ty) * ntz + tz;
-        const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        const int nb1 = (g.ny + 7) >> 3, nb2 = (g.nz + 7) >> 3;
         const int bxa = (tx * ET_X) >> 3, bxb = (tx * ET_X + ET_X - 1) >> 3, nbz = min(ET_Z / 8, nb2 - ((tz * ET_Z) >> 3));
         int lab = XB_MIXED;
         bool mixed = false;
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
     // it takes to start, read the list length and leave -- half of the kernel's 0.27 ms.  A loop used to cost the kernel its
     // occupancy, the compiler kept edge_tile's ~60 LDS row addresses alive across iterations; the staging by planes has none.)
     const int n = *n_tiles;
-    const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = g.ny / ET_Y;
+    const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y;
 #pragma unroll 1
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
         const unsigned entry = (unsigned)tiles[item];
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
         if (entry & 0x80000000u) {   // uniform vacuum: flags 0
             for (int i = threadIdx.x; i < ET_X * ET_Y * ET_Z; i += TPB) {
                 const int z = z0 + (i % ET_Z), y = y0 + (i / ET_Z) % ET_Y, x = tx0 + i / (ET_Z * ET_Y);
-                if (z < g.nz) known[(x * g.ny + y) * g.nz + z] = 0;
+                if (z < g.nz && y < g.ny && x < g.nx) known[(x * g.ny + y) * g.nz + z] = 0;
             }
             continue;
         }
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         rec = fetch_rec_w(g, G, v);
         vol_num = labels[v];
         moving = true;
-        if (region_blab && region_blab[((px >> 3) * (g.ny >> 3) + (py >> 3)) * (g.nz >> 3) + (pz >> 3)] > 0) {
+        if (region_blab && region_blab[((px >> 3) * ((g.ny + 7) >> 3) + (py >> 3)) * ((g.nz + 7) >> 3) + (pz >> 3)] > 0) {
             result = v; moving = false;   // slabs: an edge voxel inside a trapping region keeps its label (see below)
         } else
         if (!(plane_in_window(g, px) && rec_exists(brick_rec, g, px, py, pz))) {   // an edge voxel without a record
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
                 // slabs (region_blab: the brick labels of the trapping regions, the same on every rank): a retrace that
                 // enters a region ends in it with the region's label -- it no longer glides along a dividing surface for
                 // tens of planes, so a narrow label halo is enough and the remote path queries become rare
-                const bool in_region = region_blab && ok_plane && region_blab[((qx >> 3) * (g.ny >> 3) + (qy >> 3)) * (g.nz >> 3) + (qz >> 3)] > 0;
+                const bool in_region = region_blab && ok_plane && region_blab[((qx >> 3) * ((g.ny + 7) >> 3) + (qy >> 3)) * ((g.nz + 7) >> 3) + (qz >> 3)] > 0;
                 if (in_region || (!RHO && regions_ok && in_win && missing && ok_plane)) {
                     // q lies in a trapping region (closed, one label): the retrace ends in it whatever happens next --
                     // no record, no density, no membership test needed (q cannot be an old path voxel: the path would

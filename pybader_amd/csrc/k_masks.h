@@ -171,9 +171,11 @@ __device__ __forceinline__ void bm_mirror(const double (&a)[3][3][3], bool want_
 //     the column: +EPS on the face (offset -1 reachable when d < tiny), -(1 - EPS) one voxel in (offset -2 when d <
 //     -nearm), -inf elsewhere (no move reaches the face); mirrored for the high face.
 struct BmCoef { double yl, yh, zl, zh; };
-template <int MT, int K, bool DIAG, typename GT>
+// PART (round 4: grids that are not made of whole bricks): the high face of a brick lies where the grid ends, at position
+// w - 1 of its w valid voxels -- the x thresholds come as a scalar (cxh) like those of y and z come per lane (co).
+template <int MT, int K, bool DIAG, bool PART, typename GT>
 __device__ __forceinline__ void bm_cross(const GT &g, double c, double ex, double ey, double ez, double mx, double my, double mz,
-                                         const BmCoef &co, bool &xl, bool &xh, bool &yl, bool &yh, bool &zl, bool &zh) {
+                                         const BmCoef &co, double cxh, bool &xl, bool &xh, bool &yl, bool &yh, bool &zl, bool &zh) {
     const bool f0 = MT ? (mx <= c) : (mx < c), f1 = MT ? (my <= c) : (my < c), f2 = MT ? (mz <= c) : (mz < c);
     const double g0 = f0 ? 0. : ex, g1 = f1 ? 0. : ey, g2 = f2 ? 0. : ez;
     double d0, d1, d2;
@@ -188,8 +190,11 @@ __device__ __forceinline__ void bm_cross(const GT &g, double c, double ex, doubl
     const bool moves = !(mg < 2E-14);   // max_grad < 1E-14 (d is doubled here): the ongrid step only
     if (K == 0) xl |= moves && d0 < mg * BM_EPS;
     if (K == 1) xl |= moves && d0 < mg * -(1. - BM_EPS);
-    if (K == GT_X - 1) xh |= moves && d0 > mg * -BM_EPS;
-    if (K == GT_X - 2) xh |= moves && d0 > mg * (1. - BM_EPS);
+    if (PART) xh |= moves && d0 > mg * cxh;
+    else {
+        if (K == GT_X - 1) xh |= moves && d0 > mg * -BM_EPS;
+        if (K == GT_X - 2) xh |= moves && d0 > mg * (1. - BM_EPS);
+    }
     yl |= moves && d1 < mg * co.yl;
     yh |= moves && d1 > mg * co.yh;
     zl |= moves && d2 < mg * co.zl;
@@ -197,10 +202,13 @@ __device__ __forceinline__ void bm_cross(const GT &g, double c, double ex, doubl
 }
 
 // one x-position K of the column: everything below the window update
-template <int MT, int K, bool DIAG, typename GT>
+template <int MT, int K, bool DIAG, bool PART, typename GT>
 __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3], double dface, bool in, int v, int ty, int zz,
                                          int &mine, bool &any_tie, int *s_cnt, int *s_mv, double mu, int mirror, const BmCoef &co,
-                                         bool deep) {
+                                         bool deep, int wx, bool at_yh, bool at_zh) {
+    // this voxel on the high x / y / z face of its brick (PART: of what the grid leaves of the brick)
+    const bool at_xh = PART ? (K == wx - 1) : (K == GT_X - 1);
+    const double cxh = at_xh ? -BM_EPS : (K == wx - 2 ? (1. - BM_EPS) : __builtin_huge_val());
     const double c = a[1][1][1];
     const double hx = a[2][1][1], lx = a[0][1][1], hy = a[1][2][1], ly = a[1][0][1], hz = a[1][1][2], lz = a[1][1][0];
     const double mx = max_raw(hx, lx), my = max_raw(hy, ly), mz = max_raw(hz, lz);
@@ -214,10 +222,10 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
     // (a deep column at x-positions 2..5 has no face within reach of any move: `deep` is wave uniform)
     if (!(deep && K >= 2 && K <= GT_X - 3)) {
         const double ex = hx - lx, ey = hy - ly, ez = hz - lz;
-        bm_cross<MT, K, DIAG>(g, c, ex, ey, ez, mx, my, mz, co, xl, xh, yl, yh, zl, zh);
+        bm_cross<MT, K, DIAG, PART>(g, c, ex, ey, ez, mx, my, mz, co, cxh, xl, xh, yl, yh, zl, zh);
         // a voxel with a tie axis gets the union of both rules, so that a trapping region is closed for the assignment's
         // walkers AND for the refinement's retraces (k_refine_trace stops a retrace that enters a region)
-        if (__any(tie)) bm_cross<!MT, K, DIAG>(g, c, ex, ey, ez, mx, my, mz, co, xl, xh, yl, yh, zl, zh);
+        if (__any(tie)) bm_cross<!MT, K, DIAG, PART>(g, c, ex, ey, ez, mx, my, mz, co, cxh, xl, xh, yl, yh, zl, zh);
     }
     // Does this voxel need its exact ongrid successor?  (a) it lies on a face of its brick that its gradient
     // interval does not cross already (an ongrid move is one voxel long: only face voxels can leave the brick
@@ -228,10 +236,10 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
     wq += c;
     const bool not_max = wq > c;
     // the faces whose crossing is still open, minus those the mirror prefilter closes (wave-uniform branches)
-    bool nxl = in && K == 0 && !xl, nxh = in && K == GT_X - 1 && !xh;
-    bool nyl = in && ty == 0 && !yl, nyh = in && ty == 7 && !yh, nzl = in && zz == 0 && !zl, nzh = in && zz == 7 && !zh;
-    if ((K == 0 || K == GT_X - 1) && (mirror & 1)) {
-        const bool wl = K == 0 && __any(nxl), wh = K == GT_X - 1 && __any(nxh);
+    bool nxl = in && K == 0 && !xl, nxh = in && at_xh && !xh;
+    bool nyl = in && ty == 0 && !yl, nyh = in && at_yh && !yh, nzl = in && zz == 0 && !zl, nzh = in && at_zh && !zh;
+    if ((PART || K == 0 || K == GT_X - 1) && (mirror & 1)) {
+        const bool wl = K == 0 && __any(nxl), wh = at_xh && __any(nxh);
         if (wl || wh) bm_mirror<0>(a, wl, wh, mu, nxl, nxh);
     }
     if (mirror & 2) {
@@ -287,11 +295,11 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
         is_max = !(wm > c);
         const bool some = wm > c;
         if (K == 0) xl |= some && (ax0 + c) == wm;
-        if (K == GT_X - 1) xh |= some && (ax2 + c) == wm;
+        if (PART ? at_xh : K == GT_X - 1) xh |= some && (ax2 + c) == wm;
         {
             const double ay0 = fmax(fmax(line[0][0], line[1][0]), line[2][0]), ay2 = fmax(fmax(line[0][2], line[1][2]), line[2][2]);
             yl |= ty == 0 && some && (ay0 + c) == wm;
-            yh |= ty == 7 && some && (ay2 + c) == wm;
+            yh |= at_yh && some && (ay2 + c) == wm;
             double az0 = pz[0][0][0], az2 = pz[0][0][2];
 #pragma unroll
             for (int ix = 0; ix < 3; ix++)
@@ -301,7 +309,7 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
                     az2 = fmax(az2, pz[ix][iy][2]);
                 }
             zl |= zz == 0 && some && (az0 + c) == wm;
-            zh |= zz == 7 && some && (az2 + c) == wm;
+            zh |= at_zh && some && (az2 + c) == wm;
         }
     }
     if (in) {
@@ -318,7 +326,7 @@ __device__ __forceinline__ void bm_voxel(const GT &g, const double (&a)[3][3][3]
 }
 
 // (SMALL: a grid so small that the tile's halo wraps more than once -- true modulo instead of the two unsigned minima)
-template <bool SMALL, typename GT>
+template <bool SMALL, bool PART, typename GT>
 __device__ __forceinline__ void bm_stage(const GT &g, const double *__restrict__ rho, double (&tile)[GT_X + 2][GT_Y + 2][BM_ROW], unsigned *s_bmax,
                                          int x0, int y0, int z0, int mirror) {
     {   // Staging of the haloed 10 x 10 x 34 tile, every load of a wave in flight before the first wait.
@@ -339,7 +347,7 @@ __device__ __forceinline__ void bm_stage(const GT &g, const double *__restrict__
         for (int ey = 0; ey < GT_Y + 2; ey++) {
             int Y = y0 + ey - 1;
             if (SMALL) Y = ((Y % g.ny) + g.ny) % g.ny;
-            else if (ey == 0 || ey == GT_Y + 1) Y = wrap_u(Y, g.ny);
+            else if (PART || ey == 0 || ey == GT_Y + 1) Y = wrap_u(Y, g.ny);   // (PART: a tile may reach beyond the grid, its rows wrap)
             Yw[ey] = (unsigned)(Y * g.nz) * 8u;   // (interior rows of the tile never wrap: whole-brick grids; a partial tile's rows beyond the grid are not read)
         }
         constexpr int PL = (GT_X + 2 + 3) / 4;   // x-planes per wave (the last one only for the waves that have it)
@@ -380,7 +388,12 @@ __device__ __forceinline__ void bm_stage(const GT &g, const double *__restrict__
         }
     }
 }
-template <typename GT, int MT, bool DIAG>
+// PART: the grid is not made of whole 8^3 bricks.  The brick lattice is ceil(n / 8) per axis; the last brick of an axis holds
+// the w = n mod 8 voxels the grid leaves of it, its high face lies at position w - 1, moves from it wrap to brick 0 and moves
+// from brick 0 downwards arrive in it -- the same 27-neighbour masks.  Only a brick of width ONE is special: a move of two
+// voxels from brick 0 would jump over it, so it is marked as never certifiable (bits 27 + 28), and every brick with a move
+// into it dies with it in the kill iteration: sound, and a width of one is rare.
+template <typename GT, int MT, bool DIAG, bool PART = false>
 __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restrict__ rho, int small, int *__restrict__ bmask,
                                                      int *__restrict__ bmaxv, int *tie_count, int xbase, double mu_scale, int mirror,
                                                      int *__restrict__ bpot) {
@@ -428,8 +441,8 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
         }
     }
 #else
-    if (small & 1) bm_stage<true>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
-    else bm_stage<false>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
+    if (small & 1) bm_stage<true, PART>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
+    else bm_stage<false, PART>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
 #endif
     __syncthreads();
     // mu: see bm_mirror; the double whose high word is s_bmax + 1 bounds every |rho| of the tile from above
@@ -437,13 +450,17 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     int ty, tz;
     bm_column(threadIdx.x, ty, tz);
     const int zz = tz & 7;
-    const bool deep = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE) == 3;   // wave 3 holds the deep columns (bm_column)
+    // the valid voxels of this lane's brick along each axis
+    const int wx = PART ? min(GT_X, g.nx - x0) : GT_X, wy = PART ? min(8, g.ny - y0) : 8, wz = PART ? min(8, g.nz - (z0 + (tz & ~7))) : 8;
+    const bool at_yh = ty == wy - 1, at_zh = zz == wz - 1;
+    // wave 3 holds the deep columns (bm_column); in a tile the grid cuts they are not deep
+    const bool deep = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE) == 3 && (!PART || (wx == GT_X && wy == 8 && z0 + GT_Z <= g.nz));
     const double kInf = __builtin_huge_val();
     BmCoef co;   // per-lane threshold coefficients of the y / z faces (bm_cross)
     co.yl = ty == 0 ? BM_EPS : (ty == 1 ? -(1. - BM_EPS) : -kInf);
-    co.yh = ty == 7 ? -BM_EPS : (ty == 6 ? (1. - BM_EPS) : kInf);
+    co.yh = at_yh ? -BM_EPS : (ty == wy - 2 ? (1. - BM_EPS) : kInf);
     co.zl = zz == 0 ? BM_EPS : (zz == 1 ? -(1. - BM_EPS) : -kInf);
-    co.zh = zz == 7 ? -BM_EPS : (zz == 6 ? (1. - BM_EPS) : kInf);
+    co.zh = at_zh ? -BM_EPS : (zz == wz - 2 ? (1. - BM_EPS) : kInf);
     const int y = y0 + ty, z = z0 + tz;
     const bool col_in = y < g.ny && z < g.nz;
     // the smallest of the six face distances: a lower bound of any face neighbour's weighted value (maximum test)
@@ -470,8 +487,8 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
         }                                                                                                            \
         const int x = x0 + K;                                                                                        \
         cmax = max_raw(cmax, a[1][1][1]);                                                                            \
-        bm_voxel<MT, K, DIAG>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie,     \
-                              &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror, co, deep);                                \
+        bm_voxel<MT, K, DIAG, PART>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie, \
+                                    &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror, co, deep, wx, at_yh, at_zh);          \
     }
     BM_STEP(0) BM_STEP(1) BM_STEP(2) BM_STEP(3) BM_STEP(4) BM_STEP(5) BM_STEP(6) BM_STEP(7)
 #undef BM_STEP
@@ -484,12 +501,14 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     }
     __syncthreads();
     if (threadIdx.x < GT_Z / 8 && z0 + threadIdx.x * 8 < g.nz) {
-        const int nb1 = g.ny >> 3, nb2 = g.nz >> 3;
+        const int nb1 = (g.ny + 7) >> 3, nb2 = (g.nz + 7) >> 3;
         if (bpot) bpot[((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x] = s_pot[threadIdx.x];
         // bits 0-26: the neighbour bricks a move can reach; bit 27: the brick holds a 26-neighbour maximum, bit 28: two or more
         const int b = ((x0 >> 3) * nb1 + (y0 >> 3)) * nb2 + (z0 >> 3) + threadIdx.x, n = s_cnt[threadIdx.x];
-        bmask[b] = (s_mask[threadIdx.x] & 0x7ffdfff) | (n >= 1 ? 1 << 27 : 0) | (n >= 2 ? 1 << 28 : 0);
-        bmaxv[b] = n == 1 ? s_mv[threadIdx.x] : -1;
+        // (PART: a brick one voxel wide is never certified -- bits 27 + 28 --, see above)
+        const bool dead = PART && (g.nx - x0 == 1 || g.ny - y0 == 1 || g.nz - (z0 + 8 * (int)threadIdx.x) == 1);
+        bmask[b] = (s_mask[threadIdx.x] & 0x7ffdfff) | ((n >= 1 || dead) ? 1 << 27 : 0) | ((n >= 2 || dead) ? 1 << 28 : 0);
+        bmaxv[b] = (n == 1 && !dead) ? s_mv[threadIdx.x] : -1;
     }
 }
 
@@ -591,7 +610,8 @@ __global__ __launch_bounds__(TPB, 4) void k_brick_records(GT g, const double *__
                 code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
             }
             o.key = pack_key(c, code, og);
-            G[rec_slot(g, vbase + (tx * g.ny + ty) * g.nz + tz)] = o;
+            // (a brick the grid cuts: only its voxels inside the grid have a record)
+            if (inner || (x0 + tx < g.nx && y0 + ty < g.ny && z0 + tz < g.nz)) G[rec_slot(g, vbase + (tx * g.ny + ty) * g.nz + tz)] = o;
         }
         if (threadIdx.x == 0) brick_rec[b] |= 1;
     }
@@ -608,5 +628,5 @@ __global__ void k_flag_mixed_bricks(int nbr, const int *__restrict__ buni3, unsi
 // brick_rec[b]: bit 0 = the records of brick b exist, bit 1 = the brick holds a 26-neighbour maximum (k_grow_finish).
 // Does the record of voxel (x,y,z) exist?  (nullptr: the table covers the whole grid / window)
 __device__ __forceinline__ bool rec_exists(const unsigned char *__restrict__ brick_rec, const GridL &g, int x, int y, int z) {
-    return !brick_rec || (brick_rec[((x >> 3) * (g.ny >> 3) + (y >> 3)) * (g.nz >> 3) + (z >> 3)] & 1) != 0;
+    return !brick_rec || (brick_rec[((x >> 3) * ((g.ny + 7) >> 3) + (y >> 3)) * ((g.nz + 7) >> 3) + (z >> 3)] & 1) != 0;
 }

@@ -126,15 +126,17 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *lab
     const int b = blab[((x >> 3) * nb1 + by) * nb2 + (z >> 3)];
     int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + by * 8) * g.nz + z));
     const int stride = g.nz >> 2;   // int4 per row
+    const int rows = min(8, g.ny - by * 8);   // (a brick the grid cuts in y: its rows inside the grid)
     if (b > 0) {
         const int l = b <= XB_BOXES_MAX ? s_rank[b - 1] : rank[box_max[b - 1]];
         const int4 v = make_int4(l, l, l, l);
 #pragma unroll
-        for (int r = 0; r < 8; r++) p[r * stride] = v;
+        for (int r = 0; r < 8; r++)
+            if (r < rows) p[r * stride] = v;
     } else {
         int4 m[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) m[r] = p[r * stride];
+        for (int r = 0; r < 8; r++) m[r] = r < rows ? p[r * stride] : make_int4(-1, -1, -1, -1);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             if (m[r].x >= 0) m[r].x = rank[m[r].x];
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *lab
             if (m[r].w >= 0) m[r].w = rank[m[r].w];
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) p[r * stride] = m[r];
+        for (int r = 0; r < 8; r++)
+            if (r < rows) p[r * stride] = m[r];
     }
 }
 // 16 bricks per thread, one atomic per block; the list keeps brick order inside a block's range
@@ -328,17 +331,21 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // WINDOW (slabs): the table covers the planes of a window only (rec_slot); a walker that steps out of it without landing in a
 // trapping region ends with -2 like an undecidable one -- its start voxel goes to `ovf_list`, here the list of the
 // trajectories the caller redoes with records derived from rho (k_ng_trace_list)
+// (the cache is a file-scope LDS array, not a pointer argument: handed over as a generic pointer it made the gfx950 backend of
+// this ROCm emit `v_cmp_ne_u32 0, src_shared_base` -- "illegal instruction, operand has incorrect register class" -- for
+// some shapes of the surrounding code)
+__shared__ GradRec xb_s_rec[512];
 template <bool OFF32, bool CACHE, bool WINDOW = false>
 __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
                                              int *labels, int *first, int *max_list, int *max_count, int max_cap,
-                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum,
-                                             const GradRec *s_rec = nullptr) {
-    // every start voxel is valid: the walk list holds whole bricks of a grid made of whole bricks
+                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum) {
+    // every start voxel is valid: the walk list holds whole bricks, and the lanes of a brick the grid cuts start from its
+    // voxels inside the grid (k_ng_trace_g PART)
     const int v = lin24(g, sx, sy, sz);
     const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
     const int ox8 = sx & ~7, oy8 = sy & ~7, oz8 = sz & ~7;   // origin of the own brick
-    GradRec rec = CACHE ? s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
+    GradRec rec = CACHE ? xb_s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
     bool moving = lab0 != -1;
     int result = -1;
     int px = sx, py = sy, pz = sz, steps = 0;
@@ -380,7 +387,7 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             int bl = 0;
             const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
             const bool in_win = !WINDOW || own || plane_in_window(g, px);
-            if (own) rec = s_rec[((px & 7) << 6) | ((py & 7) << 3) | (pz & 7)];
+            if (own) rec = xb_s_rec[((px & 7) << 6) | ((py & 7) << 3) | (pz & 7)];
             else {
                 rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);   // (outside the window: any valid slot, the value is not used)
                 const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *
 // (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
 // LEAN 3 / 4 (= 1 / 2 with the brick cache): the workgroup is exactly eight waves, a pull is exactly one brick, and its 512
 // records are copied into LDS (16 KB) before the waves start (see ng_walk_lean).
-template <int K, int LEAN, bool WINDOW = false>
+template <int K, int LEAN, bool WINDOW = false, bool PART = false>
 __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                        const int *__restrict__ blab, int nb1, int nb2,
                                                        const int *__restrict__ walk, int *fs, int *labels, int *first,
@@ -547,7 +554,6 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
     __shared__ int s_w[8], s_mixed;
     constexpr bool CACHE = LEAN >= 3;
     int prev_brick = -1;
-    __shared__ GradRec s_rec[CACHE ? 512 : 1];
     const int n_items = fs[FS_N_WALK] * 8;
     const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
     const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
@@ -580,8 +586,10 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 prev_brick = b;
                 const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
                 const int t = threadIdx.x;
-                const int lt = lin24(g, b0 * 8 + (t >> 6), b1 * 8 + ((t >> 3) & 7), b2 * 8 + (t & 7));
-                s_rec[t] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
+                int cx = b0 * 8 + (t >> 6), cy = b1 * 8 + ((t >> 3) & 7), cz = b2 * 8 + (t & 7);
+                if (PART) { cx = min(cx, g.nx - 1); cy = min(cy, g.ny - 1); cz = min(cz, g.nz - 1); }   // (beyond the grid: any record, nobody reads the slot)
+                const int lt = lin24(g, cx, cy, cz);
+                xb_s_rec[t] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
                 __syncthreads();
             }
             for (;;) {
@@ -591,9 +599,13 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 if (item >= stop) break;
                 int sx, sy, sz;
                 brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
+                // PART (a brick the grid cuts): a lane whose voxel lies beyond the grid walks from the nearest voxel of the brick
+                // inside it -- the same trajectory, the same label and notes as that voxel's own lane leaves, so the duplicates
+                // change nothing, and the brick's verdict below still speaks of its voxels inside the grid only
+                if (PART) { sx = min(sx, g.nx - 1); sy = min(sy, g.ny - 1); sz = min(sz, g.nz - 1); }
                 if (LEAN) {
                     const int res = ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
-                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0, s_rec);
+                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
                     if (CACHE && bres) {
                         volatile int *w = s_w;
                         if (lane == 0) w[item & 7] = res;

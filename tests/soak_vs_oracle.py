@@ -1,7 +1,7 @@
 """Random soak of the one-GPU pipeline against the CPU oracle (test infrastructure; run by hand on a GPU box, and in a short
 seeded form by tests/test_gpu_soak.py):
 
-    python tests/soak_vs_oracle.py [cases] [seed] [--method neargrid|ongrid] [--odd | --big]
+    python tests/soak_vs_oracle.py [cases] [seed] [--method neargrid|ongrid] [--odd | --oddbig | --big]
 
 Each case: a random grid shape (whole 8^3 bricks, or anything from 10 to 60 with --odd: the routes for grids that are not
 made of bricks), one of four lattices, optional noise / plateaus / vacuum tolerance, a random refinement mode.  The library's
@@ -22,7 +22,7 @@ HEX = np.array([[6.0, 0.0, 0.0], [-3.0, 5.196152422706632, 0.0], [0.0, 0.0, 7.0]
 ORTHO = np.array([[5.0, 0.0, 0.0], [0.0, 6.5, 0.0], [0.0, 0.0, 7.25]])
 
 
-def run(cases, seed, method='neargrid', odd=False, verbose=False, big=False):
+def run(cases, seed, method='neargrid', odd=False, verbose=False, big=False, oddbig=False):
     """-> descriptions of the cases whose result differs from the oracle's"""
     import oracle
     from pybader_amd import _lib, synth
@@ -35,6 +35,8 @@ def run(cases, seed, method='neargrid', odd=False, verbose=False, big=False):
         shape = tuple(int(rng.choice([16, 24, 32, 40, 48, 64, 72, 96])) for _ in range(3))
         if big:       # (--big: a few seconds of oracle time per case)
             shape = tuple(int(rng.choice([64, 96, 128, 160, 192])) for _ in range(3))
+        elif oddbig:  # (--oddbig: grids the brick lattice does not divide, large enough for trapping regions to form)
+            shape = tuple(int(rng.integers(41, 150)) for _ in range(3))
         elif odd:
             shape = tuple(int(rng.integers(10, 61)) for _ in range(3))
         elif rng.random() < 0.3:
@@ -89,7 +91,8 @@ if __name__ == '__main__':
     method = sys.argv[sys.argv.index('--method') + 1] if '--method' in sys.argv else 'neargrid'
     if '--method' in sys.argv:
         args.remove(method)
-    failures = run(int(args[0]) if args else 20, int(args[1]) if len(args) > 1 else 1, method, '--odd' in sys.argv, verbose=True, big='--big' in sys.argv)
+    failures = run(int(args[0]) if args else 20, int(args[1]) if len(args) > 1 else 1, method, '--odd' in sys.argv, verbose=True, big='--big' in sys.argv,
+                   oddbig='--oddbig' in sys.argv)
     print('\n'.join(failures))
     print('bad cases:', len(failures))
     sys.exit(1 if failures else 0)
