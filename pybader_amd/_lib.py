@@ -78,6 +78,7 @@ SYMBOLS = {
     'xb_enable_timing': (_int, [_vp, _int]),
     'xb_set_option': (_int, [_vp, _int, _int]),
     'xb_box_stats': (_int, [_vp, _pi64, _pi64]),
+    'xb_brick_labels': (_int, [_vp, _vp, _i64, _pi64]),
     'xb_slow_path_stats': (_int, [_vp, _pi64, _pi64]),
     'xb_deferred_stats': (_int, [_vp, _pi64]),
     'xb_growth_stats': (_int, [_vp, _pi64, _pi64]),
@@ -593,6 +594,14 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_box_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def brick_labels(self):
+        """per 8^3 brick of the last neargrid assignment: the trapping region it was certified for (> 0) or 0 (walked)"""
+        dims = (C.c_int64 * 3)()
+        check(self.lib.xb_brick_labels(self.h, None, 0, dims))
+        out = np.zeros(tuple(int(d) for d in dims), np.int32)
+        check(self.lib.xb_brick_labels(self.h, _ptr(out), out.size, dims))
+        return out
 
     def slow_path_stats(self):
         a, b = C.c_int64(), C.c_int64()

@@ -350,6 +350,18 @@ int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels) {
     if (box_voxels) *box_voxels = c->box_voxels;
     return XB_OK;
 }
+int xb_brick_labels(xb_ctx *c, int32_t *out, int64_t capacity, int64_t dims[3]) {
+    if (!c || !c->has_grid) return fail(XB_E_STATE, "xb_brick_labels: no grid");
+    if (!c->blab) return fail(XB_E_STATE, "xb_brick_labels: no trapping regions on this context (no neargrid assignment yet)");
+    const int64_t nbr = (int64_t)c->nbk[0] * c->nbk[1] * c->nbk[2];
+    if (dims) { dims[0] = c->nbk[0]; dims[1] = c->nbk[1]; dims[2] = c->nbk[2]; }
+    if (!out) return XB_OK;
+    if (capacity < nbr) return fail(XB_E_ARG, "xb_brick_labels: capacity too small");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->blab, nbr * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
 #ifdef XB_DEBUG_COUNT
 int xb_debug_counts(unsigned long long *out, int reset) {
     hipDeviceSynchronize();

@@ -562,7 +562,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                         box_max, fs, fs + FS_SORT_OK);
         else
-            k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max, fs + FS_SORT_OK);
+            k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                     box_max, fs, fs + FS_SORT_OK);
         k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
         if (bres) k_buni_from_walk<<<256, 256, 0, c->stream>>>(walk, fs + FS_N_WALK, bres, c->first, buni, fs + FS_SORT_OK);
         else k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);

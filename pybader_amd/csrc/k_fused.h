@@ -228,12 +228,19 @@ __global__ __launch_bounds__(TPB) void k_grow_parent(int nb0, int nb1, int nb2, 
     if (seed[b] != 0) { parent[b] = b; return; }            // exactly one maximum: the root of its region
     if ((m >> 27) & 3) { parent[b] = -1; return; }          // several maxima (or a seed beyond the table): never certified
     const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int best = -1, bp = bpot[b];
+    // Round 4: the order along a chain is (potential, is a seed, brick index), lexicographic -- a strict total order, so chains
+    // still cannot cycle, but a TIE of the single-precision potentials no longer ends one.  It matters exactly where it hurts
+    // most: a maximum that lies on a face of its brick has a neighbour voxel of almost its density in the next brick, the two
+    // bricks get the same potential, the neighbour found no higher successor, kept label 0, and the seed brick -- which can
+    // move into it -- died in the kill iteration with its whole region (a third of the voxels of a 500^3 grid walked instead
+    // of certified; the brick-aligned 512^3 of the headline happens to have no maximum on a brick face).
+    int best = -1, bp = bpot[b], bs = 0, bq = b;
     for (unsigned mm = (unsigned)m & 0x7ffffffu; mm; mm &= mm - 1) {   // the bricks it can move into
         const int k = __ffs(mm) - 1;
         const int q = (wrap_any(b0 + k / 9 - 1, nb0) * nb1 + wrap_any(b1 + (k / 3) % 3 - 1, nb1)) * nb2 + wrap_any(b2 + k % 3 - 1, nb2);
-        const int pq = bpot[q];
-        if (pq > bp) { bp = pq; best = q; }
+        if (q == b) continue;   // (a lattice two bricks wide wraps onto the brick itself)
+        const int pq = bpot[q], sq = seed[q] != 0 ? 1 : 0;
+        if (pq > bp || (pq == bp && (sq > bs || (sq == bs && q > bq)))) { bp = pq; bs = sq; bq = q; best = q; }
     }
     parent[b] = best;
 }

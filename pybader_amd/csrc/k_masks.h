@@ -486,7 +486,7 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
             a[2][iy][iz] = tile[K + 2][ty + iy][tz + iz];                                                            \
         }                                                                                                            \
         const int x = x0 + K;                                                                                        \
-        cmax = max_raw(cmax, a[1][1][1]);                                                                            \
+        if (!PART || x < g.nx) cmax = max_raw(cmax, a[1][1][1]);   /* (beyond the grid the tile holds wrapped planes) */ \
         bm_voxel<MT, K, DIAG, PART>(g, a, dface, col_in && x < g.nx, (x * g.ny + y) * g.nz + z, ty, zz, mine, any_tie, \
                                     &s_cnt[tz >> 3], &s_mv[tz >> 3], mu, mirror, co, deep, wx, at_yh, at_zh);          \
     }

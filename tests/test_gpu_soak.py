@@ -11,3 +11,10 @@ pytestmark = pytest.mark.gpu
 def test_random_cases_equal_the_oracle(method, odd, seed):
     failures = run(25, seed, method, odd)
     assert not failures, '\n'.join(failures)
+
+
+def test_random_grids_the_brick_lattice_does_not_divide():
+    """round 4: grids of 41..149 voxels per axis, any remainder modulo 8 (also 1: the bricks one voxel wide that are never
+    certified) -- the brick pipeline with cut bricks against the oracle"""
+    failures = run(8, 105, 'neargrid', oddbig=True)
+    assert not failures, '\n'.join(failures)
