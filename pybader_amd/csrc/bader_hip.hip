@@ -94,6 +94,7 @@ struct xb_ctx {
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
     bool buni_halo_safe = false;   // ... and marks every brick outside the owned planes that is not of a trapping region as mixed:
                                    // it stays right when the peers' halo planes arrive (slabs, xb_assign_finish)
+    bool regions_neargrid = false; // the regions in `blab` are closed under NEARGRID moves (k_brick_masks); false: the ongrid pointer field's
     bool regions_labels = false;   // the resident labels are the last neargrid assignment's (+ refinement): every voxel of a
                                    // trapping-region brick (blab > 0) still carries the region's label
     int n_walk = 0;                // bricks on the walk list of the last assignment

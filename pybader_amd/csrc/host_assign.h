@@ -86,6 +86,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
     }
     c->first_clean = false;
     c->regions_pending = false;
+    c->regions_neargrid = method == XB_METHOD_NEARGRID;
     if (method == XB_METHOD_NEARGRID) {
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
         // the table is a pure function of the resident density, but it is part of the assignment
@@ -351,7 +352,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
         }
     } else
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, nullptr);
-    c->regions_labels = c->regions_pending && c->blab && !c->has_vacuum;   // certain bricks carry their region's label now
+    c->regions_labels = c->regions_pending && c->blab && !c->has_vacuum && c->regions_neargrid;   // certain bricks carry their (neargrid) region's label now
     c->regions_pending = false;
     HIPCHK(hipGetLastError());
     if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
@@ -488,6 +489,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         stage_done("region growth");
     }
     c->blab = c->blab_buf;
+    c->regions_neargrid = true;
     c->walk = walk;
     c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
     const long long own = c->N;
@@ -617,6 +619,119 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     return finish_numbering_on_host(c, nmax, n_maxima);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The single-GPU ongrid assignment with the control flow on the device (round 4): k_og_masks (pointers + brick masks, maxima,
+// potentials) -> the neargrid path's region growth (seed bricks, chase, kill launches, verdict) -> walk list -> pointer chase
+// of the uncertain bricks -> numbering and relabel on the device.  One host wait.  Without vacuum only (a chain that steps
+// onto a vacuum voxel ends there, methods.py:166-168: a brick with vacuum voxels is no trapping region of its maximum).
+// ---------------------------------------------------------------------------------------------------------------
+static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
+    Grid &g = c->g;
+    const int nb0 = (g.nx + BRK - 1) / BRK, nb1 = (g.ny + BRK - 1) / BRK, nb2 = (g.nz + BRK - 1) / BRK, nbr = nb0 * nb1 * nb2;
+    const bool part = g.nx % BRK || g.ny % BRK || g.nz % BRK;
+    if (int rc = ensure_brick_bytes(c, nbr)) return rc;
+    int *fs = c->fs;
+    int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
+    int *bmaxv = walk, *bpot = c->list + 5 * nbr;
+    int *box_max = c->boxbuf + BB_REGMAX, *box_first = c->boxbuf + BB_REGFIRST;
+    c->box_max_tab = box_max;
+    HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
+    if (!c->first_clean) {
+        k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
+        HIPCHK(hipGetLastError());
+    }
+    c->first_clean = false;
+    c->regions_pending = false;
+    c->buni_valid = false; c->regions_labels = false;
+    c->list_valid = false;
+    c->zero_outside[0] = -1;
+    const GridL gl = light(g);
+    {
+        ScopedTimer t(c, 1);
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
+        GridS gs;
+        if (sym_grid(g, gs)) {
+            if (part) k_og_masks<GridS, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->labels, small, 0, bmask, bmaxv, bpot);
+            else k_og_masks<GridS, false><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->labels, small, 0, bmask, bmaxv, bpot);
+        } else {
+            if (part) k_og_masks<Grid, true><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, 0, bmask, bmaxv, bpot);
+            else k_og_masks<Grid, false><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, 0, bmask, bmaxv, bpot);
+        }
+    }
+    {
+        ScopedTimer t4(c, 4);
+        k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
+        k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
+        k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64);
+        k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
+        const int long_schedule = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
+        const int launches = std::min(long_schedule, c->grow_kill_launches);
+        const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
+        for (int l = 0; l < launches; l++)
+            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
+        if (launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
+        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, nullptr, 0);
+        HIPCHK(hipGetLastError());
+    }
+    c->blab = c->blab_buf;
+    c->regions_neargrid = false;   // (closed under the pointer moves only: the refinement's retraces must not stop on them)
+    c->walk = walk;
+    c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
+    {
+        ScopedTimer t0(c, 0);
+        int bits = 0;
+        while ((1 << bits) < std::max(std::max(nb0, nb1), nb2)) bits++;
+        const unsigned n_codes = 1u << (3 * bits);
+        k_brick_walk_list_morton<<<(n_codes + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nb0, nb1, nb2, n_codes, c->blab, walk,
+                                                                                              fs + FS_N_WALK, fs + FS_GROW_RETRY);
+        k_note_regions<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, nb1, nb2, fs, box_first, box_max, c->first, c->max_list, fs + FS_N_MAX, c->max_cap);
+        c->regions_pending = true;
+        k_og_walk_dev<<<16384, XB_WAVE, 0, c->stream>>>(gl, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap,
+                                                        1 << 22);
+        HIPCHK(hipGetLastError());
+    }
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
+    int *buni = reinterpret_cast<int *>(c->st);
+    if (g.nz % 4 == 0)
+        k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                    box_max, fs, fs + FS_SORT_OK);
+    else
+        k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                 box_max, fs, fs + FS_SORT_OK);
+    k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+    k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints + FS_COUNT, c->max_aux, XB_SORT_MAX * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int *h = c->host_ints;
+    if (h[FS_GROW_RETRY]) {   // the short kill schedule did not reach the fixpoint: once more, with the worst-case one from now on
+        c->grow_kill_launches = 1 << 20;
+        c->stat_grow_retries++;
+        return assign_ongrid_fused(c, n_maxima);
+    }
+    if (h[FS_ERR] & 1) return fail(XB_E_STATE, "ongrid pointer chase did not terminate");
+    c->n_boxes = h[FS_N_BOXES];
+    c->box_voxels = (long long)h[FS_N_CERTAIN] * BRK * BRK * BRK;
+    c->n_walk = h[FS_N_WALK];
+    const int nmax = h[FS_N_MAX];
+    if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+    if (h[FS_SORT_OK]) {
+        c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+        c->label_wire = label_wire_for(nmax);
+        c->regions_pending = false;
+        c->buni_valid = true;
+        c->first_clean = true;
+        if (n_maxima) *n_maxima = nmax;
+        return XB_OK;
+    }
+    return finish_numbering_on_host(c, nmax, n_maxima);   // more maxima than the device sort takes
+}
+
 // maxima table -> host, sort by first voxel, rank + relabel (the tail of the host-driven path)
 static int sort_and_finish(xb_ctx *c, int64_t n, int64_t *n_maxima);
 static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima) {
@@ -640,6 +755,7 @@ int xb_assign(xb_ctx *c, int method, int64_t *n_maxima) {
         return assign_neargrid_fused(c, n_maxima);
     }
     if (method == XB_METHOD_ONGRID && !c->has_vacuum) c->labels_zero_pending = false;   // the pointer pass writes every label
+    if (method == XB_METHOD_ONGRID && !c->has_vacuum && fused_ok(c)) return assign_ongrid_fused(c, n_maxima);
     int64_t n = 0;
     if (int rc = xb_assign_trace(c, method, &n)) return rc;
     return sort_and_finish(c, n, n_maxima);
