@@ -291,12 +291,8 @@ def main():
     windowed = runner.enable_table_window(args.table_margin) if world > 1 else False
     ctx.synth_density(lattice, atoms, background)      # inputs resident in HBM before timing starts
     ctx.enable_timing(True)
-    if 'XB_OPT_TRACE' in os.environ:
-        ctx.set_option(0, int(os.environ['XB_OPT_TRACE']))
     if 'XB_OPT_DBG' in os.environ:
         ctx.set_option(3, int(os.environ['XB_OPT_DBG']))
-    if 'XB_OPT_TPB' in os.environ:
-        ctx.set_option(2, int(os.environ['XB_OPT_TPB']))
     for key in range(7, 27):
         if f'XB_OPT_{key}' in os.environ:
             ctx.set_option(key, int(os.environ[f'XB_OPT_{key}']))

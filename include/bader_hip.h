@@ -240,15 +240,18 @@ int xb_host_waits(int64_t *n);
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 int xb_enable_timing(xb_ctx *c, int on);
-/* tuning knobs (key 0: trace-kernel launch shape, bit0 4x4x4 brick per wave, bit1 XCD-aware order;
- * key 1: trapping boxes bit0 / brick growth bit1; key 2: trace threads per block; key 3: debug prints;
- * key 13-18: round-3 switches, each an exactness cross-check in the tests (13 mirror prefilter of pass A, 14 lean walker,
- * 15 waves per trace workgroup, 16 chase growth, 17 kill launches scheduled after a chase, 18 narrowed label halos,
- * 19 self exchange (tests), 20 diagonal T_grad form, 21 brick cache of the trace, 22 slab-sized table / scratch (before xb_set_grid), 24 collectives return
- * without waiting (ordered on the stream));
- * key 4: workgroups of the edge_check chase; key 5: its LDS queue capacity, lowered in tests to force
- * the overflow hand-over; key 6: drop the cached gradient-field table, so that the next refinement
- * rebuilds it -- bench.py does this every step: a table kept from an earlier step would hide 1.6 ms) */
+/* Switches.  A USER of the library sets none of them: every default is the measured best, and no switch changes a result.
+ * What each is for:
+ *   6  drop the cached gradient-field table (benchmarks: a table kept from an earlier step would hide 1.6 ms per step);
+ *   3  debug prints (bit 2 edge_check passes, bit 4 slab statistics, bit 5 wait after every stage of an assignment);
+ *   24 collectives return without waiting, 22 slab-sized table / scratch (before xb_set_grid): set by pybader_amd.slab itself;
+ *   exactness cross-checks the tests run BOTH ways -- 1 trapping regions (0: plain full trajectories from a record per voxel),
+ *   7 device-side control flow (0: the host-driven calls), 13 mirror prefilter of pass A, 14 lean walker (0: the generic one),
+ *   16 chase growth (0: propagation launches), 20 diagonal T_grad form, 25 tile-wise dilation;
+ *   test plumbing -- 4 / 5 workgroups and LDS queue capacity of the edge_check chase (lowered to force the overflow
+ *   hand-over), 8 waves of the persistent trace, 17 kill launches scheduled after a chase, 18 narrowed label halos,
+ *   19 a rank may exchange planes with itself.
+ * (Round 4 removed 0, 2, 9-12, 15, 21: launch shapes and routes that no shipped configuration used.) */
 int xb_set_option(xb_ctx *c, int key, int value);
 /* device bytes held for the grid (density, labels, flags, numbering + the table of the window planes + scratch sized by the
  * slab): what a rank of the slab decomposition costs; the reference's blocks are copies of the block extent

@@ -117,7 +117,6 @@ struct xb_ctx {
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
-    int opt_trace_tpb = 64;   // one wave per block: a finished wave frees its slot at once
     bool grad_valid = false;
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
@@ -130,16 +129,13 @@ struct xb_ctx {
     int opt_tile_dilate = 1;   // the dilation of the edge sweep tile by tile (k_edge_dilate_tiles) instead of from the edge list (tests compare)
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
     int opt_lean_mem = 1;      // slabs: table, `list` and `stage` sized by the slab instead of the grid (0: everything full size)
-    int opt_trace_cache = 1;   // group trace: the own brick's records in LDS (k_ng_trace_g, LEAN 3 / 4)
     int opt_mask_diag = 1;     // pass A: the three-product form of T_grad . grad on orthogonal lattices (tests compare)
     int opt_narrow_halo = 1;   // label halos travel as dtype_calc(-n_maxima) (int8 / int16) instead of int32 (comm.h)
     int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
     int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
     long long stat_grow_retries = 0;
-    int opt_trace_group = 8;   // persistent trace: waves per workgroup (the eighths of a brick on one compute unit, k_ng_trace_g)
     int opt_lean = 1;          // persistent trace: the lean walker (k_trace.h, ng_walk_lean); 0: ng_walk_wave (tests compare)
     int opt_mirror = 1;        // pass A: mirror prefilter of the ongrid face test (k_masks.h, bm_mirror)
-    int opt_sparse = 1;        // single-GPU neargrid assignment: brick masks for every voxel + records for the walk-list bricks only
     int grad_rule = 0;         // which tie rule the resident table obeys: 0 refinement.py:111, 1 methods.py:324, 2 both
                                // (the density has no voxel where they differ)
     int *labels = nullptr;
@@ -161,10 +157,7 @@ struct xb_ctx {
     bool labels_zero_pending = false;   // volumes_init without vacuum: labels := 0 is owed (see xb_vacuum_assign)
     int zero_outside[3] = {-1, -1, -1}; // slab (x0, x1, halo) for which every label outside the planes [x0-halo, x1+halo) is known to be 0
     int opt_fused = 1;         // 0: the host-driven round-1 orchestration (kept for slabs and odd grids)
-    int opt_trace_grid = 8192; // one-wave workgroups of the persistent trace
-    int opt_trace_chunk = 1;   // items (4x4x4 eighths of a brick) per pull: 1 keeps the waves of an XCD on ~128 neighbouring bricks (2 MB of table, L2 resident); 32 per pull ran 1.8x slower
-    int opt_trace_xcd = 1;     // 1: ranges by the real XCC id, 0: by blockIdx % 8
-    int opt_morton = 1;        // walk list in Morton order of the bricks
+    int opt_trace_grid = 8192; // waves of the persistent trace (1024 workgroups of eight)
     unsigned long long *counters64 = nullptr;
     double *dsum = nullptr;
     int *host_ints = nullptr;  // pinned
@@ -181,7 +174,6 @@ struct xb_ctx {
     int list_n = 0;            // entries of `list` that hold the owned known == -2 voxels ...
     bool list_valid = false;   // ... when this is set (by xb_edge_find)
     bool timing = false;
-    int opt_trace = 1;   // bit0: 4x4x4 brick per wave, bit1: XCD-aware block order
     TimedKernel tk[8];
     long long n_alloc = 0;
 };
@@ -286,30 +278,22 @@ const char *xb_last_error(void) { return g_err.c_str(); }
 
 int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
-    if (key == 0) c->opt_trace = value;
-    else if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
+    if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
     else if (key == 3) c->opt_dbg = value;
     else if (key == 4 && value >= 1 && value <= 4096) c->opt_ec_groups = value;
     else if (key == 5 && value >= 2 && value <= EC_Q) c->opt_ec_qcap = value;
     else if (key == 6) c->grad_valid = false;  // drop the cached gradient-field table (a refinement rebuilds it)
-    else if (key == 2 && (value == 64 || value == 128 || value == 256)) c->opt_trace_tpb = value;
     else if (key == 7) c->opt_fused = value != 0;  // 0: the host-driven orchestration on one GPU too (tests compare the two)
     else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
-    else if (key == 9 && value >= 1 && value <= 4096) c->opt_trace_chunk = value;
-    else if (key == 10) c->opt_trace_xcd = value != 0;
-    else if (key == 11) c->opt_morton = value != 0;
-    else if (key == 12) c->opt_sparse = value != 0;   // 0: the round-1 route (a 32-byte record for every voxel)
     else if (key == 14) c->opt_lean = value != 0;
     else if (key == 16) c->opt_chase = value != 0;
     else if (key == 18) c->opt_narrow_halo = value != 0;
     else if (key == 19) c->opt_self_exchange = value != 0;
     else if (key == 20) c->opt_mask_diag = value != 0;
-    else if (key == 21) c->opt_trace_cache = value != 0;
     else if (key == 22) c->opt_lean_mem = value != 0;   // (before xb_set_grid)
     else if (key == 24) c->opt_async_comm = value != 0;
     else if (key == 25) c->opt_tile_dilate = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
-    else if (key == 15 && (value == 1 || value == 2 || value == 4 || value == 8)) c->opt_trace_group = value;
     else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;

@@ -97,11 +97,11 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
             if (int rc = ensure_grad(c, true, true, true)) return rc;
         }
         c->g.main_ties = 1;   // methods.neargrid's stepping rule for everything the assignment traces
-        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX;
+        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX;
         {
             ScopedTimer t(c, 0);
-            const int opt = c->opt_trace;
-            const int tpb = c->opt_trace_tpb;
+            const int opt = 3;      // (k_ng_trace: one wave per 4x4x4 cube of start voxels, XCD-aware block order)
+            const int tpb = 64;     // one wave per block: a finished wave frees its slot at once
             const bool slab_bricks = (g.x0 % 8 == 0) && (g.x1 % 8 == 0);
             if (c->blab && slab_bricks) {
                 // trapping regions known per brick: fill them in one sweep, trace only the rest
@@ -140,10 +140,9 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     ScopedTimer tw(c, 6);
                     int *redo = (int *)c->stage;
                     const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
-                    k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                    k_ng_trace_g<2, 0><<<std::max(1, c->opt_trace_grid / 8), XB_WAVE * 8, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
                                                                                   c->fs, c->labels, c->first, c->max_list, c->max_cap, redo,
-                                                                                  redo_cap, maxsteps, c->has_vacuum ? 1 : 0,
-                                                                                  c->opt_trace_chunk, c->opt_trace_xcd);
+                                                                                  redo_cap, maxsteps, c->has_vacuum ? 1 : 0, 8, 1);
                     k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
                         light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], redo, c->fs + FS_N_OVF, c->labels,
                         c->first, c->max_list, max_count_dev, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap,
@@ -207,76 +206,36 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
         c->g.main_ties = 0;
     } else if (method == XB_METHOD_ONGRID) {
         c->zero_outside[0] = -1;   // (the pointer pass writes the labels of every plane, on a slab too)
-        const int nbr_all = (int)(c->N / (BRK * BRK * BRK));
-        // trapping regions of the pointer field (whole 8^3 bricks, one slab, no vacuum), else plain pointer jumping
-        const bool regions = c->opt_boxes && c->opt_bricks && !c->has_vacuum && g.x1 - g.x0 == g.nx && g.nx % BRK == 0 &&
-                             g.ny % BRK == 0 && g.nz % BRK == 0 && g.nx >= 16 && g.ny >= 16 && g.nz >= 16 &&
-                             40LL * nbr_all <= c->N;
+        // Host-driven ongrid (slabs, vacuum, tiny grids, option 7 = 0): the pointer of every voxel by k_og_masks -- its brick
+        // outputs go to scratch, nobody reads them -- then pointer jumping until every chain has reached its root.  (The
+        // trapping regions of the pointer field are built by assign_ongrid_fused, one GPU without vacuum.)
         c->blab = nullptr;
         c->n_boxes = 0;
         c->box_voxels = 0;
         {
             ScopedTimer t(c, 1);
             const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+            const int nbr = ((g.nx + BRK - 1) / BRK) * ((g.ny + BRK - 1) / BRK) * ((g.nz + BRK - 1) / BRK);
+            if (3LL * nbr > c->list_cap) return fail(XB_E_LIMIT, "xb_assign: scratch too small for the brick arrays of the pointer pass");
             dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
-            HIPCHK(hipMemsetAsync(c->counters + 9, 0, sizeof(int), c->stream));
-            int *bm = regions ? c->list + nbr_all : nullptr;
+            int *bm = c->list, *bmv = c->list + nbr, *bpt = c->list + 2 * nbr;
             GridS gs;
-            if (sym_grid(g, gs))
-                k_og_pointer_tiled<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->labels, small, c->has_vacuum ? 1 : 0,
-                                                                       c->boxbuf + BB_SEEDS, c->counters + 9, BB_SEED_CAP, bm);
-            else
-                k_og_pointer_tiled<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, c->has_vacuum ? 1 : 0,
-                                                                      c->boxbuf + BB_SEEDS, c->counters + 9, BB_SEED_CAP, bm);
+            if (sym_grid(g, gs)) k_og_masks<GridS, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->labels, small, c->has_vacuum ? 1 : 0, bm, bmv, bpt);
+            else k_og_masks<Grid, true><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->labels, small, c->has_vacuum ? 1 : 0, bm, bmv, bpt);
         }
         HIPCHK(hipGetLastError());
-        if (regions) {
-            int ns = 0;
-            if (int rc = read_counter(c, 9, &ns)) return rc;
-            if (ns >= 1 && ns <= XB_BOX_SEEDS_MAX) {
-                std::vector<int> seeds(ns);
-                HIPCHK(hipMemcpyAsync(seeds.data(), c->boxbuf + BB_SEEDS, ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (int rc = table_regions(c, seeds, true, true)) return rc;
-            }
-        }
-        box_max = c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX;
-        if (c->blab) {
-            const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
-            int *walk = c->list + 4 * nbr;
-            c->walk = walk;
-            HIPCHK(hipMemsetAsync(c->counters + 13, 0, sizeof(int), c->stream));
-            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, c->counters + 13);
-            k_note_certain_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(light(g), c->nbk[0], c->nbk[1], c->nbk[2], 0, nbr, c->blab,
-                                                                          box_max, c->first, c->max_list,
-                                                                          c->counters + 0, c->max_cap);
-            int nwalk = 0;
-            if (int rc = read_counter(c, 13, &nwalk)) return rc;
-            c->n_walk = nwalk;
-            if (nwalk) {
-                HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));
-                k_og_walk<<<8 * nwalk, XB_WAVE, 0, c->stream>>>(light(g), box_max, c->blab, c->nbk[1], c->nbk[2], walk,
-                                                               nwalk, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap,
-                                                               1 << 22, c->counters + 8);
-                HIPCHK(hipGetLastError());
-                int err = 0;
-                if (int rc = read_counter(c, 8, &err)) return rc;
-                if (err) return fail(XB_E_STATE, "ongrid pointer chase did not terminate");
-            }
-            c->regions_pending = true;
-        } else {
-            for (int it = 0; it < 64; it++) {
-                HIPCHK(hipMemsetAsync(c->counters + 4, 0, sizeof(int), c->stream));
-                k_og_jump<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->labels, c->counters + 4);
-                HIPCHK(hipGetLastError());
-                int nd = 0;
-                if (int rc = read_counter(c, 4, &nd)) return rc;
-                if (!nd) break;
-                if (it == 63) return fail(XB_E_LIMIT, "ongrid pointer jumping did not converge");
-            }
-            k_note_roots<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap);
+        box_max = c->boxbuf + BB_REGMAX;
+        for (int it = 0; it < 64; it++) {
+            HIPCHK(hipMemsetAsync(c->counters + 4, 0, sizeof(int), c->stream));
+            k_og_jump<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->labels, c->counters + 4);
             HIPCHK(hipGetLastError());
+            int nd = 0;
+            if (int rc = read_counter(c, 4, &nd)) return rc;
+            if (!nd) break;
+            if (it == 63) return fail(XB_E_LIMIT, "ongrid pointer jumping did not converge");
         }
+        k_note_roots<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, c->max_list, c->counters + 0, c->max_cap);
+        HIPCHK(hipGetLastError());
     } else
         return fail(XB_E_ARG, "xb_assign: unknown method %d", method);
     int nmax = 0;
@@ -318,20 +277,19 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     }
     c->buni_valid = false; c->regions_labels = false;
     if (c->regions_pending && c->blab) {
-        if (g.nz % 4 == 0 && g.ny % 8 == 0 && g.x0 % 8 == 0 && g.x1 % 8 == 0 && c->nbk[1] == g.ny / 8)   // whole bricks: one brick-label lookup per 8 rows
+        // (one brick-label lookup per 8 rows; 16-byte stores when the rows are aligned.  The launch covers 4-plane groups from x0 on)
+        if (g.nz % 4 == 0)
             k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
-                light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX),
+                light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX),
                 nullptr, nullptr, c->n_boxes);
-        else if (g.nz % 4 == 0)
-            k_relabel_regions4<<<nblocks(own / 4), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1],
-                                                                    c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
         else
-            k_relabel_regions<<<nblocks(own), TPB, 0, c->stream>>>(light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2],
-                                                                   (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), nullptr);
+            k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
+                light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX),
+                nullptr, nullptr, c->n_boxes);
         if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), c->first, buni, nullptr);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr);
             if (c->n_walk)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
                                                                                 c->walk, c->n_walk, nullptr, nullptr, buni);
@@ -343,7 +301,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
             k_fill<int><<<64, TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_BOXMAX), c->first, buni, nullptr);
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr);
             if (c->n_walk)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
                                                                                 c->walk, c->n_walk, nullptr, nullptr, buni);
@@ -387,16 +345,12 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     int *fs = c->fs;
     // scratch carved from `list` (free during an assignment): seed labels, brick masks, two label buffers, walk list
     int *seed = c->list, *bmask = c->list + nbr, *buf0 = c->list + 2 * nbr, *buf1 = c->list + 3 * nbr, *walk = c->list + 4 * nbr;
-    const bool sparse = c->opt_sparse != 0;
-    int *seeds = c->boxbuf + BB_SEEDS, *mxyz = c->boxbuf + BB_MXYZ, *rcap = c->boxbuf + BB_RCAP,
-        *box_max = c->boxbuf + (sparse ? BB_REGMAX : BB_BOXMAX), *bx = c->boxbuf + BB_EXT, *br = c->boxbuf + BB_EXT + 3 * XB_BOXES_MAX,
-        *box_first = c->boxbuf + (sparse ? BB_REGFIRST : BB_EXT + 4 * XB_BOXES_MAX), *bad = c->boxbuf + BB_BAD;
+    int *box_max = c->boxbuf + BB_REGMAX, *box_first = c->boxbuf + BB_REGFIRST;
     int *bmaxv = walk;   // (free until the walk list is made)
     int *bpot = c->list + 5 * nbr;   // brick potentials of the region growth (k_grow_parent); buf1 doubles as the parent array
-    const bool chase = sparse && c->opt_chase;
+    const bool chase = c->opt_chase != 0;
     int *bres = nullptr;   // per walk-list brick: the one maximum all its voxels ended on (k_ng_trace_g), for the edge sweep's uniformity
     c->box_max_tab = box_max;
-    const int stride = XB_BOX_K + 4;
     // (debug switch 32: wait after every stage and say so -- finds the kernel that does not come back)
     auto stage_done = [&](const char *what) {
         if (c->opt_dbg & 32) {
@@ -409,7 +363,6 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         }
     };
     HIPCHK(hipMemsetAsync(fs, 0, FS_TOTAL * sizeof(int), c->stream));
-    if (!sparse) HIPCHK(hipMemsetAsync(bad, 0, (size_t)XB_BOXES_MAX * stride * sizeof(int), c->stream));   // (the seed cubes' shell scans only)
     if (!c->first_clean) {  // a previous assignment did not finish: `first` may hold stale minima
         k_fill<int><<<4096, TPB, 0, c->stream>>>(c->first, XB_INT_MAX, c->N);
         HIPCHK(hipGetLastError());
@@ -421,7 +374,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     g.main_ties = 1;   // methods.neargrid's tie test (methods.py:324)
     const GridL gl = light(g);
     (void)gl0;
-    {   // brick masks + seeds (+ the full table on the round-1 route, opt_sparse = 0)
+    {   // brick masks + seeds
         ScopedTimer t4(c, 4);
         {
             ScopedTimer t5(c, 5);
@@ -429,7 +382,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             dim3 grid((g.nz + GT_Z - 1) / GT_Z, (g.ny + GT_Y - 1) / GT_Y, (g.nx + GT_X - 1) / GT_X);
             GridS gs;
             const bool sym = sym_grid(g, gs);
-            if (sparse) {
+            {
                 // the assignment's tie rule (methods.py:324) is the template argument
                 int mirror = 0;
                 double mu_scale = 0.;
@@ -444,18 +397,13 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                 if (sym && diag) k_brick_masks<GridS, 1, true><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
                 else if (sym) k_brick_masks<GridS, 1, false><<<grid, TPB, 0, c->stream>>>(gs, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, mu_scale, mirror, bpot);
                 else k_brick_masks<Grid, 1, false><<<grid, TPB, 0, c->stream>>>(g, c->rho, small, bmask, bmaxv, fs + FS_TIES, 0, 0., 0, bpot);
-            } else if (sym)
-                k_grad_field<GridS><<<grid, TPB, 0, c->stream>>>(gs, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
-                                                                bmask, fs + FS_TIES);
-            else
-                k_grad_field<Grid><<<grid, TPB, 0, c->stream>>>(g, c->rho, c->grad, seeds, fs + FS_N_SEEDS, BB_SEED_CAP, small,
-                                                               bmask, fs + FS_TIES);
+            }
         }
         stage_done("brick masks");
         c->grad_valid = true;
         c->grad_rule = 1;
-        c->grad_cover = sparse ? 1 : 0;
-        if (sparse) {
+        c->grad_cover = 1;
+        {
             // seeds: the bricks that hold exactly one maximum (no cubes, no cap on the number of maxima); they are not
             // fixed: the kill iteration certifies them like every other brick
             k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
@@ -465,13 +413,6 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                 k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
             } else
                 k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
-        } else {
-            // closed seed cubes around the maxima, then brick growth -- all decided on the device
-            k_box_setup<<<1, XB_BOXES_MAX, 0, c->stream>>>(gl, fs, seeds, BB_SEED_CAP, XB_BOX_SEEDS_MAX, mxyz, rcap);
-            const long long wmax = 2LL * XB_BOX_K + 1;
-            k_box_shells_dev<false><<<dim3(nblocks(wmax * wmax * wmax), 8), TPB, 0, c->stream>>>(g, c->rho, c->grad, fs, mxyz, rcap, bad, stride);
-            k_box_pick<<<1, XB_BOXES_MAX, 0, c->stream>>>(fs, seeds, mxyz, rcap, bad, stride, box_max, bx, br);
-            k_brick_seed_dev<<<(nbr + 255) / 256, 256, 0, c->stream>>>(gl, nb0, nb1, nb2, fs, bx, br, seed, buf0);
         }
         // the worst-case schedule; after a chase only the kill iteration is left, which dies out within a few bricks of the
         // dividing surfaces: a short schedule first, and a repeat of the whole assignment with the long one (FS_GROW_RETRY)
@@ -480,11 +421,10 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         const int launches = chase ? std::min(long_schedule, c->grow_kill_launches) : long_schedule;
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
-            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, sparse ? 0 : 1);
+            k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
         if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
-        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, sparse ? XB_REGIONS_MAX : XB_BOXES_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, sparse ? c->brick_rec : nullptr,
-                                                 sparse ? 0 : 1);
+        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
         HIPCHK(hipGetLastError());
         stage_done("region growth");
     }
@@ -495,15 +435,14 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     const long long own = c->N;
     {   // region fill / notes, then the walkers of the uncertain bricks
         ScopedTimer t0(c, 0);
-        if (c->opt_morton) {
+        {
             int bits = 0;
             while ((1 << bits) < std::max(std::max(nb0, nb1), nb2)) bits++;
             const unsigned n_codes = 1u << (3 * bits);
             k_brick_walk_list_morton<<<(n_codes + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nb0, nb1, nb2, n_codes, c->blab, walk,
                                                                                                   fs + FS_N_WALK, fs + FS_GROW_RETRY);
-        } else
-            k_brick_walk_list<<<(nbr + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nbr, 0, nbr, c->blab, walk, fs + FS_N_WALK, fs + FS_GROW_RETRY);
-        if (sparse) {   // pass B: records for the bricks of the walk list only
+        }
+        {   // pass B: records for the bricks of the walk list only
             ScopedTimer t7(c, 7);
             const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
             GridS gs;
@@ -526,31 +465,20 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             // the lean walker needs 24-bit index products and nothing else the fused path does not already guarantee (whole-grid
             // table window, brick-label regions); 32-bit table offsets up to 2^27 voxels
             const int lean = (gl.use24 && c->opt_lean) ? (c->N <= (1LL << 27) ? 2 : 1) : 0;
-            const int gw = c->opt_trace_group;   // waves per workgroup (1: one-wave workgroups, every wave pulls for itself)
 #define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
                       maxsteps, c->has_vacuum ? 1 : 0
-            if (gw > 1 || part) {
-                const int groups = std::max(1, c->opt_trace_grid / (part ? 8 : gw)), ch = part ? 8 : std::max(8, c->opt_trace_chunk);
-                if (lean && (part || (gw == 8 && ch == 8 && c->opt_trace_cache))) {   // one brick per pull: its records go through LDS
-                    // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
-                    if (!c->has_vacuum) bres = c->list + 6 * nbr;
-                    if (part) {
-                        if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
-                        else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
-                    } else
-                    if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
-                    else k_ng_trace_g<2, 3><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd, bres);
-                } else
-                if (part) k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);   // (the generic walker tests every start voxel)
-                else if (lean == 2) k_ng_trace_g<2, 2><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
-                else if (lean == 1) k_ng_trace_g<2, 1><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
-                else k_ng_trace_g<2, 0><<<groups, XB_WAVE * gw, 0, c->stream>>>(XB_TRACE_ARGS, ch, c->opt_trace_xcd);
-            } else if (lean == 2)
-                k_ng_trace_p<2, 2><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
-            else if (lean == 1)
-                k_ng_trace_p<2, 1><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
-            else
-                k_ng_trace_p<2, 0><<<c->opt_trace_grid, XB_WAVE, 0, c->stream>>>(XB_TRACE_ARGS, c->opt_trace_chunk, c->opt_trace_xcd);
+            // persistent workgroups of eight waves, one brick per pull (per-XCD cursors over the Morton-ordered walk list)
+            const int groups = std::max(1, c->opt_trace_grid / 8);
+            if (lean) {   // the lean walker, the own brick's records in LDS
+                // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
+                if (!c->has_vacuum) bres = c->list + 6 * nbr;
+                if (part) {
+                    if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                    else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                else k_ng_trace_g<2, 3><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+            } else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
+                k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
 #undef XB_TRACE_ARGS
         }
         HIPCHK(hipGetLastError());
@@ -784,4 +712,3 @@ int xb_get_maxima(xb_ctx *c, int64_t *maxima_out, int64_t capacity) {
     }
     return XB_OK;
 }
-

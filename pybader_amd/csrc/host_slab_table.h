@@ -20,7 +20,7 @@ int xb_set_table_window(xb_ctx *c, int64_t margin) {
 }
 static bool slab_sparse_ok(const xb_ctx *c) {
     const Grid &g = c->g;
-    return c->opt_sparse && c->opt_boxes && c->opt_bricks && table_windowed(c) && g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 &&
+    return c->opt_boxes && c->opt_bricks && table_windowed(c) && g.nx % BRK == 0 && g.ny % BRK == 0 && g.nz % BRK == 0 &&
            g.x0 % BRK == 0 && g.x1 % BRK == 0 && g.ny >= 16 && g.nz >= 16 && 7LL * (c->N / (BRK * BRK * BRK)) <= c->N;
 }
 int xb_table_build(xb_ctx *c, int64_t *n_local_seeds) {
@@ -148,16 +148,11 @@ int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t an
         c->table_prebuilt = true;
         return XB_OK;
     }
-    int rc = XB_OK;
-    if (n_seeds >= 1 && n_seeds <= XB_BOX_SEEDS_MAX) {
-        std::vector<int> sv(n_seeds);
-        for (int64_t i = 0; i < n_seeds; i++) sv[i] = (int)seeds[i];
-        ScopedTimer t(c, 4);
-        rc = table_regions(c, sv, true);
-    }
+    // (no trapping regions on this route: the records of every voxel of the window are there, the slab is traced in full)
+    (void)seeds; (void)n_seeds;
     c->table_stage = 2;
     c->table_prebuilt = true;
-    return rc;
+    return XB_OK;
 }
 
 void *xb_labels_ptr(xb_ctx *c) {

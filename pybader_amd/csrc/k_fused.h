@@ -41,98 +41,18 @@ enum {
 };
 
 #define XB_REGIONS_MAX 65535   // trapping regions seeded by bricks (k_seed_bricks)
-#define XB_BOX_K 32   // seed cubes are searched up to this radius (brick growth takes over from there)
 
-// seeds (unsorted, appended atomically by the table pass) -> sorted seeds, their coordinates and the largest
-// radius each cube may take (stay clear of the nearest other maximum; a cube must not wrap onto itself)
-// (one block of XB_BOXES_MAX threads: a cell with hundreds of atoms has hundreds of maxima)
-#define XB_BOXES_MAX 1024
-__global__ __launch_bounds__(XB_BOXES_MAX) void k_box_setup(GridL g, int *fs, int *seeds, int seed_cap, int max_seeds, int *mxyz, int *rcap) {
-    __shared__ int s[XB_BOXES_MAX];
-    const int t = threadIdx.x;
-    int ns = fs[FS_N_SEEDS];
-    if (ns < 1 || ns > max_seeds || ns > seed_cap || ns > XB_BOXES_MAX) ns = 0;
-    const int mine = t < ns ? seeds[t] : XB_INT_MAX;
-    int rank = 0;
-    if (t < ns) s[t] = mine;
-    __syncthreads();
-    for (int o = 0; o < ns; o++) rank += (s[o] < mine);   // seeds are distinct voxels
-    __syncthreads();
-    if (t < ns) s[rank] = mine;
-    __syncthreads();
-    if (t < ns) {
-        const int v = s[t];
-        seeds[t] = v;
-        const int x = v / g.nyz, y = (v % g.nyz) / g.nz, z = v % g.nz;
-        mxyz[3 * t] = x; mxyz[3 * t + 1] = y; mxyz[3 * t + 2] = z;
-        int cap = min(min(g.nx, g.ny), g.nz) / 2 - 2;
-        for (int o = 0; o < ns; o++)
-            if (o != t) {
-                const int w = s[o];
-                const int d = max(max(min_image_abs(x - w / g.nyz, g.nx), min_image_abs(y - (w % g.nyz) / g.nz, g.ny)),
-                                  min_image_abs(z - w % g.nz, g.nz));
-                cap = min(cap, d - 1);
-            }
-        rcap[t] = max(cap, 0);
-    }
-    if (t == 0) fs[FS_N_SEEDS_EFF] = ns;
-}
-// shells 0..XB_BOX_K of every seed cube (see k_box_shells); blockIdx.y strides over the seeds found on the device
-template <bool FROM_RHO>
-__global__ __launch_bounds__(TPB) void k_box_shells_dev(Grid g, const double *__restrict__ rho, const GradRec *__restrict__ G,
-                                                        const int *__restrict__ fs, const int *__restrict__ mxyz,
-                                                        const int *__restrict__ rcap, int *bad, int stride) {
-    const int ns = fs[FS_N_SEEDS_EFF];
-    for (int m = blockIdx.y; m < ns; m += gridDim.y) {
-        const int rhi = min(XB_BOX_K, rcap[m]);
-        const int w = 2 * rhi + 1;
-        const long long t = (long long)blockIdx.x * TPB + threadIdx.x;
-        if (t >= (long long)w * w * w) continue;
-        const int o[3] = {(int)(t / ((long long)w * w)) - rhi, (int)((t / w) % w) - rhi, (int)(t % w) - rhi};
-        const int d = max(max(abs(o[0]), abs(o[1])), abs(o[2]));
-        const int x = wrap_any(mxyz[3 * m] + o[0], g.nx), y = wrap_any(mxyz[3 * m + 1] + o[1], g.ny),
-                  z = wrap_any(mxyz[3 * m + 2] + o[2], g.nz);
-        int lo[3], hi[3];
-        if (FROM_RHO) move_ranges_rho(rho, g, x, y, z, lo, hi);
-        else move_ranges(fetch_rec_w(g, G, (x * g.ny + y) * g.nz + z), lo, hi);
-        int D = 0;
-#pragma unroll
-        for (int j = 0; j < 3; j++) D = max(D, max(abs(o[j] + lo[j]), abs(o[j] + hi[j])));
-        for (int R = d; R < D; R++) bad[m * stride + R] = 1;
-    }
-}
-// the largest closed radius per seed; seeds with one become boxes (ids in seed order)
-__global__ __launch_bounds__(XB_BOXES_MAX) void k_box_pick(int *fs, const int *__restrict__ seeds, const int *__restrict__ mxyz,
-                                                 const int *__restrict__ rcap, const int *__restrict__ bad, int stride,
-                                                 int *box_max, int *bx, int *br) {
-    __shared__ int best[XB_BOXES_MAX];
-    const int ns = fs[FS_N_SEEDS_EFF];
-    const int t = threadIdx.x;
-    if (t < ns) {
-        int b = 0;
-        for (int R = 1; R <= min(XB_BOX_K, rcap[t]); R++)
-            if (!bad[t * stride + R]) b = R;
-        best[t] = b;
-    }
-    __syncthreads();
-    if (t == 0) {
-        int n = 0;
-        for (int m = 0; m < ns; m++)
-            if (best[m] >= 1) {
-                box_max[n] = seeds[m];
-                bx[3 * n] = mxyz[3 * m]; bx[3 * n + 1] = mxyz[3 * m + 1]; bx[3 * n + 2] = mxyz[3 * m + 2];
-                br[n] = best[m];
-                n++;
-            }
-        fs[FS_N_BOXES] = n;
-        fs[FS_GROW_PHASE] = n ? 0 : 2;   // nothing to grow without a box
-        fs[FS_GROW_CONVERGED] = 0;
-    }
-}
-
-// k_brick_grow with the convergence logic on the device: every launch of the fixed schedule reads the phase
-// (0 propagate, 1 kill, 2 done: return at once); the block that finishes last advances the phase when the launch
-// changed nothing and flips the current buffer otherwise.  See k_brick_grow for the iteration itself.
+#define XB_BOXES_MAX 1024   // regions whose rank sits in the LDS table of the relabel kernels (the others are looked up)
+// Growing the trapping regions brick by brick (8x8x8 voxels).  Let U be a union of sets certain for maximum m.  A brick B
+// without a 26-neighbour maximum whose every possible move (any dr) from every voxel lands in B itself or in bricks that are
+// certain for the SAME m keeps U + B closed, and a trajectory cannot stay in B forever (it only ends on a maximum), so it must
+// enter U: B is certain for m as well.  Mutually dependent bricks are certified together by a greatest-fixpoint (kill)
+// iteration on provisional labels: a workgroup stages an 8^3 chunk of brick labels + a one-brick periodic halo in LDS and
+// iterates on it until nothing changes or `inner` rounds are done; the halo is what the previous launch left.  The schedule
+// does not matter for soundness: a provisional label is only a guess, and the kill iteration is monotone (stale neighbour
+// labels can only delay a kill), so its fixpoint -- reached when a whole launch changes nothing -- is the same greatest
+// fixpoint.  Convergence logic on the device: every launch of the fixed schedule reads the phase (0 propagate, 1 kill, 2 done:
+// return at once); the block that finishes last advances the phase when the launch changed nothing and flips the buffer.
 __global__ __launch_bounds__(BG * BG * BG) void k_brick_grow_dev(int nb0, int nb1, int nb2, const int *__restrict__ bmask,
                                                                  const int *__restrict__ seed, int *buf0, int *buf1, int *fs,
                                                                  int inner, int seeds_fixed) {
@@ -335,30 +255,6 @@ __global__ void k_seed_finish(int *fs) {
     fs[FS_GROW_PHASE] = n ? 0 : 2;   // nothing to grow without a seed
     fs[FS_GROW_CONVERGED] = 0;
 }
-__global__ void k_brick_seed_dev(GridL g, int nb0, int nb1, int nb2, const int *__restrict__ fs, const int *__restrict__ mxyz,
-                                 const int *__restrict__ radius, int *blab, int *blab2) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb0 * nb1 * nb2) return;
-    const int n_boxes = fs[FS_N_BOXES];
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int lab = 0;
-    for (int m = 0; m < n_boxes; m++) {
-        const int R = radius[m];
-        bool in = true;
-        const int n3[3] = {g.nx, g.ny, g.nz}, bb[3] = {b0, b1, b2};
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            int lo = bb[j] * BRK - mxyz[3 * m + j];
-            lo = ((lo % n3[j]) + n3[j]) % n3[j];
-            if (lo > n3[j] / 2) lo -= n3[j];
-            in &= (lo >= -R) && (lo + BRK - 1 <= R);
-        }
-        if (in) lab = m + 1;
-    }
-    blab[b] = lab;
-    blab2[b] = lab;   // first label buffer of the growth
-}
-
 // numbering on the device: maxima sorted by the smallest voxel index that reaches them (thread_handlers.py:59-65
 // numbers maxima in scan order); first[m] := rank.  One block, bitonic sort in LDS; more than XB_SORT_MAX maxima
 // (noisy data) leave FS_SORT_OK = 0 and the host sorts instead.

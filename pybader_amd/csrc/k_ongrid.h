@@ -27,37 +27,6 @@ __global__ __launch_bounds__(TPB) void k_og_jump(Grid g, int *labels, int *not_d
     labels[v] = q;
     if (q >= 0) *not_done = 1;
 }
-// With trapping regions (see k_table.h) only the voxels of the listed (uncertain) bricks chase their
-// pointers, and only until the chain enters a certain brick or reaches a root.  labels[] holds successor
-// indices on entry; a walker overwrites its own entry with the root it found -- also an ancestor, so a chain
-// that reads it mid-way still ends at the same root.  One wave per 4x4x4 eighth of a brick.
-__global__ __launch_bounds__(XB_WAVE) void k_og_walk(GridL g, const int *__restrict__ box_max, const int *__restrict__ blab,
-                                                     int nb1, int nb2, const int *__restrict__ walk, int n_walk, int *labels,
-                                                     int *first, int *max_list, int *max_count, int max_cap, int maxsteps,
-                                                     int *err) {
-    const int e = blockIdx.x >> 3, sub = blockIdx.x & 7, lane = threadIdx.x;
-    if (e >= n_walk) return;
-    const int b = walk[e];
-    const int x = (b / (nb1 * nb2)) * 8 + ((sub >> 2) << 2) + (lane >> 4);
-    const int y = ((b / nb2) % nb1) * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
-    const int z = (b % nb2) * 8 + ((sub & 1) << 2) + (lane & 3);
-    const int v = (x * g.ny + y) * g.nz + z;
-    int cur = v, p = labels[v], result = -1;
-    bool done = false;
-    for (int s = 0; s <= maxsteps && !done; s++) {
-        if (p < 0) { done = true; break; }       // vacuum (not reached here: regions are used without vacuum)
-        if (p == cur) { result = p; done = true; break; }     // a root
-        const int px = p / g.nyz, r = p - px * g.nyz;
-        const int bl = blab[((px >> 3) * nb1 + ((r / g.nz) >> 3)) * nb2 + ((r % g.nz) >> 3)];
-        if (bl > 0) { result = box_max[bl - 1]; done = true; break; }
-        cur = p;
-        p = labels[cur];
-    }
-    if (!done) atomicExch(err, 1);  // the pointer field is acyclic: cannot happen, reported loudly if it does
-    labels[v] = result;
-    note_maximum_wave(result >= 0, result, v, first, max_list, max_count, max_cap);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Round 4: the ongrid pass in the shape of k_brick_masks.  One sweep over the density gives every voxel its best-neighbour
 // pointer (methods.py:84-117: the first neighbour in (ix, iy, iz) order with the largest distance-weighted value, strict '>')
@@ -155,8 +124,11 @@ __global__ __launch_bounds__(TPB) void k_og_masks(GT g, const double *__restrict
         bpot[b] = s_pot[threadIdx.x];
     }
 }
-// the pointer chase of the walk-list bricks with the list length on the device: a fixed grid of one-wave workgroups strides
-// over the eighths of the listed bricks (see k_og_walk; PART: lanes beyond the grid stay idle)
+// With trapping regions only the voxels of the listed (uncertain) bricks chase their pointers, and only until the chain enters
+// a certain brick or reaches a root.  labels[] holds successor indices on entry; a walker overwrites its own entry with the
+// root it found -- also an ancestor, so a chain that reads it mid-way still ends at the same root.  The list length lives on
+// the device: a fixed grid of one-wave workgroups strides over the 4x4x4 eighths of the listed bricks (lanes beyond the grid,
+// in a brick the grid cuts, stay idle).
 __global__ __launch_bounds__(XB_WAVE) void k_og_walk_dev(GridL g, const int *__restrict__ box_max, const int *__restrict__ blab,
                                                          int nb1, int nb2, const int *__restrict__ walk, int *fs, int *labels,
                                                          int *first, int *max_list, int max_cap, int maxsteps) {

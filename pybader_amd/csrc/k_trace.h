@@ -49,67 +49,8 @@ __global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_
     note_maximum_wave(has, has ? box_max[l - 1] : 0, ((b0 * 8) * g.ny + b1 * 8) * g.nz + b2 * 8, first, max_list,
                       max_count, max_cap);
 }
-// labels := rank of the maximum; voxels of certain bricks take it from the brick label, the others
-// from the maximum index the trace left in `labels`
-__global__ __launch_bounds__(TPB) void k_relabel_regions(GridL g, int *labels, const int *__restrict__ rank,
-                                                         const int *__restrict__ blab, int nb1, int nb2,
-                                                         const int *__restrict__ box_max, const int *gate) {
-    const int v = g.x0 * g.nyz + blockIdx.x * TPB + threadIdx.x;
-    if (v >= g.x1 * g.nyz || (gate && !*gate)) return;
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
-    if (b > 0) labels[v] = rank[box_max[b - 1]];
-    else {
-        const int m = labels[v];
-        if (m >= 0) labels[v] = rank[m];
-    }
-}
-// the same, four z-consecutive voxels per thread (nz % 4 == 0: they share a brick): one 16-byte store
-__global__ __launch_bounds__(TPB) void k_relabel_regions4(GridL g, int *labels, const int *__restrict__ rank,
-                                                          const int *__restrict__ blab, int nb1, int nb2,
-                                                          const int *__restrict__ box_max, const int *gate) {
-    const long long v = (long long)g.x0 * g.nyz + 4LL * ((long long)blockIdx.x * TPB + threadIdx.x);
-    if (v >= (long long)g.x1 * g.nyz || (gate && !*gate)) return;
-    const int x = (int)(v / g.nyz);
-    const int r = (int)(v - (long long)x * g.nyz);
-    const int y = r / g.nz, z = r - y * g.nz;
-    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
-    int4 *p = reinterpret_cast<int4 *>(labels + v);
-    if (b > 0) {
-        const int l = rank[box_max[b - 1]];
-        *p = make_int4(l, l, l, l);
-    } else {
-        int4 m = *p;
-        if (m.x >= 0) m.x = rank[m.x];
-        if (m.y >= 0) m.y = rank[m.y];
-        if (m.z >= 0) m.z = rank[m.z];
-        if (m.w >= 0) m.w = rank[m.w];
-        *p = m;
-    }
-}
-// The same with a 3-D launch (x = blockIdx.z, 4 y-rows per block, threads along z/4): no divisions, 32-bit index math
-__global__ __launch_bounds__(TPB) void k_relabel_regions4_3d(GridL g, int *labels, const int *__restrict__ rank,
-                                                             const int *__restrict__ blab, int nb1, int nb2,
-                                                             const int *__restrict__ box_max, const int *gate) {
-    if (gate && !*gate) return;
-    const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), x = blockIdx.z;
-    if (z >= g.nz || y >= g.ny) return;
-    const int b = blab[((x >> 3) * nb1 + (y >> 3)) * nb2 + (z >> 3)];
-    int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + y) * g.nz + z));
-    if (b > 0) {
-        const int l = rank[box_max[b - 1]];
-        *p = make_int4(l, l, l, l);
-    } else {
-        int4 m = *p;
-        if (m.x >= 0) m.x = rank[m.x];
-        if (m.y >= 0) m.y = rank[m.y];
-        if (m.z >= 0) m.z = rank[m.z];
-        if (m.w >= 0) m.w = rank[m.w];
-        *p = m;
-    }
-}
+// labels := rank of the maximum; voxels of certain bricks take it from the brick label, the others from the maximum index the
+// trace left in `labels`.
 // Brick-shaped version: a thread owns the 8 y-rows of one brick at one (x, z/4): ONE brick-label lookup (through a
 // per-block LDS table of the region ranks) for 8 16-byte stores; a block covers 4 x-planes x 256 voxels of z.
 __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *labels, const int *__restrict__ rank,
@@ -155,10 +96,10 @@ __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *lab
 __global__ __launch_bounds__(TPB) void k_relabel_regions_brick1(GridL g, int *labels, const int *__restrict__ rank,
                                                                 const int *__restrict__ blab, int nb1, int nb2,
                                                                 const int *__restrict__ box_max, const int *__restrict__ fs,
-                                                                const int *gate) {
+                                                                const int *gate, int n_boxes = -1) {
     __shared__ int s_rank[XB_BOXES_MAX];
     if (gate && !*gate) return;
-    for (int i = threadIdx.x; i < min(fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
+    for (int i = threadIdx.x; i < min(n_boxes >= 0 ? n_boxes : fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
     __syncthreads();
     const int z = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y, x = g.x0 + blockIdx.z * 4 + (threadIdx.x >> 6);
     if (z >= g.nz || x >= g.x1) return;
@@ -522,47 +463,12 @@ __global__ __launch_bounds__(TPB) void k_ng_trace_list(GridL g, const GradRec *_
                               ovf_list, ovf_count, ovf_cap, maxsteps, rho, gc, has_vacuum != 0);
     }
 }
-// Persistent form (single GPU, device-side control flow, k_fused.h): a fixed grid of one-wave workgroups pulls
-// 4x4x4 eighths of the walk-list bricks until none is left; the list length stays on the device.  One cursor per
-// XCD (each XCD takes the k-th contiguous eighth of the list first -- spatial neighbours read the same table
-// lines, one L2 each -- and helps the others afterwards).
+// (the XCD a workgroup runs on: each XCD takes the k-th contiguous eighth of the walk list first -- spatial neighbours read
+// the same table lines, one L2 each -- and helps the others afterwards)
 __device__ __forceinline__ int xcc_id() {
     int x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     return x & 7;
-}
-template <int K, int LEAN>   // LEAN: 0 ng_walk_wave, 1 ng_walk_lean, 2 ng_walk_lean with 32-bit table offsets
-__global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
-                                                        const int *__restrict__ blab, int nb1, int nb2,
-                                                        const int *__restrict__ walk, int *fs, int *labels, int *first,
-                                                        int *max_list, int max_cap, int *ovf_list, int ovf_cap, int maxsteps,
-                                                        int has_vacuum, int CH, int xcd_split) {
-    const int n_items = fs[FS_N_WALK] * 8;
-    const int per = (n_items + 7) >> 3;
-    const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
-    const int lane = threadIdx.x;
-    // CH items per pull (16 = two bricks: one device-scope atomic per 1024 start voxels)
-    for (int r = 0; r < 8; r++) {
-        const int q = (home + r) & 7;
-        const int beg = q * per, end = min(beg + per, n_items);
-        for (;;) {
-            int base = 0;
-            if (lane == 0) base = beg + atomicAdd(&fs[FS_CURSOR0 + q * FS_CURSOR_STRIDE], CH);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= end) break;
-            const int stop = min(base + CH, end);
-            for (int item = base; item < stop; item++) {
-                int sx, sy, sz;
-                brick_sub_voxel(walk[item >> 3], item & 7, lane, nb1, nb2, sx, sy, sz);
-                if (LEAN)
-                    ng_walk_lean<LEAN == 2, false>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX], max_cap, ovf_list,
-                                                   &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
-                else
-                    ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
-                                           max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
-            }
-        }
-    }
 }
 
 // Group form of the persistent trace: a workgroup of W waves pulls CH consecutive items (CH / 8 whole bricks of the Morton
@@ -571,8 +477,10 @@ __global__ __launch_bounds__(XB_WAVE) void k_ng_trace_p(GridL g, const GradRec *
 // loads meet in that unit's L1 (hit, or merged with the miss in flight) instead of each occupying a miss slot of a
 // different unit.  The trace is bound by exactly that: L2 requests x L2 latency / misses in flight per compute unit
 // (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
-// LEAN 3 / 4 (= 1 / 2 with the brick cache): the workgroup is exactly eight waves, a pull is exactly one brick, and its 512
-// records are copied into LDS (16 KB) before the waves start (see ng_walk_lean).
+// LEAN 0: the generic walker ng_walk_wave (tests every start voxel, box ids in the keys, table windows); LEAN 3 / 4: the lean
+// walker (4: 32-bit table offsets) -- the workgroup is exactly eight waves, a pull is exactly one brick, and its 512 records are
+// copied into LDS (16 KB) before the waves start (see ng_walk_lean).  (LEAN 1 / 2, the lean walker without the cache, and the
+// one-wave form k_ng_trace_p were measured against these in round 3 and removed in round 4.)
 template <int K, int LEAN, bool WINDOW = false, bool PART = false>
 __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                        const int *__restrict__ blab, int nb1, int nb2,

@@ -151,22 +151,17 @@ def test_768_eight_slabs_equal_one_gpu():
 
 @pytest.mark.parametrize('size,lattice', [(256, synth.CUBIC6), (192, synth.TRICLINIC), (512, synth.CUBIC6)])
 def test_trapping_regions_do_not_change_the_map(size, lattice):
-    """The trapping-region early exit (closed cubes + brick growth) is exact by construction; check it
-    anyway against the plain full-trajectory trace at sizes the CPU oracle cannot reach."""
+    """The trapping-region early exit (brick masks + growth) is exact by construction; check it anyway against the plain
+    full-trajectory trace (option 1 = 0: records for every voxel, no regions) at sizes the CPU oracle cannot reach."""
     ctx = _lib.Context(0)
     shape = (size,) * 3
     ctx.set_option(1, 0)                      # plain tracing
     n0, max0, lab0 = run(ctx, shape, lattice)
     assert ctx.box_stats() == (0, 0)
-    ctx.set_option(1, 1)                      # closed cubes only
-    n1, max1, lab1 = run(ctx, shape, lattice)
-    nb, nv1 = ctx.box_stats()
-    assert nb == n1 and nv1 > 0.05 * size ** 3
-    assert n0 == n1 and np.array_equal(max0, max1) and np.array_equal(lab0, lab1)
-    ctx.set_option(1, 3)                      # cubes + brick growth (the default)
+    ctx.set_option(1, 3)                      # trapping regions (the default)
     n2, max2, lab2 = run(ctx, shape, lattice)
     nb, nv2 = ctx.box_stats()
-    assert nv2 > nv1
+    assert nb == n2 and nv2 > 0.4 * size ** 3
     assert n0 == n2 and np.array_equal(max0, max2) and np.array_equal(lab0, lab2)
     ctx.close()
 
@@ -244,17 +239,16 @@ def test_many_atoms_keep_their_trapping_regions():
 
 @pytest.mark.parametrize('method', ['neargrid', 'ongrid'])
 def test_vacuum_at_scale_sparse_table_equals_full_table(method):
-    """256^3 with half of the cell declared vacuum: the sparse-table pipeline (brick masks, records for the walk-list /
-    mixed bricks only, deferred from-rho retraces -- no region stop with vacuum) against the round-1 route that writes a
-    record for every voxel, and against plain full-trajectory tracing; maps, maxima and refinement logs must agree."""
+    """256^3 with half of the cell declared vacuum: the pipeline (brick masks, records for the walk-list / mixed bricks
+    only, deferred from-rho retraces -- no region stop with vacuum) against plain full-trajectory tracing over a record for
+    every voxel (option 1 = 0); maps, maxima and refinement logs must agree."""
     shape = (256,) * 3
     dm, tg = matrices(shape, synth.CUBIC6)
     ctx = _lib.Context(0)
     ctx.set_grid(shape, dm, tg)
     ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
     res = []
-    for sparse, boxes in ((1, 3), (0, 3), (0, 0)):
-        ctx.set_option(12, sparse)
+    for boxes in (3, 0):
         ctx.set_option(1, boxes)
         ctx.set_option(6, 1)
         vc, vv = ctx.vacuum_assign(0.03, 1.0)
@@ -405,15 +399,15 @@ def test_brick_uniformity_left_by_the_walkers_equals_the_label_scan():
     """The group trace leaves, per walk-list brick, the one maximum all its 512 voxels ended on (LDS min / max of the
     walkers' results), which replaces k_label_uniform_list's pass over the labels for the edge sweep.  Checked where it
     shows: the edge sweep's flags -- `known` after the first refinement iteration must equal the flags of a run whose
-    uniformity came from the label scan (the one-wave trace kernel, option 15 = 1, keeps the scan)."""
+    uniformity came from the label scan (the generic walker, option 14 = 0, keeps the scan)."""
     shape = (192, 192, 192)
     ctx = _lib.Context(0)
     dm, tg = matrices(shape, synth.TRICLINIC)
     ctx.set_grid(shape, dm, tg)
     ctx.synth_density(synth.TRICLINIC, synth.ATOMS8, synth.BACKGROUND)
     res = []
-    for group in (8, 1):
-        ctx.set_option(15, group)
+    for lean in (1, 0):
+        ctx.set_option(14, lean)
         ctx.set_option(6, 1)
         ctx.vacuum_assign(None, 1.0)
         n = ctx.assign('neargrid')
