@@ -88,6 +88,7 @@ struct xb_ctx {
     int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
     std::vector<int64_t> esc_starts, esc_offsets, esc_vox;  // xb_escaped_paths -> xb_escaped_paths_fetch
     unsigned long long *ec_pend = nullptr;  // edge_check's counter word per voxel (8 N bytes, allocated on first use)
+    int8_t *ec_pflag = nullptr;             // ... and a flag byte per voxel, set on the processed voxels while their boxes are applied (zero otherwise)
     std::vector<int8_t> esc_complete;
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
@@ -171,6 +172,7 @@ struct xb_ctx {
                                // volume_assign (the largest atom index); planes or voxels written from outside make it 4
     std::vector<int> local_max, local_first;
     bool first_clean = false;
+    int chg_n = -1;            // >= 0: the upper half of `stage` lists the chg_n voxels the last retrace pass relabelled (all known == -2 voxels)
     int list_n = 0;            // entries of `list` that hold the owned known == -2 voxels ...
     bool list_valid = false;   // ... when this is set (by xb_edge_find)
     bool timing = false;

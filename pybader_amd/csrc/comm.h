@@ -165,7 +165,7 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
     };
     for (int i = 0; i < n_send; i++) if (bad(send_peer[i], send_xa[i], send_xb[i])) return fail(XB_E_ARG, "xb_comm_exchange_planes: bad send %d", i);
     for (int i = 0; i < n_recv; i++) if (bad(recv_peer[i], recv_xa[i], recv_xb[i])) return fail(XB_E_ARG, "xb_comm_exchange_planes: bad recv %d", i);
-    if (n_recv) { c->list_valid = false; c->buni_valid = c->buni_valid && c->buni_halo_safe; }   // halo planes of peers that ran the same assignment
+    if (n_recv) { c->list_valid = false; c->chg_n = -1; c->buni_valid = c->buni_valid && c->buni_halo_safe; }   // halo planes of peers that ran the same assignment
     // Label planes travel in the narrowest signed type that holds every label (the reference's own dtype_calc(-n_maxima),
     // thread_handlers.py:70-74: int8 for every BASELINE configuration -- a quarter of the int32 bytes per halo): packed into
     // the staging buffer before the group, widened back behind it, all on the context's stream.

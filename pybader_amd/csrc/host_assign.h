@@ -370,7 +370,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     c->first_clean = false;
     c->regions_pending = false;
     c->buni_valid = false; c->regions_labels = false;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     g.main_ties = 1;   // methods.neargrid's tie test (methods.py:324)
     const GridL gl = light(g);
     (void)gl0;
@@ -572,7 +572,7 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     c->first_clean = false;
     c->regions_pending = false;
     c->buni_valid = false; c->regions_labels = false;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     c->zero_outside[0] = -1;
     const GridL gl = light(g);
     {

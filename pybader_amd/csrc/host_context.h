@@ -33,7 +33,7 @@ int xb_create(int device, xb_ctx **out) {
 
 static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
-    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->ec_pflag); c->ec_pflag = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->labels_zero_pending = false;
     hipFree(c->ec_buf); c->ec_buf = nullptr; c->ec_buf_cap = 0; c->grad_cap = 0; c->list_cap = 0;
     c->brick_rec = nullptr; c->grad_cover = 0;
@@ -83,7 +83,7 @@ static int need_scratch(xb_ctx *c) {
         hipFree(c->list); c->list = nullptr; c->list_cap = 0;
         HIPCHK(hipMalloc(&c->list, (size_t)list_want * sizeof(int)));
         c->list_cap = list_want;
-        c->list_valid = false; c->walk = nullptr; c->n_walk = 0;
+        c->list_valid = false; c->chg_n = -1; c->walk = nullptr; c->n_walk = 0;
     }
     if (c->stage_bytes < stage_want) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -410,7 +410,7 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     NEED_GRID_RAW("xb_upload_labels");
     c->labels_zero_pending = false;   // every label is overwritten
     c->zero_outside[0] = -1;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     c->has_vacuum = true;
     c->buni_valid = false; c->regions_labels = false;
     const size_t sz = dtype_size(dtype);
@@ -461,7 +461,7 @@ int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {
 }
 int xb_upload_known(xb_ctx *c, const int8_t *known_host) {
     NEED_GRID("xb_upload_known");
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     HIPCHK(hipMemcpyAsync(c->known, known_host, c->N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;

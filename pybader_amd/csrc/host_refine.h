@@ -145,7 +145,7 @@ int xb_escaped_paths(xb_ctx *c, int64_t max_len, int64_t *n_paths, int64_t *n_vo
     c->g.main_ties = 0;   // retraces follow refinement.py's rule
     int n = 0;
     if (int rc = compact(c, -6, &n)) return rc;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     if (n) {
         if (max_len < 2 || max_len > (1 << 15)) return fail(XB_E_ARG, "xb_escaped_paths: max_len out of range");
         const int lmax = (int)max_len, chunk = (int)std::max<int64_t>(256, std::min<int64_t>(8192, (32LL << 20) / max_len));
@@ -224,7 +224,7 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         if (e == hipSuccess) e = hipMemcpyAsync(dlab, lab, n * sizeof(int), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dkn, kn, n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) k_scatter_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, dlab, dkn, c->labels, c->known);
-        c->list_valid = false;
+        c->list_valid = false; c->chg_n = -1;
         c->buni_valid = false; c->regions_labels = false;
         c->zero_outside[0] = -1;
         c->label_wire = 4;
@@ -254,7 +254,7 @@ static int refine_trace_impl(xb_ctx *c, int flag, int64_t *changed, int64_t *esc
     int n = 0;
     if (c->list_valid && flag == -2) n = c->list_n;
     else if (int rc = compact(c, flag, &n)) return rc;
-    c->list_valid = false;  // the retrace rewrites known
+    c->list_valid = false; c->chg_n = -1;  // the retrace rewrites known
     c->buni_valid = false;  // ... and may relabel edge voxels; st is also edge_check's scratch
     c->walk_n_out = 0; c->walk_n_res = 0; c->walk_out_dev = nullptr;
     c->walk_host.clear(); c->res_host.clear();
@@ -421,7 +421,7 @@ int xb_walkers_apply(xb_ctx *c, const int64_t *results, int64_t n, int64_t *chan
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 18, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->list_valid = false; c->buni_valid = false;
+    c->list_valid = false; c->chg_n = -1; c->buni_valid = false;
     if (changed) *changed = c->host_ints[0];
     if (stuck) *stuck = c->host_ints[1];
     return XB_OK;
@@ -457,6 +457,10 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
             buf[0] = c->ec_buf; buf[1] = c->ec_buf + cap;
         }
         if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 8 * (size_t)c->N + 16));
+        if (!c->ec_pflag) {
+            HIPCHK(hipMalloc(&c->ec_pflag, (size_t)c->N + 16));
+            HIPCHK(hipMemsetAsync(c->ec_pflag, 0, (size_t)c->N + 16, c->stream));
+        }
         ec_word *pend_w = c->ec_pend;
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
         if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, pend_w);
@@ -490,8 +494,10 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     const int new_cap = (int)std::min<long long>(c->list_cap - n, 1LL << 30);   // the rest of `list` behind the compacted edges
     HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
-    k_ec_apply<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st, c->counters64 + 1,
-                                                  c->list + n, c->counters + 7, new_cap);
+    k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)1);
+    k_ec_apply<<<(unsigned)std::min<long long>(nblocks(27LL * n), 4096), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st,
+                                                  c->counters64 + 1, c->list + n, c->counters + 7, new_cap, c->ec_pflag);
+    k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)0);   // (the flags are zero again)
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
     {   // -1 ring around the new edges (-3): from their list, or by a full-grid sweep if the list did not fit
         int n_new = 0;
@@ -499,12 +505,18 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
         if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
         else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new, nullptr);
     }
+    // (the sweep also lists the voxels flagged -2 afterwards, the retrace list of the next pass, into `list` itself: its
+    // compacted entries and the new-edge list behind them have served)
+    HIPCHK(hipMemsetAsync(c->counters + 26, 0, sizeof(int), c->stream));
+    const int fin_cap = (int)std::min<long long>(c->list_cap, 1LL << 30);
     k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64,
-                                                                                                      count_lo, count_hi);
+                                                                                                      count_lo, count_hi, c->list, c->counters + 26, fin_cap);
     HIPCHK(hipGetLastError());
     unsigned long long r[2];
     HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 26, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->host_ints[0] <= fin_cap) { c->list_n = c->host_ints[0]; c->list_valid = true; }   // (else: the next pass compacts the flags itself)
     if (edges) *edges = (int64_t)r[0];
     if (checked) *checked = (int64_t)(r[1] + r[0]);  // refinement.py:479 + 504
     return XB_OK;
@@ -513,12 +525,16 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     NEED_GRID("xb_edge_check");
     const Grid &g = c->g;
-    c->list_valid = false;
+    const int chg_n = c->chg_n;   // (read before the invalidations below)
+    c->list_valid = false; c->chg_n = -1;
     c->buni_valid = false;
     if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: one slab only; slabs use xb_edge_check_local + xb_edge_check_global");
     if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
     int n = 0;
-    if (int rc = compact(c, -2, &n)) return rc;
+    if (chg_n >= 0) {   // the last retrace pass listed its relabelled voxels: exactly the known == -2 ones
+        n = chg_n;
+        if (n) HIPCHK(hipMemcpyAsync(c->list, (int *)c->stage + c->N, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    } else if (int rc = compact(c, -2, &n)) return rc;
     return edge_check_resolve(c, n, nullptr, 0, g.nx, 0, c->N, checked, edges);
 }
 
@@ -532,7 +548,7 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
 // (xb_edge_check_global).  Needs label AND known halos refreshed beforehand.
 int xb_edge_check_local(xb_ctx *c, int64_t *n_out) {
     NEED_GRID("xb_edge_check_local");
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     int n = 0;
     if (int rc = compact(c, -2, &n)) return rc;   // owned planes only
     if (n) {
@@ -557,7 +573,7 @@ int xb_edge_check_local_fetch(xb_ctx *c, int64_t *idx_out, int8_t *cls_out) {
 int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64_t n, int64_t *checked, int64_t *edges) {
     NEED_GRID("xb_edge_check_global");
     const Grid &g = c->g;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     c->buni_valid = false;
     if (checked) *checked = 0;
     if (edges) *edges = 0;
@@ -606,8 +622,9 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
     int *fs = c->fs;
     c->g.main_ties = 0;
     const GridL gl = light(g);
-    static_assert(FS_N_TILES == FS_N_EDGES + 5, "one memset clears the refinement's counters");
-    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 6 * sizeof(int), c->stream));   // edges, changed, escaped, overflows, deferred, listed tiles
+    static_assert(FS_N_CHGLIST == FS_N_EDGES + 6, "one memset clears the refinement's counters");
+    HIPCHK(hipMemsetAsync(fs + FS_N_EDGES, 0, 7 * sizeof(int), c->stream));   // edges, changed, escaped, overflows, deferred, listed tiles, relabelled list
+    c->chg_n = -1;
     {
         ScopedTimer t(c, 2);
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
@@ -639,7 +656,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         if (buni && c->opt_tile_dilate && g.nz % ET_Z == 0) k_edge_dilate_tiles<<<std::min(ntiles_listed, 4096), TPB, 0, c->stream>>>(gl, c->known, (const int *)c->stage, fs + FS_N_TILES);
         else k_edge_dilate_list<<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->known, c->list, 0, fs + FS_N_EDGES);
     }
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     c->buni_valid = false;
     {
         ScopedTimer t(c, 3);
@@ -647,21 +664,29 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
         const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
         const int regions_ok = c->grad_cover == 1 && c->regions_labels && !c->has_vacuum ? 1 : 0;
         int *defer = (int *)c->stage;
+        WalkerIO wl{};   // (no walkers on one GPU)
         k_refine_trace<2, false><<<nblocks(c->N / 16), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, fs + FS_N_EDGES,
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, defer, fs + FS_R_DEFER,
-                                                              regions_ok, nullptr, WalkerIO{});
+                                                              regions_ok, nullptr, wl);
         if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
             k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
                                                                fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
-                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, WalkerIO{});
+                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, wl);
+        // the relabelled start voxels (known == -2 now), listed for the next edge_check in the upper half of `stage`
+        if (c->stage_bytes >= 8 * (size_t)c->N)
+            k_list_changed<<<1024, TPB, 0, c->stream>>>(c->list, fs + FS_N_EDGES, c->known, (int *)c->stage + c->N, fs + FS_N_CHGLIST,
+                                                        (int)std::min<long long>(c->N, 1LL << 30));
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 7 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *edges = c->host_ints[0];
     *changed = c->host_ints[1];
     const int novf = c->host_ints[3];
+    // the relabelled start voxels are listed (complete: nothing went to the exact slow kernel, the list did not overflow)
+    if (novf == 0 && c->host_ints[6] == c->host_ints[1] && c->stage_bytes >= 8 * (size_t)c->N && c->host_ints[1] <= (int)std::min<long long>(c->N, 1LL << 30))
+        c->chg_n = c->host_ints[1];
     c->stat_deferred += c->host_ints[4];
     if (c->host_ints[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", c->host_ints[2]);
     if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);

@@ -172,7 +172,7 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
     // (a slab's halo planes come from peers that ran the same assignment: the regions' labels stay what they are)
     if (to_device && which == 0) { c->zero_outside[0] = -1; c->label_wire = 4; }   // (planes from outside: any label may arrive)
-    if (to_device) { c->list_valid = false; c->has_vacuum = c->has_vacuum || c->g.x1 - c->g.x0 == c->g.nx;
+    if (to_device) { c->list_valid = false; c->chg_n = -1; c->has_vacuum = c->has_vacuum || c->g.x1 - c->g.x0 == c->g.nx;
                      c->buni_valid = c->buni_valid && c->buni_halo_safe && c->g.x1 - c->g.x0 < c->g.nx;
                      if (c->g.x1 - c->g.x0 == c->g.nx) c->regions_labels = false; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));

@@ -592,6 +592,22 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
     }
 }
 
+// The retraces leave known == -2 on exactly the start voxels they relabelled, all of them entries of the edge list: the list of
+// the next edge_check is a pass over that list (round 4) instead of a sweep of the whole grid for the flag and a host wait.
+__global__ __launch_bounds__(TPB) void k_list_changed(const int *__restrict__ list, const int *n_dev, const int8_t *__restrict__ known,
+                                                      int *__restrict__ out, int *out_count, int out_cap) {
+    __shared__ int s_buf[BlockAppender<1>::CAP], s_n[2];
+    BlockAppender<1> app;
+    app.init(s_buf, s_n, out, out_count, out_cap);
+    const int n = *n_dev;
+    for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // (uniform per block)
+        const int t = base + threadIdx.x;
+        const int v = t < n ? list[t] : 0;
+        const bool hit = t < n && known[v] == -2;
+        app.add(hit ? 1 : 0, [&](int) { return v; });
+    }
+    app.finish();
+}
 // compaction of owned voxels with known == value, 16 voxels per thread, one atomic per block
 #define CK_CHUNKS 4   // 16-voxel chunks per thread: all loads of a thread in flight, one scan + one atomic per 16 K voxels
 __global__ __launch_bounds__(TPB) void k_compact_known16(GridL g, const int8_t *__restrict__ known, int value,
@@ -1203,56 +1219,68 @@ __global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__rest
     st[t] = (k == EC_PROC) ? 1 : 2;
     if (k == -2) atomicAdd(undecided, 1);
 }
-// apply: every processed voxel re-classifies its 27-box (refinement.py:428-504)
+// apply: every processed voxel re-classifies its 27-box (refinement.py:428-504).
+// Round 4: every box voxel is classified ONCE.  The boxes of neighbouring processed voxels overlap ninefold on a dividing
+// surface, and round 3 classified every (processed voxel, box position) pair: 729 label loads per processed voxel, 0.79 ms
+// and 2.4 GB of fetches at 512^3.  Now the processed voxels carry a flag byte in an array of their own (`pflag`, indexed by
+// voxel, zero everywhere else: k_ec_mark sets and clears it); for a box voxel u a thread reads the 27 flags around u (nine
+// 3-byte rows), and only the processed voxel with the SMALLEST index among them classifies u -- no atomics, no duplicates.
+// The same 27 flags give `checked` the multiplicity the sequential scan gives it: a non-edge voxel is "checked" once per
+// processed voxel whose box holds it (refinement.py:477-479).  (Tried first: claiming box voxels with atomicOr on a bitmap --
+// 27 scattered atomics per processed voxel cost more than the loads they saved, 0.86 ms.)
+__global__ void k_ec_mark(const int *__restrict__ list, int n, const int8_t *__restrict__ st, int8_t *__restrict__ pflag, int8_t value) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || st[t] != 1) return;
+    pflag[list[t]] = value;
+}
+// (a thread per (listed voxel, box position) pair, a fixed grid striding over the pairs: the 27 positions of a box are
+// independent, and walked one after the other by one thread they were 27 serial memory latencies)
 __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
                                                   const int *__restrict__ labels, int8_t *known,
                                                   const int *__restrict__ list, int n, const int8_t *st,
-                                                  unsigned long long *checked, int *new_edges, int *n_new, int new_cap) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    const bool act = t < n && st[t] == 1;
-    const int v = act ? list[t] : 0;
-    const int x = v / g.nyz;
-    const int r = v - x * g.nyz;
-    const int y = r / g.nz, z = r - y * g.nz;
-    unsigned int nchk = 0, m3 = 0;  // m3: box positions this thread turned into new edges (-3)
-    for (int ex = -1; ex < 2 && act; ex++) {
-        const int tx = wrapi(x + ex, g.nx);
-        for (int ey = -1; ey < 2; ey++) {
-            const int ty = wrapi(y + ey, g.ny);
-            for (int ez = -1; ez < 2; ez++) {
-                const int tz = wrapi(z + ez, g.nz);
-                const int l = lin3(g, tx, ty, tz);
+                                                  unsigned long long *checked, int *new_edges, int *n_new, int new_cap,
+                                                  const int8_t *__restrict__ pflag) {
+    __shared__ int s_buf[BlockAppender<1>::CAP], s_n[2];
+    BlockAppender<1> app;
+    app.init(s_buf, s_n, new_edges, n_new, new_cap);
+    unsigned int nchk = 0;
+    const long long pairs = 27LL * n;
+    for (long long base = (long long)blockIdx.x * TPB; base < pairs; base += (long long)gridDim.x * TPB) {   // (uniform per block)
+        const long long p = base + threadIdx.x;
+        const int t = (int)(p / 27), j = (int)(p - 27LL * t);
+        const bool act = p < pairs && st[t] == 1;
+        int new_edge = -1;
+        if (act) {
+            const int v = list[t];
+            const int x = v / g.nyz;
+            const int r = v - x * g.nyz;
+            const int y = r / g.nz, z = r - y * g.nz;
+            const int tx = wrapi(x + j / 9 - 1, g.nx), ty = wrapi(y + (j / 3) % 3 - 1, g.ny), tz = wrapi(z + j % 3 - 1, g.nz);
+            const int l = lin3(g, tx, ty, tz);
+            // the processed voxels in l's own 27-box: how many, and is v the first of them (in C order)?
+            int rows[9];
+            unsigned int w[9];
+            ec_box(g, pflag, tx, ty, tz, rows, w);
+            unsigned cnt = 0;
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                const bool pk = ((w[k / 3] >> (8 * (k % 3))) & 0xffu) != 0;
+                cnt += pk;
+                first &= !(pk && ec_box_voxel(g, rows, tz, k) < v);
+            }
+            if (first) {
                 // NB no vacuum test on the box voxel (bug-compatible)
                 bool is_edge, is_max;
                 classify27(g, rho, labels, tx, ty, tz, l, is_edge, is_max);
-                if (!is_edge) { known[l] = -1; nchk++; }
-                else if (!is_max) { known[l] = -3; m3 |= 1u << ((ex + 1) * 9 + (ey + 1) * 3 + ez + 1); }
+                if (!is_edge) { known[l] = -1; nchk += cnt; }
+                else if (!is_max) { known[l] = -3; new_edge = l; }
             }
         }
+        app.add(new_edge >= 0 ? 1 : 0, [&](int) { return new_edge; });   // the new edges, for the -1 ring around them
     }
-    // the new edges go to a list (with duplicates: boxes overlap) for the -1 ring around them: one atomic per wave
-    {
-        const int lane = threadIdx.x % XB_WAVE;
-        const int cnt = __popc(m3);
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < XB_WAVE; o <<= 1) {
-            const int u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
-        }
-        const int total = __shfl(incl, XB_WAVE - 1);
-        int base = 0;
-        if (lane == XB_WAVE - 1 && total) base = atomicAdd(n_new, total);
-        base = __shfl(base, XB_WAVE - 1);
-        int at = base + incl - cnt;
-        for (unsigned int m = m3; m; m &= m - 1) {
-            const int j = __ffs(m) - 1;
-            if (at < new_cap)
-                new_edges[at] = lin3(g, wrapi(x + j / 9 - 1, g.nx), wrapi(y + (j / 3) % 3 - 1, g.ny), wrapi(z + j % 3 - 1, g.nz));
-            at++;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) nchk += __shfl_down(nchk, o);  // one atomic per wave (lanes that returned early hold 0)
+    app.finish();
+    for (int o = 32; o > 0; o >>= 1) nchk += __shfl_down(nchk, o);  // one atomic per wave of the (fixed) grid
     if (threadIdx.x % XB_WAVE == 0 && nchk) atomicAdd(checked, (unsigned long long)nchk);
 }
 // restore processed edge&max voxels (untouched by their own box) to -2
@@ -1264,26 +1292,46 @@ __global__ void k_ec_restore(int8_t *known, const int *list, int n) {
 }
 // count -3 and turn them into -2 (refinement.py:505-507); 16 voxels per thread and step, one atomic per block
 // (count_lo, count_hi): only the -3 voxels with a linear index in that range are counted (a slab counts its own planes)
+// Round 4: the sweep reads every flag anyway, so it also LISTS the voxels that are -2 afterwards (new edges and the restored
+// edge&maximum voxels) in that range -- the retrace list of the next refinement pass, which round 3 compacted out of the flags
+// with another sweep and another host wait.  (list_out null: no list; more entries than list_cap: the count says so.)
 __global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, unsigned long long *edges, long long count_lo,
-                                                   long long count_hi) {
+                                                   long long count_hi, int *list_out, int *list_count, int list_cap) {
     __shared__ unsigned int s_cnt;
+    __shared__ int s_buf[BlockAppender<16>::CAP], s_n[2];
+    BlockAppender<16> app;
+    app.init(s_buf, s_n, list_out, list_count, list_cap);
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     unsigned int cnt = 0;
-    for (long long base = ((long long)blockIdx.x * TPB + threadIdx.x) * 16; base < N; base += (long long)gridDim.x * TPB * 16) {
+    const long long stride = (long long)gridDim.x * TPB * 16;
+    for (long long base0 = (long long)blockIdx.x * TPB * 16; base0 < N; base0 += stride) {   // (uniform per block)
+        const long long base = base0 + (long long)threadIdx.x * 16;
+        unsigned hits = 0;   // bit k: voxel base + k is -2 now and inside the range
         if (base + 16 <= N) {
             uint4 w = *reinterpret_cast<const uint4 *>(known + base);
             int8_t *b = reinterpret_cast<int8_t *>(&w);
             unsigned int c = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (b[k] == -3) { b[k] = -2; c++; cnt += (base + k >= count_lo) & (base + k < count_hi); }
+            for (int k = 0; k < 16; k++) {
+                const bool in = (base + k >= count_lo) & (base + k < count_hi);
+                if (b[k] == -3) { b[k] = -2; c++; cnt += in; }
+                hits |= (unsigned)((b[k] == -2) & in) << k;
+            }
             if (c) *reinterpret_cast<uint4 *>(known + base) = w;
-        } else {
-            for (long long k = base; k < N; k++)
-                if (known[k] == -3) { known[k] = -2; cnt += (k >= count_lo && k < count_hi); }
+        } else if (base < N) {
+            for (long long k = base; k < N; k++) {
+                const bool in = k >= count_lo && k < count_hi;
+                if (known[k] == -3) { known[k] = -2; cnt += in; }
+                hits |= (unsigned)((known[k] == -2) & in) << (int)(k - base);
+            }
+        }
+        if (list_out) {
+            unsigned m = hits;
+            app.add(__popc(hits), [&](int) { const int k = __ffs(m) - 1; m &= m - 1; return (int)(base + k); });
         }
     }
+    if (list_out) app.finish();
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if (threadIdx.x % XB_WAVE == 0 && cnt) atomicAdd(&s_cnt, cnt);
     __syncthreads();

@@ -30,6 +30,7 @@ enum {
     FS_CHANGED, FS_ESCAPED, FS_R_OVF,
     FS_R_DEFER,          // refinement: retraces handed to the from-rho kernel (their walk goes on through a brick without records)
     FS_N_TILES,          // refinement: tiles of the edge sweep that are not of one label with their surroundings
+    FS_N_CHGLIST,        // refinement: start voxels the retraces relabelled, as listed for the next edge_check
     FS_GROW_RETRY,       // the scheduled kill launches did not reach the fixpoint: the host repeats the assignment with the long schedule
     FS_N_RECL,           // slabs: bricks of the table window that get records (the walk list holds the owned ones among them)
     FS_N_REDO,           // slabs: trajectories that left the table window and were redone from rho (statistics)

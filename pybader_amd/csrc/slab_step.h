@@ -309,7 +309,7 @@ int xb_slab_assign_trace(xb_ctx *c) {
     c->first_clean = false;
     c->regions_pending = false;
     c->buni_valid = false; c->regions_labels = false;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     const bool chase = c->opt_chase != 0;
     {
         ScopedTimer t4(c, 4);
@@ -471,7 +471,7 @@ int xb_slab_refine_pass(xb_ctx *c) {
         k_edge_dilate_list<<<2048, TPB, 0, c->stream>>>(gl, c->known, c->list, 0, c->counters + 5);
     }
     c->g.main_ties = 0;
-    c->list_valid = false;
+    c->list_valid = false; c->chg_n = -1;
     c->buni_valid = false;
     c->walk_n_out = 0; c->walk_n_res = 0; c->walk_out_dev = nullptr;
     c->walk_host.clear(); c->res_host.clear();
@@ -544,7 +544,7 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last) {
         c->walk_last = src;
     }
     HIPCHK(hipGetLastError());
-    c->list_valid = false; c->buni_valid = false;
+    c->list_valid = false; c->chg_n = -1; c->buni_valid = false;
     return XB_OK;
 }
 
