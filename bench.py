@@ -530,6 +530,12 @@ def main():
     if phase_ms is not None:
         out['config']['slab_phase_ms_avg'] = phase_ms
         out['config']['halo_bytes_sent_per_step'] = ctx.comm_bytes_sent() / (args.warmup + args.steps + 2) if comm.transport == 'rccl' else None
+        # what every rank's RCCL communicator says about itself (ranks, rank, device, library version): the first run on a
+        # real node proves with this that it saw N ranks on N devices
+        info = ctx.comm_info() if comm.transport == 'rccl' else {'nccl_comm_count': -1, 'nccl_user_rank': rank, 'nccl_device': dev_index, 'rccl_version': -1}
+        infos = comm.allgather([info['nccl_comm_count'], info['nccl_user_rank'], info['nccl_device'], info['rccl_version']])
+        out['config']['rccl'] = {'comm_count_per_rank': [int(i[0]) for i in infos], 'user_rank_per_rank': [int(i[1]) for i in infos],
+                                 'device_per_rank': [int(i[2]) for i in infos], 'version': int(infos[0][3])}
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, (rho_s, dm_s, tg_s, want, bmax) = cpu_baseline(args.cpu_size, args.method, mode, iters,
                                                            lattice, atoms, background, args.size)

@@ -294,6 +294,9 @@ int xb_comm_share_brick_masks(xb_ctx *c, const int64_t *first, const int64_t *co
  * block 5: summed := sum over the ranks of local.  Ordered on the context's stream, no host wait. */
 int xb_comm_allgather_block(xb_ctx *c, int which, const int64_t *first, const int64_t *count);
 int xb_comm_allreduce_block(xb_ctx *c);
+/* what the communicator says about the run: out = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion}
+ * (-1 where this librccl lacks the entry point) -- lets a multi-GPU bench line prove it ran on N ranks and N devices */
+int xb_comm_info(xb_ctx *c, int64_t out[4]);
 /* plane bytes this rank has sent since xb_comm_init (label halos travel as dtype_calc(-n_maxima): int8 for up to 127 basins) */
 int xb_comm_stats(xb_ctx *c, int64_t *bytes_sent);
 

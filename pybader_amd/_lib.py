@@ -103,6 +103,7 @@ SYMBOLS = {
     'xb_slab_block_copy': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
     'xb_host_waits': (_int, [_pi64]),
     'xb_comm_stats': (_int, [_vp, _pi64]),
+    'xb_comm_info': (_int, [_vp, _pi64]),
     'xb_memory_stats': (_int, [_vp, _pi64, _pi64, _pi64]),
 }
 
@@ -570,6 +571,12 @@ class Context:
         a, b, d = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(self.lib.xb_memory_stats(self.h, C.byref(a), C.byref(b), C.byref(d)))
         return int(a.value), int(b.value), int(d.value)
+
+    def comm_info(self):
+        """{ranks, rank, device, rccl_version} as the RCCL communicator itself reports them (-1: not available)"""
+        out = (C.c_int64 * 4)()
+        check(self.lib.xb_comm_info(self.h, out))
+        return {'nccl_comm_count': int(out[0]), 'nccl_user_rank': int(out[1]), 'nccl_device': int(out[2]), 'rccl_version': int(out[3])}
 
     def comm_bytes_sent(self):
         n = C.c_int64(0)

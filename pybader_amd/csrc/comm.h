@@ -31,6 +31,11 @@ struct Api {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    // what the communicator itself says about the run (xb_comm_info); optional: an older librccl may lack one
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     std::string err;
 };
 static Api g_api;
@@ -58,6 +63,10 @@ static bool load_api() {
     bind("ncclAllReduce", (void **)&a.AllReduce);
     bind("ncclAllGather", (void **)&a.AllGather);
     bind("ncclBroadcast", (void **)&a.Broadcast);
+    a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.lib, "ncclCommUserRank");
+    a.CommCuDevice = (decltype(a.CommCuDevice))dlsym(a.lib, "ncclCommCuDevice");
+    a.GetVersion = (decltype(a.GetVersion))dlsym(a.lib, "ncclGetVersion");
     if (!ok) { dlclose(a.lib); a.lib = nullptr; }
     return ok;
 }
@@ -224,6 +233,19 @@ int xb_comm_exchange_planes(xb_ctx *c, int which, int n_send, const int32_t *sen
 }
 
 // plane bytes this rank has sent since xb_comm_init (the narrowed halos show here)
+// out[0..3]: ncclCommCount, ncclCommUserRank, ncclCommCuDevice of this rank's communicator and ncclGetVersion -- the
+// communicator's own word that the run saw N ranks on N devices (-1: that entry point is missing in this librccl)
+int xb_comm_info(xb_ctx *c, int64_t out[4]) {
+    if (int rc = comm_need(c, "xb_comm_info")) return rc;
+    int v[4] = {-1, -1, -1, -1};
+    const xbcomm::Api &a = xbcomm::g_api;
+    if (a.CommCount) NCCLCHK(a.CommCount(c->comm->comm, &v[0]));
+    if (a.CommUserRank) NCCLCHK(a.CommUserRank(c->comm->comm, &v[1]));
+    if (a.CommCuDevice) NCCLCHK(a.CommCuDevice(c->comm->comm, &v[2]));
+    if (a.GetVersion) NCCLCHK(a.GetVersion(&v[3]));
+    for (int i = 0; i < 4; i++) out[i] = v[i];
+    return XB_OK;
+}
 int xb_comm_stats(xb_ctx *c, int64_t *bytes_sent) {
     if (!c || !c->comm) return fail(XB_E_STATE, "xb_comm_stats: call xb_comm_init first");
     if (bytes_sent) *bytes_sent = (int64_t)c->comm->bytes_sent;

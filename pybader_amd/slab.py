@@ -20,11 +20,16 @@ import numpy as np
 
 
 def slab_ranges(nx, nranks):
-    """np.array_split semantics along axis 0 (thread_handlers.py:35): first nx % n slabs get one more."""
-    base, extra = divmod(int(nx), int(nranks))
+    """Contiguous planes of axis 0 per rank.  A grid of whole 8^3 bricks with at least one brick per rank is split on brick
+    boundaries (np.array_split over the BRICKS: the first (nx / 8) % n slabs get one brick more) -- a slab that cuts bricks
+    cannot use the trapping regions and traces its planes in full (round 4).  Otherwise np.array_split over the planes, as the
+    reference splits its blocks (thread_handlers.py:35): the first nx % n slabs get one plane more."""
+    nx, nranks = int(nx), int(nranks)
+    unit = 8 if nx % 8 == 0 and nx // 8 >= nranks else 1
+    base, extra = divmod(nx // unit, nranks)
     out, x = [], 0
     for r in range(nranks):
-        w = base + (1 if r < extra else 0)
+        w = (base + (1 if r < extra else 0)) * unit
         out.append((x, x + w))
         x += w
     return out

@@ -318,6 +318,8 @@ def test_rccl_transport_through_the_c_abi_single_rank():
     ctx.upload_density(rho)
     ctx.comm_init(0, 1, ctx.comm_unique_id())
     assert ctx.comm_allreduce([5, -3, 1 << 40]) == [5, -3, 1 << 40]
+    info = ctx.comm_info()         # what the communicator says about itself (bench.py puts it into the multi-GPU line)
+    assert info['nccl_comm_count'] == 1 and info['nccl_user_rank'] == 0 and info['nccl_device'] == 0 and info['rccl_version'] > 20000, info
     assert ctx.comm_allreduce([7], 'max') == [7] and ctx.comm_allreduce([7], 'min') == [7]
     assert ctx.comm_allgather([4, 9, 2]).tolist() == [4, 9, 2]
     ctx.comm_exchange_planes(0, [], [])

@@ -32,6 +32,10 @@ def run_world(n, args, tmp_path, port, halo=4, transport='gloo'):
 def test_slab_ranges_and_halo_plan():
     assert slab.slab_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
     assert slab.slab_ranges(8, 8) == [(k, k + 1) for k in range(8)]
+    # whole bricks, a brick or more per rank: the slabs do not cut bricks
+    assert slab.slab_ranges(512, 3) == [(0, 176), (176, 344), (344, 512)]
+    assert slab.slab_ranges(64, 8) == [(8 * k, 8 * k + 8) for k in range(8)]
+    assert slab.slab_ranges(40, 8)[0] == (0, 5)            # fewer bricks than ranks: plane by plane
     rngs = slab.slab_ranges(16, 4)
     for r in range(4):
         sends, recvs = slab.halo_plan(rngs, r, 2, 16)
