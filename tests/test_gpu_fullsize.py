@@ -209,6 +209,43 @@ def test_config4_1024_one_gpu_four_and_eight_slabs():
         assert per_rank < (36 << 30 if n_slabs == 8 else 48 << 30)
 
 
+def test_config4_1024_against_the_reference():
+    """BASELINE config 4's grid against what pybader itself returns on it (tests/golden/c1024_cubic.npz: 1.7 h of the
+    reference's numba path, hashes + logs + maxima + charges).  ongrid + refinement: bit for bit.  neargrid: the reference's
+    default two iterations do NOT converge at this size (its log ends with 33 relabelled voxels), so its ('changed', 2) map
+    is not yet the own-trajectory map this library returns: the basin volumes differ by a handful of voxels of 2^30 (asserted
+    below), the per-basin charges agree far inside north_star's 1e-6, and where the fixture holds the reference's converged
+    ('changed', -1) map the hashes must be equal."""
+    g = load_golden('c1024_cubic')
+    shape = tuple(int(x) for x in g['shape'])
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, g['dist_mat'], g['T_grad'])
+    ctx.synth_density(g['lattice'], g['atoms'], float(g['background']))
+    vv = float(g['voxel_volume'])
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a)).hexdigest()
+    ctx.vacuum_assign(None, vv)
+    n = ctx.assign('neargrid')
+    assert np.array_equal(ctx.maxima(), g['ng_bader_max'])
+    log = ctx.refine('changed', 2)
+    assert all(c == 0 for _, c in log)
+    ch, vo = ctx.charge_sum(vv, n)
+    moved = np.abs(np.round((vo - g['ng_bader_volume']) / vv)).astype(np.int64)
+    assert int(g['ng_changed_2_log'][-1, 1]) == 33 and 0 < moved.sum() <= 66, moved      # (each of the 33 can move two counts)
+    np.testing.assert_allclose(ch, g['ng_bader_charge'], rtol=1e-6)
+    if 'ng_changed_inf_sha256' in g:
+        assert sha(ctx.download_labels(np.int8)) == str(g['ng_changed_inf_sha256'])
+    ctx.vacuum_assign(None, vv)
+    ctx.assign('ongrid')
+    assert np.array_equal(ctx.maxima(), g['og_bader_max'])
+    assert sha(ctx.download_labels(np.int8)) == str(g['og_main_sha256'])
+    log = ctx.refine('changed', 2)
+    assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['og_ngrefine_changed_2_log'])
+    assert sha(ctx.download_labels(np.int8)) == str(g['og_ngrefine_changed_2_sha256'])
+    ctx.close()
+
+
 def test_many_atoms_keep_their_trapping_regions():
     """A cell with 216 atoms (more than the 64 seed cubes round 1 allowed): the trapping regions are built and the map
     equals the plain full-trajectory trace; one more case with more maxima than seed cubes can be (plain tracing)."""
