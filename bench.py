@@ -100,7 +100,10 @@ def traffic_from_profile(kernel, method):
         name = os.path.basename(f)
         m = re.match(r'r(\d+)', name)
         return (int(m.group(1)) if m else -1, '_final_' in name, name)
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_fetch_write_512_{method}.txt')), key=order)
+    # (the steady-state summary of a round -- 1 warm-up + 3 steps, first step dropped -- goes before its one-step, cold one)
+    def order2(f):
+        return order(f)[:2] + ('_steady_' in os.path.basename(f), os.path.basename(f))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_fetch_write*_512_{method}.txt')), key=order2)
     for path in reversed(files):
         kb, launches = 0.0, 0
         with open(path) as f:
