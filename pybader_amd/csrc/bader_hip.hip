@@ -119,6 +119,7 @@ struct xb_ctx {
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
     bool grad_valid = false;
+    bool brick_max_valid = false;   // brick_rec bit 1 (the brick holds a 26-neighbour maximum) is right for the density on the card
     int grad_cover = 0;        // 0: the table holds a record for every voxel (of the window); 1: only for the bricks flagged in brick_rec
     unsigned char *brick_rec = nullptr;   // per 8^3 brick: its records exist (k_brick_records), nbr bytes inside blab_buf's allocation
     void *xbuf = nullptr;      // the device-driven slab step's exchange blocks 3-5 (slab_step.h): tie flags, counters, maxima tables
@@ -284,7 +285,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 3) c->opt_dbg = value;
     else if (key == 4 && value >= 1 && value <= 4096) c->opt_ec_groups = value;
     else if (key == 5 && value >= 2 && value <= EC_Q) c->opt_ec_qcap = value;
-    else if (key == 6) c->grad_valid = false;  // drop the cached gradient-field table (a refinement rebuilds it)
+    else if (key == 6) { c->grad_valid = false; if (value == 2) c->brick_max_valid = false; }  // drop the cached gradient-field table (a refinement rebuilds it)
     else if (key == 7) c->opt_fused = value != 0;  // 0: the host-driven orchestration on one GPU too (tests compare the two)
     else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
     else if (key == 14) c->opt_lean = value != 0;

@@ -601,9 +601,12 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
         if (launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
         k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, nullptr, 0);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
         HIPCHK(hipGetLastError());
     }
+    c->grad_valid = false;          // (brick_rec is rewritten: bit 1 = holds a maximum, no records)
+    c->grad_cover = 0;
+    c->brick_max_valid = true;
     c->blab = c->blab_buf;
     c->regions_neargrid = false;   // (closed under the pointer moves only: the refinement's retraces must not stop on them)
     c->walk = walk;

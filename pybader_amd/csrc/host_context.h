@@ -37,7 +37,7 @@ static void free_grid(xb_ctx *c) {
     hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->labels_zero_pending = false;
     hipFree(c->ec_buf); c->ec_buf = nullptr; c->ec_buf_cap = 0; c->grad_cap = 0; c->list_cap = 0;
     c->brick_rec = nullptr; c->grad_cover = 0;
-    c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
+    c->rho = nullptr; c->grad = nullptr; c->grad_valid = false; c->brick_max_valid = false; c->labels = nullptr; c->known = nullptr; c->first = nullptr; c->list = nullptr;
     c->st = nullptr; c->stage = nullptr; c->max_list = nullptr; c->max_aux = nullptr; c->ovf_list = nullptr;
     c->n_alloc = 0; c->stage_bytes = 0;
 }
@@ -101,7 +101,7 @@ static int need_grad(xb_ctx *c) {
     g.ntot = (int)c->N;
     if (c->grad_cap < want || c->grad_cap > 2 * want) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(c->grad); c->grad = nullptr; c->grad_cap = 0; c->grad_valid = false;
+        hipFree(c->grad); c->grad = nullptr; c->grad_cap = 0; c->grad_valid = false; c->brick_max_valid = false;
         HIPCHK(hipMalloc(&c->grad, (size_t)want * sizeof(GradRec)));
         c->grad_cap = want;
     }
@@ -148,19 +148,19 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
     }
     c->zero_outside[0] = -1;
     Grid &g = c->g;
-    if (g.nx != (int)shape[0] || g.ny != (int)shape[1] || g.nz != (int)shape[2]) c->grad_valid = false;
+    if (g.nx != (int)shape[0] || g.ny != (int)shape[1] || g.nz != (int)shape[2]) { c->grad_valid = false; c->brick_max_valid = false; }
     if (dist_mat && !T_grad) return fail(XB_E_ARG, "xb_set_grid: dist_mat without T_grad");
     g.nx = (int)shape[0]; g.ny = (int)shape[1]; g.nz = (int)shape[2];
     g.nyz = g.ny * g.nz;
     g.x0 = (int)x0; g.x1 = (int)x1;
     if (dist_mat) {
-        if (memcmp(g.dist, dist_mat, sizeof g.dist) != 0) c->grad_valid = false;   // the tabulated ongrid successors depend on it
+        if (memcmp(g.dist, dist_mat, sizeof g.dist) != 0) { c->grad_valid = false; c->brick_max_valid = false; }   // the tabulated ongrid successors depend on it
         memcpy(g.dist, dist_mat, sizeof g.dist);
         HIPCHK(hipMemcpyAsync(c->dist_dev, dist_mat, sizeof g.dist, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->dist_dev + 27, T_grad, sizeof g.T, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    if (T_grad && memcmp(g.T, T_grad, sizeof g.T) != 0) { memcpy(g.T, T_grad, sizeof g.T); c->grad_valid = false; }
+    if (T_grad && memcmp(g.T, T_grad, sizeof g.T) != 0) { memcpy(g.T, T_grad, sizeof g.T); c->grad_valid = false; c->brick_max_valid = false; }
     c->N = N;
     c->halo = (x0 == 0 && x1 == shape[0]) ? g.nx : 0;
     set_valid_range(c);
@@ -282,7 +282,7 @@ static int staged_d2h(xb_ctx *c, void *dst_host, const void *src_dev, size_t byt
 
 int xb_upload_density(xb_ctx *c, const double *rho_host) {
     NEED_GRID("xb_upload_density");
-    c->grad_valid = false;
+    c->grad_valid = false; c->brick_max_valid = false;
     if (int rc = staged_h2d(c, c->rho, rho_host, c->N * sizeof(double))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return XB_OK;
@@ -319,7 +319,7 @@ int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double di
     if (!text || nbytes <= 0) return fail(XB_E_ARG, "xb_parse_density_text: empty text");
     if (nbytes / (TPB * TXT_BYTES) >= (1LL << 31) - 2) return fail(XB_E_LIMIT, "xb_parse_density_text: text too large");
     if (!(divisor == divisor) || divisor == 0.) return fail(XB_E_ARG, "xb_parse_density_text: bad divisor");
-    c->grad_valid = false;
+    c->grad_valid = false; c->brick_max_valid = false;
     static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
     const int nblk = (int)((nbytes + TPB * TXT_BYTES - 1) / (TPB * TXT_BYTES));
@@ -394,7 +394,7 @@ int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double di
 int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, int64_t n_atoms, double background) {
     NEED_GRID("xb_synth_density");
     if (n_atoms < 0 || n_atoms > 4096) return fail(XB_E_ARG, "xb_synth_density: bad atom count");
-    c->grad_valid = false;
+    c->grad_valid = false; c->brick_max_valid = false;
     double *tmp = (double *)c->stage;
     HIPCHK(hipMemcpyAsync(tmp, lattice, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(tmp + 16, atoms5, n_atoms * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));

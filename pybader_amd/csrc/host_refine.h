@@ -617,7 +617,7 @@ int xb_prepare_refine(xb_ctx *c) {
 
 // edge_find + retrace of one refinement iteration on one slab with ONE host wait: the edge count stays on the
 // device (the list kernels stride over it), the counters come back together at the end.
-static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
+static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, bool late_records = false) {
     const Grid &g = c->g;
     int *fs = c->fs;
     c->g.main_ties = 0;
@@ -638,7 +638,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
             k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
             buni += nbr;
         }
-        const unsigned char *brec = c->grad_valid && c->grad_cover == 1 ? c->brick_rec : nullptr;
+        const unsigned char *brec = (c->grad_valid && c->grad_cover == 1) || late_records ? c->brick_rec : nullptr;
         if (buni) {
             // flags preset to "known", then only the tiles that are not of one non-vacuum label with their surroundings
             const int ntiles = ((g.nz + ET_Z - 1) / ET_Z) * ((g.ny + ET_Y - 1) / ET_Y) * ((g.nx + ET_X - 1) / ET_X);
@@ -658,6 +658,27 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed) {
     }
     c->list_valid = false; c->chg_n = -1;
     c->buni_valid = false;
+    if (late_records) {
+        // the records of the band bricks (k_masks.h), now that the flags say where the band is
+        if (int rc = need_grad(c)) return rc;
+        ScopedTimer t(c, 4);
+        const int nb0 = (g.nx + 7) / 8, nb1 = (g.ny + 7) / 8, nb2 = (g.nz + 7) / 8, nbr = nb0 * nb1 * nb2;
+        const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
+        k_rec_clear_bit0<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->brick_rec);
+        k_flag_band_bricks<<<4096, TPB, 0, c->stream>>>(gl, c->known, (const int *)c->stage, fs + FS_N_TILES, c->brick_rec);
+        GridS gs;
+        if (sym_grid(g, gs))
+            k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, nullptr, nullptr, nbr, nb1, nb2, c->brick_rec, small);
+        else
+            k_brick_records<Grid><<<4096, TPB, 0, c->stream>>>(g, c->rho, c->grad, nullptr, nullptr, nbr, nb1, nb2, c->brick_rec, small);
+        HIPCHK(hipGetLastError());
+        c->grad_valid = true;
+        c->grad_cover = 1;
+        c->grad_rule = 0;
+        c->regions_labels = false;
+        c->blab = nullptr;
+        c->table_stage = 0;
+    }
     {
         ScopedTimer t(c, 3);
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
@@ -704,9 +725,13 @@ int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capa
     NEED_GRID("xb_refine");
     if (n_iters) *n_iters = 0;
     if (iters == 0) return XB_OK;  // thread_handlers.py:146-147
-    if (int rc = xb_prepare_refine(c)) return rc;
     int64_t edges = 0, changed = 0, esc = 0, checked = 0;
     const bool fused = c->opt_fused && c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
+    // After an ongrid assignment (no table yet, the bricks' maxima known, no vacuum) the first iteration builds the records
+    // itself, after its edge sweep and only where the band is; otherwise the table comes first (the sweep reads it).
+    const bool late = fused && !c->grad_valid && c->brick_max_valid && !c->has_vacuum && c->brick_rec && c->g.nx >= 16 && c->g.ny >= 16 && c->g.nz >= 16;
+    if (!late)
+        if (int rc = xb_prepare_refine(c)) return rc;
     int64_t k = 0;
     auto put = [&](int64_t e, int64_t ch) {
         if (log && 2 * k + 1 < log_capacity) { log[2 * k] = e; log[2 * k + 1] = ch; }
@@ -714,7 +739,7 @@ int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capa
         if (n_iters) *n_iters = k;
     };
     if (fused) {
-        if (int rc = refine_iteration_fused(c, &edges, &changed)) return rc;
+        if (int rc = refine_iteration_fused(c, &edges, &changed, late)) return rc;
         if (edges == 0) return XB_OK;  // thread_handlers.py:151-153 (no edge: the retrace had nothing to do)
     } else {
         if (int rc = xb_edge_find(c, &edges)) return rc;

@@ -16,7 +16,7 @@ static bool table_windowed(const xb_ctx *c) { return c->g.wlen < c->g.nx; }
 // per-brick arrays that outlive an assignment: blab_buf (nbr ints: region label per brick) and brick_rec (nbr bytes)
 static int ensure_brick_bytes(xb_ctx *c, int nbr) {
     if (c->blab_alloc < nbr) {
-        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->brick_rec = nullptr;
+        hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->brick_rec = nullptr; c->brick_max_valid = false;
         if (c->grad_cover) { c->grad_cover = 0; c->grad_valid = false; }
         HIPCHK(hipMalloc(&c->blab_buf, (size_t)nbr * sizeof(int) + (size_t)nbr + 16));
         c->blab_alloc = nbr;

@@ -625,6 +625,52 @@ __global__ void k_flag_mixed_bricks(int nbr, const int *__restrict__ buni3, unsi
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nbr) brick_rec[b] = (unsigned char)(2 | (buni3[b] == XB_MIXED_LABEL ? 1 : 0));
 }
+// A refinement after an ongrid assignment (round 4): the retraces of refinement.py:283-303 stop on the first known == 2 voxel, so
+// records are needed for the BAND only (known != 2: the edge voxels and the ring around them) -- the bricks that hold band
+// voxels, found from the flags of the listed tiles once the edge sweep has run, instead of every brick whose 27-brick
+// surroundings carry two labels (at 512^3 half as many: k_brick_records 0.90 -> 0.45 ms).  Bricks within ONE voxel of the
+// band are flagged too: the next iteration's new edges lie inside the boxes of changed edge voxels (refinement.py:428-504)
+// and its ring one voxel further; what walks on beyond that is redone by the from-rho kernel as before.
+__global__ void k_rec_clear_bit0(int nbr, unsigned char *brick_rec) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbr) brick_rec[b] &= 2;
+}
+__global__ __launch_bounds__(TPB) void k_flag_band_bricks(GridL g, const int8_t *__restrict__ known, const int *__restrict__ tiles, const int *n_tiles,
+                                                          unsigned char *brick_rec) {
+    const int ntz = (g.nz + 63) / 64, nty = (g.ny + 7) / 8, n = *n_tiles;   // the edge sweep's tiles: 4 x 8 x 64 voxels (k_edges.h)
+    const int nb0 = (g.nx + 7) >> 3, nb1 = (g.ny + 7) >> 3, nb2 = (g.nz + 7) >> 3;
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        const int t = (int)((unsigned)tiles[item] & 0x7fffffffu);
+        const int x = (t / (ntz * nty)) * 4 + threadIdx.x / 64, y = ((t / ntz) % nty) * 8 + (threadIdx.x / 8) % 8, z = (t % ntz) * 64 + 8 * (threadIdx.x % 8);
+        if (x >= g.nx || y >= g.ny || z >= g.nz) continue;
+        const int8_t *row = known + ((size_t)x * g.ny + y) * g.nz;
+        bool any = false, lo = false, hi = false;   // band voxels in this chunk / at its first / at its last voxel
+        if (g.nz % 8 == 0) {
+            const unsigned long long w = *reinterpret_cast<const unsigned long long *>(row + z);
+            any = w != 0x0202020202020202ull; lo = (w & 0xffull) != 2; hi = (w >> 56) != 2;
+        } else
+            for (int k = 0; k < 8 && z + k < g.nz; k++) {
+                const bool bnd = row[z + k] != 2;
+                any |= bnd;
+                if (k == 0) lo = bnd;
+                if (k == 7 || z + k == g.nz - 1) hi = bnd;
+            }
+        if (!any) continue;
+        const int bx = x >> 3, by = y >> 3, bz = z >> 3;
+        const bool mx = (x & 7) == 0, px = (x & 7) == 7 || x == g.nx - 1, my = (y & 7) == 0, py = (y & 7) == 7 || y == g.ny - 1;
+        for (int ax = -1; ax < 2; ax++) {
+            if ((ax < 0 && !mx) || (ax > 0 && !px)) continue;
+            for (int ay = -1; ay < 2; ay++) {
+                if ((ay < 0 && !my) || (ay > 0 && !py)) continue;
+                for (int az = -1; az < 2; az++) {
+                    if ((az < 0 && !lo) || (az > 0 && !hi)) continue;
+                    unsigned char *p = brick_rec + (wrapi(bx + ax, nb0) * nb1 + wrapi(by + ay, nb1)) * nb2 + wrapi(bz + az, nb2);
+                    if (!(*p & 1)) *p |= 1;   // (bit 1 never changes here: concurrent writers store the same byte)
+                }
+            }
+        }
+    }
+}
 // brick_rec[b]: bit 0 = the records of brick b exist, bit 1 = the brick holds a 26-neighbour maximum (k_grow_finish).
 // Does the record of voxel (x,y,z) exist?  (nullptr: the table covers the whole grid / window)
 __device__ __forceinline__ bool rec_exists(const unsigned char *__restrict__ brick_rec, const GridL &g, int x, int y, int z) {
