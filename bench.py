@@ -121,7 +121,7 @@ def traffic_from_profile(kernel, method):
                 if k not in ('k_synth_density', 'k_fill', 'k_charge_sum_lds'):   # the generator, the one-off fill and the map check after the timed region are not part of a step
                     kb += float(m.group(4))
                     launches = 1
-            elif k == kernel:
+            elif k == kernel or k.startswith(kernel + '_'):   # (k_ng_trace: the group form k_ng_trace_g)
                 kb += float(m.group(4))
                 launches = max(launches, int(m.group(3)))
         if launches:
@@ -349,7 +349,7 @@ def main():
         raise SystemExit(f'map check failed: basin volumes {vols[:16]}... sum {sum(vols)} of {int(nvox)} voxels')
     ms_per_step = dt / args.steps * 1e3
     # HIP-event timings on the library's own stream (xb_kernel_time)
-    stage_names = ['assign_after_masks(walk_list+k_brick_records+k_ng_trace)', 'k_og_pointer', 'edge_find', 'k_refine_trace',
+    stage_names = ['assign_after_masks(walk_list+k_brick_records+k_ng_trace)', 'k_og_masks', 'edge_find', 'k_refine_trace',
                    'masks+trapping_regions', 'k_brick_masks', 'k_ng_trace', 'k_brick_records']   # (6: whichever trace kernel ran)
     tm = {name: ctx.kernel_time(i) for i, name in enumerate(stage_names)}
     avg = {k: (ms / n if n else 0.0) for k, (ms, n) in tm.items()}
@@ -361,7 +361,7 @@ def main():
     achieved = BYTES_PATH * nvox / step_s / 1e9
     kernels = {}
     for name, bytes_per_voxel in (('k_brick_masks', BYTES_ASSIGN), ('k_ng_trace', BYTES_ASSIGN), ('k_brick_records', BYTES_ASSIGN),
-                                  ('k_og_pointer', BYTES_ASSIGN), ('edge_find', 13), ('k_refine_trace', 13)):
+                                  ('k_og_masks', BYTES_ASSIGN), ('edge_find', 13), ('k_refine_trace', 13)):
         if avg[name] > 0:
             gbs = bytes_per_voxel * nvox * own_frac / (avg[name] * 1e-3) / 1e9
             kernels[name] = {'ms_avg': avg[name], 'launches': int(tm[name][1]), 'algorithmic_bytes_per_voxel': bytes_per_voxel,
@@ -424,7 +424,7 @@ def main():
         fence()
         dt5 = (time.perf_counter() - t5) / args.steps
         tm5 = {name: ctx.kernel_time(i) for i, name in enumerate(
-            ['-', 'k_og_pointer_tiled', 'edge_find', 'k_refine_trace', 'table_for_retraces(k_grad_field)', 'k_grad_field'])}
+            ['-', 'k_og_masks', 'edge_find', 'k_refine_trace', 'regions+records_for_retraces', 'k_brick_masks'])}
         out['config5'] = {'workload': f'{args.size}^3 same density, ongrid assign + neargrid edge refinement {mode}:{iters}',
                           'value': nvox / dt5 / 1e6, 'unit': 'Mvoxels/s', 'ms_per_step': dt5 * 1e3, 'steps': args.steps,
                           'basins': int(n5), 'refine_log': log5,
