@@ -664,8 +664,10 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
         ScopedTimer t(c, 4);
         const int nb0 = (g.nx + 7) / 8, nb1 = (g.ny + 7) / 8, nb2 = (g.nz + 7) / 8, nbr = nb0 * nb1 * nb2;
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
-        k_rec_clear_bit0<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->brick_rec);
-        k_flag_band_bricks<<<4096, TPB, 0, c->stream>>>(gl, c->known, (const int *)c->stage, fs + FS_N_TILES, c->brick_rec);
+        unsigned char *band = reinterpret_cast<unsigned char *>(c->blab_buf);   // (the bricks' region labels have served: scratch)
+        HIPCHK(hipMemsetAsync(band, 0, (size_t)nbr, c->stream));
+        k_flag_band_bricks<<<4096, TPB, 0, c->stream>>>(gl, c->known, (const int *)c->stage, fs + FS_N_TILES, band);
+        k_rec_set_bit0<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->brick_rec, band);
         GridS gs;
         if (sym_grid(g, gs))
             k_brick_records<GridS><<<4096, TPB, 0, c->stream>>>(gs, c->rho, c->grad, nullptr, nullptr, nbr, nb1, nb2, c->brick_rec, small);

@@ -1305,13 +1305,21 @@ __global__ __launch_bounds__(TPB) void k_ec_finish(int8_t *known, long long N, u
     __syncthreads();
     unsigned int cnt = 0;
     const long long stride = (long long)gridDim.x * TPB * 16;
+    // (the next chunk travels while this one is counted and listed: the list append is a block scan with two barriers)
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    {
+        const long long b0 = (long long)blockIdx.x * TPB * 16 + (long long)threadIdx.x * 16;
+        if (b0 + 16 <= N) nxt = *reinterpret_cast<const uint4 *>(known + b0);
+    }
     for (long long base0 = (long long)blockIdx.x * TPB * 16; base0 < N; base0 += stride) {   // (uniform per block)
         const long long base = base0 + (long long)threadIdx.x * 16;
         unsigned hits = 0;   // bit k: voxel base + k is -2 now and inside the range
+        uint4 w = nxt;
+        if (base + stride + 16 <= N) nxt = *reinterpret_cast<const uint4 *>(known + base + stride);
         if (base + 16 <= N) {
-            uint4 w = *reinterpret_cast<const uint4 *>(known + base);
             int8_t *b = reinterpret_cast<int8_t *>(&w);
             unsigned int c = 0;
+            if ((w.x | w.y | w.z | w.w) & 0x80808080u)   // (no negative flag among the 16: nothing to count or list -- most of the grid)
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const bool in = (base + k >= count_lo) & (base + k < count_hi);

@@ -631,12 +631,14 @@ __global__ void k_flag_mixed_bricks(int nbr, const int *__restrict__ buni3, unsi
 // surroundings carry two labels (at 512^3 half as many: k_brick_records 0.90 -> 0.45 ms).  Bricks within ONE voxel of the
 // band are flagged too: the next iteration's new edges lie inside the boxes of changed edge voxels (refinement.py:428-504)
 // and its ring one voxel further; what walks on beyond that is redone by the from-rho kernel as before.
-__global__ void k_rec_clear_bit0(int nbr, unsigned char *brick_rec) {
+// (the flags go to a byte array of their own first -- plain stores of 1, nothing to wait for -- and are merged into bit 0
+// afterwards: read-modify-write of the brick bytes themselves was up to 27 dependent round trips per band row, 62 us)
+__global__ void k_rec_set_bit0(int nbr, unsigned char *brick_rec, const unsigned char *__restrict__ flag) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbr) brick_rec[b] &= 2;
+    if (b < nbr) brick_rec[b] = (unsigned char)((brick_rec[b] & 2) | (flag[b] ? 1 : 0));
 }
 __global__ __launch_bounds__(TPB) void k_flag_band_bricks(GridL g, const int8_t *__restrict__ known, const int *__restrict__ tiles, const int *n_tiles,
-                                                          unsigned char *brick_rec) {
+                                                          unsigned char *flag) {
     const int ntz = (g.nz + 63) / 64, nty = (g.ny + 7) / 8, n = *n_tiles;   // the edge sweep's tiles: 4 x 8 x 64 voxels (k_edges.h)
     const int nb0 = (g.nx + 7) >> 3, nb1 = (g.ny + 7) >> 3, nb2 = (g.nz + 7) >> 3;
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
@@ -664,8 +666,7 @@ __global__ __launch_bounds__(TPB) void k_flag_band_bricks(GridL g, const int8_t 
                 if ((ay < 0 && !my) || (ay > 0 && !py)) continue;
                 for (int az = -1; az < 2; az++) {
                     if ((az < 0 && !lo) || (az > 0 && !hi)) continue;
-                    unsigned char *p = brick_rec + (wrapi(bx + ax, nb0) * nb1 + wrapi(by + ay, nb1)) * nb2 + wrapi(bz + az, nb2);
-                    if (!(*p & 1)) *p |= 1;   // (bit 1 never changes here: concurrent writers store the same byte)
+                    flag[(wrapi(bx + ax, nb0) * nb1 + wrapi(by + ay, nb1)) * nb2 + wrapi(bz + az, nb2)] = 1;
                 }
             }
         }
