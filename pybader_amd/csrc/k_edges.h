@@ -1154,6 +1154,47 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
             push((ec_word)((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (ow & 0xFFFFFFFF00000000ull));
     }
 }
+// The same for a QUEUE entry of the chase (the decision and the later-neighbour mask ride in the entry), spread over 16 lanes:
+// lane `sub` notifies the sub-th later neighbour.  Round 4: a chain hop is one round of a workgroup in which a single wave has
+// work, so the hop lasts as long as that wave's longest dependent instruction chain -- and walked by one lane, the ten
+// notifications of a voxel (decode with two integer divisions, nine row bases, ten address computations, ten wake tests, the
+// pushes) were ~700 instructions, 1.3 of the 3.0 us per hop; a device-scope atomic with its result takes 0.4-0.7 us on this
+// card and a pair of barriers 0.08 (scratch microbenchmark).  Sixteen lanes cut the chain to ~100 instructions.
+#ifndef EC_LANES
+#define EC_LANES 8
+#endif
+template <typename Push>
+__device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, double inv_nz, int8_t *known, ec_word *pend, ec_word entry,
+                                                 int sub, Push push) {
+    const int v = (int)(entry & 0x3FFFFFFFu);
+    const int d = (entry & EC_E_SKIP) ? 2 : 1;
+    const unsigned int later = (unsigned int)(entry >> 32);
+    if (sub == 0) {   // publish the decision (a queue entry is the only one for its voxel: nobody waits for the result)
+        const int sh = (v & 3) * 8;
+        __hip_atomic_fetch_and(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int nl = __popc(later);
+    if (sub >= nl) return;
+    // v -> (x, y, z) with two multiplications by reciprocals and a correction step (exact: v < 2^30)
+    int x = (int)((double)v * inv_nyz);
+    int r = v - x * g.nyz;
+    if (r < 0) { x--; r += g.nyz; } else if (r >= g.nyz) { x++; r -= g.nyz; }
+    int y = (int)((double)r * inv_nz);
+    int z = r - y * g.nz;
+    if (z < 0) { y--; z += g.nz; } else if (z >= g.nz) { y++; z -= g.nz; }
+    const ec_word delta = d == 1 ? 0xFFull : ~0ull;  // +0x100 - 1  |  -1
+    for (int s = sub; s < nl; s += EC_LANES) {   // (a voxel with more later listed neighbours than lanes: another turn)
+        unsigned int m = later;
+        for (int k = 0; k < s; k++) m &= m - 1;
+        const int j = __ffs(m) - 1;
+        const int u = lin3(g, wrapi(x + j / 9 - 1, g.nx), wrapi(y + (j / 3) % 3 - 1, g.ny), wrapi(z + j % 3 - 1, g.nz));
+        const ec_word ow = atomicAdd(pend + u, delta);
+        const unsigned int ob = (unsigned int)ow & 0xffffu;
+        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1))
+            push((ec_word)((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (ow & 0xFFFFFFFF00000000ull));
+    }
+}
 // Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
 // decided, the voxels that become decidable through these decisions seed the chase (32-bit entries: the seeds read
 // their word again).
@@ -1185,6 +1226,7 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
     const int seed_end = min(seed_cur + per, n_seeds);
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
+    const double inv_nyz = 1.0 / (double)g.nyz, inv_nz = 1.0 / (double)g.nz;
     for (int cur = 0;; cur ^= 1) {
         const int n = min(s_n[cur], qcap);  // qcap <= EC_Q (smaller only to exercise the overflow path in tests)
         const int take = n <= qcap / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
@@ -1201,10 +1243,16 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                 if (o < ovf_cap) ovf[o] = (int)(unsigned int)u;
             }
         };
-        for (int e = threadIdx.x; e < n + take; e += EC_CHASE_THREADS) {
-            if (e < n) ec_resolve<false>(g, known, pend, q[cur][e], push);
-            else ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)seeds[seed_cur + e - n], push);
+        if (n > 2 * (EC_CHASE_THREADS / EC_LANES)) {   // a long queue (the first rounds): throughput counts, a lane per entry
+            for (int e = threadIdx.x; e < n; e += EC_CHASE_THREADS) ec_resolve<false>(g, known, pend, q[cur][e], push);
+        } else {                                       // the chains' tail: latency counts, EC_LANES lanes per entry
+            for (int e0 = 0; e0 < n; e0 += EC_CHASE_THREADS / EC_LANES) {
+                const int e = e0 + (int)(threadIdx.x / EC_LANES);
+                if (e < n) ec_resolve_lanes(g, inv_nyz, inv_nz, known, pend, q[cur][e], threadIdx.x % EC_LANES, push);
+            }
         }
+        for (int e = threadIdx.x; e < take; e += EC_CHASE_THREADS)   // seeds: a lane each (they read their word and claim first)
+            ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)seeds[seed_cur + e], push);
         seed_cur += take;
         __syncthreads();  // the next round's queue is complete (every atomic's result was used: they have returned)
     }
