@@ -438,6 +438,8 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
     if (checked) *checked = 0;
     if (edges) *edges = 0;
     if (!n) return XB_OK;
+    int *plist = nullptr;   // the processed voxels, listed for k_ec_apply (in the first seed list: free once the chase is over)
+    int plist_cap = 0;
     {
         // counters + classes for the whole list, round 1 over the whole list, then the dependency chains are
         // chased asynchronously by a small grid of workgroups; queue overflows seed another launch.  Scratch: two
@@ -456,6 +458,7 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
             }
             buf[0] = c->ec_buf; buf[1] = c->ec_buf + cap;
         }
+        plist = buf[0]; plist_cap = cap;
         if (!c->ec_pend) HIPCHK(hipMalloc(&c->ec_pend, 8 * (size_t)c->N + 16));
         if (!c->ec_pflag) {
             HIPCHK(hipMalloc(&c->ec_pflag, (size_t)c->N + 16));
@@ -494,10 +497,11 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     const int new_cap = (int)std::min<long long>(c->list_cap - n, 1LL << 30);   // the rest of `list` behind the compacted edges
     HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
-    k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)1);
-    k_ec_apply<<<(unsigned)std::min<long long>(nblocks(27LL * n), 4096), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, c->st,
+    HIPCHK(hipMemsetAsync(c->counters + 27, 0, sizeof(int), c->stream));
+    k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)1, plist, c->counters + 27, plist_cap);
+    k_ec_apply<<<(unsigned)std::min<long long>(nblocks(27LL * n), 4096), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, plist, c->counters + 27,
                                                   c->counters64 + 1, c->list + n, c->counters + 7, new_cap, c->ec_pflag);
-    k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)0);   // (the flags are zero again)
+    k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)0, nullptr, nullptr, 0);   // (the flags are zero again)
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
     {   // -1 ring around the new edges (-3): from their list, or by a full-grid sweep if the list did not fit
         int n_new = 0;

@@ -1276,30 +1276,41 @@ __global__ void k_ec_collect(const int8_t *__restrict__ known, const int *__rest
 // The same 27 flags give `checked` the multiplicity the sequential scan gives it: a non-edge voxel is "checked" once per
 // processed voxel whose box holds it (refinement.py:477-479).  (Tried first: claiming box voxels with atomicOr on a bitmap --
 // 27 scattered atomics per processed voxel cost more than the loads they saved, 0.86 ms.)
-__global__ void k_ec_mark(const int *__restrict__ list, int n, const int8_t *__restrict__ st, int8_t *__restrict__ pflag, int8_t value) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n || st[t] != 1) return;
-    pflag[list[t]] = value;
+// (plist / n_proc: the processed voxels are also listed -- a quarter of the entries at 512^3 --, so that k_ec_apply spends its
+// threads on their boxes only)
+__global__ __launch_bounds__(TPB) void k_ec_mark(const int *__restrict__ list, int n, const int8_t *__restrict__ st, int8_t *__restrict__ pflag,
+                                                 int8_t value, int *plist, int *n_proc, int pcap) {
+    __shared__ int s_buf[BlockAppender<1>::CAP], s_n[2];
+    BlockAppender<1> app;
+    if (plist) app.init(s_buf, s_n, plist, n_proc, pcap);
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    const bool proc = t < n && st[t] == 1;
+    const int v = proc ? list[t] : 0;
+    if (proc) pflag[v] = value;
+    if (plist) {
+        app.add(proc ? 1 : 0, [&](int) { return v; });
+        app.finish();
+    }
 }
 // (a thread per (listed voxel, box position) pair, a fixed grid striding over the pairs: the 27 positions of a box are
 // independent, and walked one after the other by one thread they were 27 serial memory latencies)
 __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restrict__ rho,
                                                   const int *__restrict__ labels, int8_t *known,
-                                                  const int *__restrict__ list, int n, const int8_t *st,
+                                                  const int *__restrict__ plist, const int *__restrict__ n_proc,
                                                   unsigned long long *checked, int *new_edges, int *n_new, int new_cap,
                                                   const int8_t *__restrict__ pflag) {
     __shared__ int s_buf[BlockAppender<1>::CAP], s_n[2];
     BlockAppender<1> app;
     app.init(s_buf, s_n, new_edges, n_new, new_cap);
     unsigned int nchk = 0;
-    const long long pairs = 27LL * n;
+    const long long pairs = 27LL * *n_proc;
     for (long long base = (long long)blockIdx.x * TPB; base < pairs; base += (long long)gridDim.x * TPB) {   // (uniform per block)
         const long long p = base + threadIdx.x;
         const int t = (int)(p / 27), j = (int)(p - 27LL * t);
-        const bool act = p < pairs && st[t] == 1;
+        const bool act = p < pairs;
         int new_edge = -1;
         if (act) {
-            const int v = list[t];
+            const int v = plist[t];
             const int x = v / g.nyz;
             const int r = v - x * g.nyz;
             const int y = r / g.nz, z = r - y * g.nz;
