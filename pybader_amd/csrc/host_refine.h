@@ -465,62 +465,65 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
             HIPCHK(hipMemsetAsync(c->ec_pflag, 0, (size_t)c->N + 16, c->stream));
         }
         ec_word *pend_w = c->ec_pend;
-        HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
+        // counters: 6 / 24 the seed list and the overflow list of a chase pass (alternating), 25 undecided voxels, 7 new edges,
+        // 27 processed voxels, 26 the next pass's list -- zeroed together; the host reads 24 once (did the LDS queues spill?) and
+        // the rest with the results
+        HIPCHK(hipMemsetAsync(c->counters + 6, 0, 2 * sizeof(int), c->stream));
+        HIPCHK(hipMemsetAsync(c->counters + 24, 0, 4 * sizeof(int), c->stream));
         if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, pend_w);
         else k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, pend_w);
         k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
                                                                                          c->counters + 6, cap);
         HIPCHK(hipGetLastError());
-        int n_seeds = 0;
-        if (int rc = read_counter(c, 6, &n_seeds)) return rc;
+        const int groups = std::max(1, std::min(256, c->opt_ec_groups));
+        int n_seeds = 1;
         for (int pass = 0; n_seeds > 0; pass++) {
-            if (n_seeds > cap) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
             if (pass > 256) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
-            HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-            const int groups = (int)std::min<long long>(std::max(1, n_seeds / 64), c->opt_ec_groups);
-            k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->known, pend_w, buf[pass & 1], n_seeds, buf[1 - (pass & 1)],
-                                                                   c->counters + 6, cap, c->opt_ec_qcap);
+            int *cnt_in = c->counters + ((pass & 1) ? 24 : 6), *cnt_out = c->counters + ((pass & 1) ? 6 : 24);
+            if (pass) HIPCHK(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
+            k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->known, pend_w, buf[pass & 1], cnt_in, buf[1 - (pass & 1)], cnt_out,
+                                                                   cap, c->opt_ec_qcap);
             HIPCHK(hipGetLastError());
-            const int before = n_seeds;
-            if (int rc = read_counter(c, 6, &n_seeds)) return rc;
-            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d seeds, %d overflowed (%d groups)\n", pass, before, n_seeds, groups);
+            if (int rc = read_counter(c, (pass & 1) ? 6 : 24, &n_seeds)) return rc;
+            if (n_seeds > cap) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
+            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d overflowed (%d groups)\n", pass, n_seeds, groups);
         }
     }
-    HIPCHK(hipMemsetAsync(c->counters + 6, 0, sizeof(int), c->stream));
-    k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st, c->counters + 6);
-    {
-        int undecided = 0;
-        if (int rc = read_counter(c, 6, &undecided)) return rc;
-        if (undecided) return fail(XB_E_STATE, "xb_edge_check: %d edge voxels left undecided", undecided);
-    }
+    HIPCHK(hipMemsetAsync(c->counters + 25, 0, sizeof(int), c->stream));
+    k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st, c->counters + 25);
     if (near_np < g.nx) k_ec_keep_near<<<nblocks(n), TPB, 0, c->stream>>>(g, c->list, n, c->st, near_xa, near_np);
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
     const int new_cap = (int)std::min<long long>(c->list_cap - n, 1LL << 30);   // the rest of `list` behind the compacted edges
     HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
-    HIPCHK(hipMemsetAsync(c->counters + 27, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->counters + 26, 0, 2 * sizeof(int), c->stream));
     k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)1, plist, c->counters + 27, plist_cap);
     k_ec_apply<<<(unsigned)std::min<long long>(nblocks(27LL * n), 4096), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, plist, c->counters + 27,
                                                   c->counters64 + 1, c->list + n, c->counters + 7, new_cap, c->ec_pflag);
     k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)0, nullptr, nullptr, 0);   // (the flags are zero again)
     k_ec_restore<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n);
-    {   // -1 ring around the new edges (-3): from their list, or by a full-grid sweep if the list did not fit
-        int n_new = 0;
-        if (int rc = read_counter(c, 7, &n_new)) return rc;
-        if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
-        else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new, nullptr);
+    {   // -1 ring around the new edges (-3): from their list (its length stays on the device) -- a list that may not fit (a
+        // grid most of whose voxels changed) is read back, and a full-grid sweep takes over if it did not
+        if (new_cap >= std::min<long long>(27LL * n, c->N))
+            k_edge_dilate_list<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, 0, c->counters + 7);
+        else {
+            int n_new = 0;
+            if (int rc = read_counter(c, 7, &n_new)) return rc;
+            if (n_new > new_cap) k_edge_dilate<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->known, 0, g.nx, -3);
+            else if (n_new) k_edge_dilate_list<<<nblocks(n_new), TPB, 0, c->stream>>>(light(g), c->known, c->list + n, n_new, nullptr);
+        }
     }
     // (the sweep also lists the voxels flagged -2 afterwards, the retrace list of the next pass, into `list` itself: its
     // compacted entries and the new-edge list behind them have served)
-    HIPCHK(hipMemsetAsync(c->counters + 26, 0, sizeof(int), c->stream));
     const int fin_cap = (int)std::min<long long>(c->list_cap, 1LL << 30);
     k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64,
                                                                                                       count_lo, count_hi, c->list, c->counters + 26, fin_cap);
     HIPCHK(hipGetLastError());
     unsigned long long r[2];
     HIPCHK(hipMemcpyAsync(r, c->counters64, sizeof r, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 26, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints, c->counters + 25, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // undecided, list length
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->host_ints[0] <= fin_cap) { c->list_n = c->host_ints[0]; c->list_valid = true; }   // (else: the next pass compacts the flags itself)
+    if (c->host_ints[0]) return fail(XB_E_STATE, "xb_edge_check: %d edge voxels left undecided", c->host_ints[0]);
+    if (c->host_ints[1] <= fin_cap) { c->list_n = c->host_ints[1]; c->list_valid = true; }   // (else: the next pass compacts the flags itself)
     if (edges) *edges = (int64_t)r[0];
     if (checked) *checked = (int64_t)(r[1] + r[0]);  // refinement.py:479 + 504
     return XB_OK;

@@ -1163,6 +1163,9 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
 #ifndef EC_LANES
 #define EC_LANES 8
 #endif
+#ifndef EC_LONG_N
+#define EC_LONG_N 128   // a queue longer than this takes the lane-per-entry form (measured: 64 / 96 / 128 / 256 / 512 entries)
+#endif
 template <typename Push>
 __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, double inv_nz, int8_t *known, ec_word *pend, ec_word entry,
                                                  int sub, Push push) {
@@ -1217,10 +1220,11 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word
 #define EC_CHASE_THREADS 1024
 #define EC_Q 6000   // queue entries per buffer (2 buffers of 64-bit entries, 94 KB of LDS)
 __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *known, ec_word *pend,
-                                                               const int *__restrict__ seeds, int n_seeds, int *ovf,
+                                                               const int *__restrict__ seeds, const int *n_seeds_dev, int *ovf,
                                                                int *n_ovf, int ovf_cap, int qcap) {
     __shared__ ec_word q[2][EC_Q];
     __shared__ int s_n[2];
+    const int n_seeds = min(*n_seeds_dev, ovf_cap);   // (the count stays on the device: the host does not wait for it)
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
     const int seed_end = min(seed_cur + per, n_seeds);
@@ -1243,7 +1247,7 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                 if (o < ovf_cap) ovf[o] = (int)(unsigned int)u;
             }
         };
-        if (n > 2 * (EC_CHASE_THREADS / EC_LANES)) {   // a long queue (the first rounds): throughput counts, a lane per entry
+        if (n > EC_LONG_N) {   // a long queue (the first rounds): throughput counts, a lane per entry
             for (int e = threadIdx.x; e < n; e += EC_CHASE_THREADS) ec_resolve<false>(g, known, pend, q[cur][e], push);
         } else {                                       // the chains' tail: latency counts, EC_LANES lanes per entry
             for (int e0 = 0; e0 < n; e0 += EC_CHASE_THREADS / EC_LANES) {
