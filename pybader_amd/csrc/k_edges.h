@@ -1196,15 +1196,28 @@ __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, 
     int z = r - y * g.nz;
     if (z < 0) { y--; z += g.nz; } else if (z >= g.nz) { y++; z -= g.nz; }
     const ec_word delta = d == 1 ? 0xFFull : ~0ull;  // +0x100 - 1  |  -1
-    for (int s = sub; s < nl; s += EC_LANES) {   // (a voxel with more later listed neighbours than lanes: another turn)
-        unsigned int m = later;
-        for (int k = 0; k < s; k++) m &= m - 1;
-        const int j = __ffs(m) - 1;
-        const int u = lin3(g, wrapi(x + j / 9 - 1, g.nx), wrapi(y + (j / 3) % 3 - 1, g.ny), wrapi(z + j % 3 - 1, g.nz));
-        const ec_word ow = atomicAdd(pend + u, delta);
-        const unsigned int ob = (unsigned int)ow & 0xffffu;
-        if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1))
-            push((ec_word)((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (ow & 0xFFFFFFFF00000000ull));
+    // a voxel with more later listed neighbours than lanes (9 to 13 of them is common on a dense sheet): a lane takes the
+    // neighbours sub and sub + EC_LANES TOGETHER, both atomics in flight -- two turns one after the other were two round trips
+    unsigned int m = later;
+    for (int k = 0; k < sub; k++) m &= m - 1;
+    for (int s = sub; s < nl; s += 2 * EC_LANES) {
+        const int j0 = __ffs(m) - 1;
+        unsigned int m1 = m;
+        for (int k = 0; k < EC_LANES; k++) m1 &= m1 - 1;
+        const bool two = s + EC_LANES < nl;
+        const int j1 = two ? __ffs(m1) - 1 : j0;
+        const int u0 = lin3(g, wrapi(x + j0 / 9 - 1, g.nx), wrapi(y + (j0 / 3) % 3 - 1, g.ny), wrapi(z + j0 % 3 - 1, g.nz));
+        const int u1 = lin3(g, wrapi(x + j1 / 9 - 1, g.nx), wrapi(y + (j1 / 3) % 3 - 1, g.ny), wrapi(z + j1 % 3 - 1, g.nz));
+        const ec_word o0 = atomicAdd(pend + u0, delta);
+        ec_word o1 = 0;
+        if (two) o1 = atomicAdd(pend + u1, delta);
+        const unsigned int b0 = (unsigned int)o0 & 0xffffu, b1 = (unsigned int)o1 & 0xffffu;
+        if (!(b0 & (EC_NPROC | EC_CLS1)) && (d == 1 || (b0 & EC_CNT) == 1))
+            push((ec_word)((unsigned int)u0 | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o0 & 0xFFFFFFFF00000000ull));
+        if (two && !(b1 & (EC_NPROC | EC_CLS1)) && (d == 1 || (b1 & EC_CNT) == 1))
+            push((ec_word)((unsigned int)u1 | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o1 & 0xFFFFFFFF00000000ull));
+        m = m1;
+        for (int k = 0; k < EC_LANES; k++) m &= m - 1;
     }
 }
 // Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
