@@ -699,14 +699,15 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, defer, fs + FS_R_DEFER,
                                                               regions_ok, nullptr, wl);
-        if (c->grad_cover == 1)   // the few retraces whose walk goes on through a brick without records (count on the device)
+        if (c->grad_cover == 1 && !regions_ok)   // the few retraces whose walk goes on through a brick without records (count on the
+                                                  // device); with regions_ok a retrace stops on such a brick: nothing is deferred
             k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
                                                                fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                                c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, wl);
         // the relabelled start voxels (known == -2 now), listed for the next edge_check in the upper half of `stage`
         if (c->stage_bytes >= 8 * (size_t)c->N)
             k_list_changed<<<1024, TPB, 0, c->stream>>>(c->list, fs + FS_N_EDGES, c->known, (int *)c->stage + c->N, fs + FS_N_CHGLIST,
-                                                        (int)std::min<long long>(c->N, 1LL << 30));
+                                                        (int)std::min<long long>(c->N, 1LL << 30), fs + FS_CHANGED);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 7 * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -603,9 +603,11 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
 
 // The retraces leave known == -2 on exactly the start voxels they relabelled, all of them entries of the edge list: the list of
 // the next edge_check is a pass over that list (round 4) instead of a sweep of the whole grid for the flag and a host wait.
+// (n_changed: the retrace pass's count of relabelled voxels -- none, the usual case after a neargrid assignment: nothing to list)
 __global__ __launch_bounds__(TPB) void k_list_changed(const int *__restrict__ list, const int *n_dev, const int8_t *__restrict__ known,
-                                                      int *__restrict__ out, int *out_count, int out_cap) {
+                                                      int *__restrict__ out, int *out_count, int out_cap, const int *n_changed) {
     __shared__ int s_buf[BlockAppender<1>::CAP], s_n[2];
+    if (*n_changed == 0) return;
     BlockAppender<1> app;
     app.init(s_buf, s_n, out, out_count, out_cap);
     const int n = *n_dev;
