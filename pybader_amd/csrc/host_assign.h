@@ -409,8 +409,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
             if (chase) {   // provisional labels by one chase along the brick potentials instead of ~6 propagation launches
                 k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
-                k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64);
-                k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
+                k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64, fs);
             } else
                 k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
         }
@@ -422,9 +421,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
-        if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
         k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0, chase && launches < long_schedule ? 1 : 0);
         HIPCHK(hipGetLastError());
         stage_done("region growth");
     }
@@ -592,16 +590,14 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
         ScopedTimer t4(c, 4);
         k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
         k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
-        k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64);
-        k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
+        k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64, fs);
         const int long_schedule = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
         const int launches = std::min(long_schedule, c->grow_kill_launches);
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
-        if (launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
         k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0, launches < long_schedule ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     c->grad_valid = false;          // (brick_rec is rewritten: bit 1 = holds a maximum, no records)

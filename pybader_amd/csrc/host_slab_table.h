@@ -117,7 +117,7 @@ int xb_table_finish(xb_ctx *c, const int64_t *seeds, int64_t n_seeds, int64_t an
         for (int l = 0; l < launches; l++)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
         k_fill<int><<<64, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0, 0);
         c->blab = c->blab_buf;
         c->nbk[0] = nb0; c->nbk[1] = nb1; c->nbk[2] = nb2;
         // the bricks of the window (it may wrap round the grid) that lie outside the regions get their records

@@ -165,9 +165,19 @@ __global__ __launch_bounds__(TPB) void k_grow_parent(int nb0, int nb1, int nb2, 
     }
     parent[b] = best;
 }
+// (fs: thread 0 also sets the growth's state for the kill iteration that follows -- the chase has made the provisional labels;
+// a launch of its own for these five words was 5 us of the step)
 __global__ __launch_bounds__(TPB) void k_grow_chase(int nbr, const int *__restrict__ parent, const int *__restrict__ seed, int *__restrict__ lab,
-                                                    int limit) {
+                                                    int limit, int *fs) {
     const int b = blockIdx.x * TPB + threadIdx.x;
+    if (b == 0) {
+        const int n = min(fs[FS_N_SEEDS], XB_REGIONS_MAX);
+        fs[FS_N_SEEDS_EFF] = n;
+        fs[FS_N_BOXES] = n;
+        fs[FS_GROW_PHASE] = n ? 1 : 2;   // nothing to grow without a seed
+        fs[FS_GROW_CONVERGED] = 0;
+        fs[FS_GROW_CUR] = 0;
+    }
     if (b >= nbr) return;
     int p = b, l = 0;
     for (int it = 0; it < limit; it++) {
@@ -178,17 +188,6 @@ __global__ __launch_bounds__(TPB) void k_grow_chase(int nbr, const int *__restri
     }
     lab[b] = l;
 }
-// after the seeds: straight to the kill iteration (the chase has made the provisional labels)
-__global__ void k_seed_finish_kill(int *fs) {
-    const int n = min(fs[FS_N_SEEDS], XB_REGIONS_MAX);
-    fs[FS_N_SEEDS_EFF] = n;
-    fs[FS_N_BOXES] = n;
-    fs[FS_GROW_PHASE] = n ? 1 : 2;   // nothing to grow without a seed
-    fs[FS_GROW_CONVERGED] = 0;
-    fs[FS_GROW_CUR] = 0;
-}
-// the scheduled kill launches are over: did they reach the fixpoint?  (if not, everything downstream is skipped)
-__global__ void k_grow_verdict(int *fs) { fs[FS_GROW_RETRY] = (fs[FS_GROW_PHASE] == 1 && !fs[FS_GROW_CONVERGED]) ? 1 : 0; }
 // blab := the surviving labels (a FIXPOINT of the kill iteration is closed under every move; without one fall
 // back to the seed cubes, which are trapping regions on their own); counts the certain bricks
 // box_first[id] (preset to INT_MAX): the smallest certain brick index of box id + 1 -- without vacuum every voxel of
@@ -197,9 +196,13 @@ __global__ void k_grow_verdict(int *fs) { fs[FS_GROW_RETRY] = (fs[FS_GROW_PHASE]
 __global__ __launch_bounds__(TPB) void k_grow_finish(int nbr, const int *__restrict__ seed, const int *__restrict__ buf0,
                                                      const int *__restrict__ buf1, int *fs, int *__restrict__ blab,
                                                      int *box_first, const int *__restrict__ bmask, unsigned char *brick_rec,
-                                                     int seeds_fixed) {
+                                                     int seeds_fixed, int verdict) {
     __shared__ int s_first[XB_BOXES_MAX];
-    if (fs[FS_GROW_RETRY]) return;
+    // verdict: the scheduled kill launches are over -- did they reach the fixpoint?  If not, everything downstream is skipped
+    // (FS_GROW_RETRY) and the host repeats the assignment with the long schedule.  Every block sees the same state.
+    const bool retry = verdict ? (fs[FS_GROW_PHASE] == 1 && !fs[FS_GROW_CONVERGED]) : fs[FS_GROW_RETRY] != 0;
+    if (verdict && blockIdx.x == 0 && threadIdx.x == 0) fs[FS_GROW_RETRY] = retry ? 1 : 0;
+    if (retry) return;
     // without a fixpoint only closed cubes are regions on their own; seed BRICKS alone certify nothing
     const int *src = fs[FS_GROW_CONVERGED] ? (fs[FS_GROW_CUR] ? buf1 : buf0) : seed;
     const int nbx = (fs[FS_GROW_CONVERGED] || seeds_fixed) ? fs[FS_N_BOXES] : 0;

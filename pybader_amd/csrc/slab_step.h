@@ -318,8 +318,7 @@ int xb_slab_assign_trace(xb_ctx *c) {
         k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
         if (chase) {
             k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
-            k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64);
-            k_seed_finish_kill<<<1, 1, 0, c->stream>>>(fs);
+            k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64, fs);
         } else
             k_seed_finish<<<1, 1, 0, c->stream>>>(fs);
         const int long_schedule = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
@@ -327,9 +326,8 @@ int xb_slab_assign_trace(xb_ctx *c) {
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
-        if (chase && launches < long_schedule) k_grow_verdict<<<1, 1, 0, c->stream>>>(fs);
         k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
-        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0);
+        k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0, chase && launches < long_schedule ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     c->blab = c->blab_buf;
