@@ -239,6 +239,8 @@ int xb_host_waits(int64_t *n);
  * (gradient field + trapping regions), 5 k_grad_field alone, 6 k_ng_trace alone. */
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
+/* on: 0 off, 1 every timer, otherwise a mask: bit k + 1 switches timer `which` = k on (event pairs between dependent kernels
+ * cost stream time: a benchmark keeps only the dominant kernel's timer on inside its timed region) */
 int xb_enable_timing(xb_ctx *c, int on);
 /* Switches.  A USER of the library sets none of them: every default is the measured best, and no switch changes a result.
  * What each is for:

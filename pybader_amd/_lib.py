@@ -583,8 +583,10 @@ class Context:
         check(self.lib.xb_comm_stats(self.h, C.byref(n)))
         return int(n.value)
 
-    def enable_timing(self, on=True):
-        check(self.lib.xb_enable_timing(self.h, int(on)))
+    def enable_timing(self, on=True, only=None):
+        """on: all timers; only=[k, ...]: just these (xb_kernel_time's `which`)"""
+        mask = int(bool(on)) if only is None else sum(2 << int(k) for k in only)
+        check(self.lib.xb_enable_timing(self.h, mask))
 
     def kernel_time(self, which):
         ms, n = C.c_double(), C.c_int64()

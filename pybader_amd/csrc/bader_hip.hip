@@ -176,7 +176,7 @@ struct xb_ctx {
     int chg_n = -1;            // >= 0: the upper half of `stage` lists the chg_n voxels the last retrace pass relabelled (all known == -2 voxels)
     int list_n = 0;            // entries of `list` that hold the owned known == -2 voxels ...
     bool list_valid = false;   // ... when this is set (by xb_edge_find)
-    bool timing = false;
+    unsigned timing = 0;   // bit k: timer k records its events (xb_enable_timing)
     TimedKernel tk[8];
     long long n_alloc = 0;
 };
@@ -254,14 +254,14 @@ struct ScopedTimer {
     int which;
     hipEvent_t a = nullptr, b = nullptr;
     ScopedTimer(xb_ctx *c_, int w) : c(c_), which(w) {
-        if (c->timing) {
+        if ((c->timing >> which) & 1u) {
             hipEventCreate(&a);
             hipEventCreate(&b);
             hipEventRecord(a, c->stream);
         }
     }
     ~ScopedTimer() {
-        if (c->timing) {
+        if ((c->timing >> which) & 1u) {
             hipEventRecord(b, c->stream);
             c->tk[which].pending.push_back({a, b});
         }
@@ -363,7 +363,9 @@ int xb_debug_counts(unsigned long long *out, int reset) {
 #endif
 int xb_enable_timing(xb_ctx *c, int on) {
     if (!c) return fail(XB_E_ARG, "null ctx");
-    c->timing = on != 0;
+    // 0: off; 1: every timer; otherwise bit k + 1 switches timer k on (an event pair costs ~10 us of an idle stream between
+    // dependent kernels: a benchmark times its step with the dominant kernel's timer alone)
+    c->timing = on == 0 ? 0u : (on == 1 ? 0xFFFFu : ((unsigned)on >> 1));
     return XB_OK;
 }
 int xb_kernel_time_reset(xb_ctx *c) {
