@@ -230,6 +230,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-config5', action='store_true', help='skip the ongrid configuration timed after the headline one')
     ap.add_argument('--no-dropin', action='store_true', help='skip the thread_handlers leg on the 216-atom 256^3 density')
+    ap.add_argument('--no-stage-steps', action='store_true', help='skip the 3 extra steps that time the other stages (profiler runs: only warm-up + timed steps on the card)')
     ap.add_argument('--no-odd', action='store_true', help='skip the leg on a grid that is not made of whole 8^3 bricks (500 x 504 x 420)')
     ap.add_argument('--halo', type=int, default=None,
                     help='label planes valid each side of a slab (default 16 for N > 1: a retrace stops when it enters a '
@@ -359,7 +360,7 @@ def main():
     dom_time = ctx.kernel_time(dom_timer)
     ctx.enable_timing(True)
     ctx.kernel_time_reset()
-    for _ in range(3):
+    for _ in range(0 if args.no_stage_steps else 3):
         step()
     fence()
     tm = {name: ctx.kernel_time(i) for i, name in enumerate(stage_names)}
