@@ -452,3 +452,30 @@ def test_brick_uniformity_left_by_the_walkers_equals_the_label_scan():
     ctx.close()
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def test_host_waits_of_one_gpu_steps():
+    """Round 4: the one-GPU pipeline waits for the card once per assignment (neargrid and ongrid), once per fused refinement
+    iteration, twice per edge_check (did the chase's LDS queues spill? + the results) and once per retrace pass after it."""
+    shape = (128,) * 3
+    dm, tg = matrices(shape, synth.CUBIC6)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
+    ctx.vacuum_assign(None, 1.0)
+    ctx.assign('neargrid')                    # (first call: allocations)
+    for method, want_assign in (('neargrid', 1), ('ongrid', 1)):
+        ctx.set_option(6, 1)
+        ctx.vacuum_assign(None, 1.0)
+        w0 = ctx.host_waits()
+        ctx.assign(method)
+        w1 = ctx.host_waits()
+        log = ctx.refine('changed', 2)
+        w2 = ctx.host_waits()
+        assert w1 - w0 == want_assign, (method, w1 - w0)
+        if log and log[0][1] and len(log) == 2:          # an iteration through edge_check + retraces
+            assert w2 - w1 == 1 + 2 + 1, (method, w2 - w1, log)
+        else:                                            # nothing changed: the second iteration is the identity
+            assert w2 - w1 == 1, (method, w2 - w1, log)
+    ctx.close()
+
