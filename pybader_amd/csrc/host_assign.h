@@ -300,7 +300,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
             // brick counts as mixed -- right whatever the peers' halo planes bring, and no pass over the labels
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
-            k_fill<int><<<64, TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
+            k_fill<int><<<(nbr + 4 * TPB - 1) / (4 * TPB), TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
             k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr);
             if (c->n_walk)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
