@@ -233,10 +233,10 @@ int xb_slab_block_copy(xb_ctx *c, int which, int to_device, void *host, int64_t 
 int xb_host_waits(int64_t *n);
 
 /* ---- measurement ------------------------------------------------------------------------- */
-/* HIP-event timing of the dominant kernel, measured on the context's stream: accumulated
- * milliseconds and launch count since the last reset.  which: 0 neargrid assignment after the table
- * (region fill + walker trace), 1 ongrid pointer, 2 edge_find, 3 refine trace, 4 whole table build
- * (gradient field + trapping regions), 5 k_grad_field alone, 6 k_ng_trace alone. */
+/* HIP-event timing of the stages, measured on the context's stream: accumulated milliseconds and launch
+ * count since the last reset.  which: 0 neargrid assignment after pass A (walk list, records, walker trace),
+ * 1 the ongrid pointer pass (k_og_masks), 2 edge_find, 3 refine trace, 4 pass A + region growth (and records built
+ * for a refinement), 5 k_brick_masks alone, 6 the trace kernel alone, 7 k_brick_records alone. */
 int xb_kernel_time(xb_ctx *c, int which, double *ms_total, int64_t *launches);
 int xb_kernel_time_reset(xb_ctx *c);
 /* on: 0 off, 1 every timer, otherwise a mask: bit k + 1 switches timer `which` = k on (event pairs between dependent kernels

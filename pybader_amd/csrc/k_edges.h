@@ -1170,7 +1170,7 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
 // work, so the hop lasts as long as that wave's longest dependent instruction chain -- and walked by one lane, the ten
 // notifications of a voxel (decode with two integer divisions, nine row bases, ten address computations, ten wake tests, the
 // pushes) were ~700 instructions, 1.3 of the 3.0 us per hop; a device-scope atomic with its result takes 0.4-0.7 us on this
-// card and a pair of barriers 0.08 (scratch microbenchmark).  Sixteen lanes cut the chain to ~100 instructions.
+// card and a pair of barriers 0.08 (tools/ubench_rtt.hip).  Sixteen lanes cut the chain to ~100 instructions.
 #ifndef EC_LANES
 #define EC_LANES 8
 #endif

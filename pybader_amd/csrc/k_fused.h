@@ -14,7 +14,7 @@ enum {
     FS_N_SEEDS = 0,      // 26-neighbour maxima appended by the table pass (raw count, may exceed the capacity)
     FS_TIES,             // != 0: some voxel's record depends on the tie rule
     FS_N_SEEDS_EFF,      // seeds used for boxes (0 when there are none or too many)
-    FS_N_BOXES,          // closed seed cubes found
+    FS_N_BOXES,          // trapping regions (seed bricks that may grow one)
     FS_GROW_PHASE,       // 0 propagate, 1 kill, 2 done
     FS_GROW_CHANGED,     // a block of the current launch changed a label
     FS_GROW_TICKET,      // blocks of the current launch that have finished
