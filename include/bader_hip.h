@@ -48,7 +48,10 @@ void *xb_stream(xb_ctx *c);                      /* the hipStream_t every kernel
  * passes to every kernel (Bader.distance_matrix interface.py:242-259, Bader.T_grad 285-290):
  * dist_mat[27] row-major [3][3][3] with index 2 == -1; T_grad[9] row-major.  Allocates/reuses
  * device buffers.  x-slab [x0,x1) is the range of axis-0 planes this context owns (multi-GPU
- * slab scheduler; x0=0,x1=nx for one GPU).  Every rank holds the full density. */
+ * slab scheduler; x0=0,x1=nx for one GPU).  Every rank holds the full density.
+ * SIZE LIMIT (the reference indexes with int64 throughout, methods.py / refinement.py): voxel indices are int32 on the
+ * device, so a grid needs nx*ny*nz < 2^31 - 1 voxels (1024^3 = 2^30 fits; 1290^3 is the largest cube) -- more returns
+ * XB_E_LIMIT before anything is allocated.  'changed' refinement (xb_edge_check*) stops at 2^30 voxels, see there. */
 int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], const double T_grad[9],
                 int64_t x0, int64_t x1);
 int xb_upload_density(xb_ctx *c, const double *rho_host);           /* H2D, nx*ny*nz float64 */
@@ -133,7 +136,10 @@ int xb_walkers_count(xb_ctx *c, int64_t *n_walkers, int64_t *n_results);
 int xb_walkers_fetch(xb_ctx *c, int64_t *walkers, int64_t *results);
 int xb_walkers_continue(xb_ctx *c, const int64_t *walkers, int64_t n);
 int xb_walkers_apply(xb_ctx *c, const int64_t *results, int64_t n, int64_t *changed, int64_t *stuck);
-/* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels) */
+/* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels).
+ * SIZE LIMIT: at most 2^30 voxels (1024^3 is exactly the last size): the seed / overflow lists of the dependency chase keep
+ * two flag bits beside the voxel index in a 32-bit entry.  A larger grid returns XB_E_LIMIT (xb_refine in 'changed' mode
+ * with it; refine mode 'all' has no such limit below xb_set_grid's). */
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
 /* refinement.edge_check across slabs ('changed' refinement on N GPUs): the greedy scan of refinement.py:420-427 is
  * global, so every rank resolves the global list of changed voxels.  _local: the owned changed voxels and their
@@ -192,6 +198,12 @@ int64_t xb_plane_elems(xb_ctx *c);
 /* copy whole x-planes [xa,xb) of labels/known between host and device (halo transport over the
  * host / gloo; the RCCL transport works on the device pointers above) */
 int xb_copy_planes(xb_ctx *c, int which /*0 labels,1 known*/, int to_device, void *host, int64_t xa, int64_t xb);
+/* Bytes per label (1 / 2 / 4) a label halo travels in (xb_comm_exchange_planes): the narrowest signed width that holds every
+ * resident label -- the reference's own dtype_calc(-n_maxima) (thread_handlers.py:70-74, utils.py:25-37).  Sender and
+ * receiver must agree on it.  It changes only in calls all ranks make alike (numbering, xb_upload_labels,
+ * xb_vacuum_assign, xb_volume_assign); xb_scatter_voxels / xb_copy_planes widen it only when a label they write does not fit.
+ * widen_to 1 / 2 / 4 raises it (0: only ask): after a per-rank write a scheduler sets the maximum over the ranks. */
+int xb_label_wire(xb_ctx *c, int widen_to, int *wire_out);
 /* the chunk [first, first+count) of the per-brick move masks (xb_brick_masks) and of the bricks' single-maximum voxels
  * (2 * count ints: masks, then voxels) from (to_device 1) or to (0) host memory -- the host-staged fallback of xb_comm_share_brick_masks */
 int xb_brick_masks_copy(xb_ctx *c, int to_device, int32_t *host, int64_t first, int64_t count);

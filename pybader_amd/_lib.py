@@ -71,6 +71,7 @@ SYMBOLS = {
     'xb_density_ptr': (_vp, [_vp]),
     'xb_plane_elems': (_i64, [_vp]),
     'xb_copy_planes': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
+    'xb_label_wire': (_int, [_vp, _int, _vp]),
     'xb_brick_masks_copy': (_int, [_vp, _int, _vp, _i64, _i64]),
     'xb_set_halo': (_int, [_vp, _i64]),
     'xb_kernel_time': (_int, [_vp, _int, _pdbl, _pi64]),
@@ -333,6 +334,12 @@ class Context:
         lab = np.ascontiguousarray(labels, np.int32)
         kn = np.ascontiguousarray(known, np.int8)
         check(self.lib.xb_scatter_voxels(self.h, _ptr(idx), idx.size, _ptr(lab), _ptr(kn)))
+
+    def label_wire(self, widen_to=0):
+        """bytes per label of a label halo on the wire; `widen_to` raises it (the ranks of a slab run must agree)"""
+        w = C.c_int()
+        check(self.lib.xb_label_wire(self.h, int(widen_to), C.byref(w)))
+        return w.value
 
     WALKER_WORDS = 10
 

@@ -170,7 +170,9 @@ struct xb_ctx {
     std::vector<int> maxima_sorted;  // global, label order
     int label_wire = 4;        // bytes per label that hold EVERY resident label (1 / 2 / 4): what the narrowed halo may travel in.
                                // Follows whoever wrote the labels last: an assignment (dtype_calc(-n_maxima)), an upload (its dtype),
-                               // volume_assign (the largest atom index); planes or voxels written from outside make it 4
+                               // volume_assign (the largest atom index) -- calls every rank of a slab run makes alike, so the
+                               // ranks agree on it (send / receive sizes).  Planes or voxels written from outside widen it only
+                               // if one of their labels does not fit; xb_label_wire lets a scheduler agree on the maximum
     std::vector<int> local_max, local_first;
     bool first_clean = false;
     int chg_n = -1;            // >= 0: the upper half of `stage` lists the chg_n voxels the last retrace pass relabelled (all known == -2 voxels)
@@ -183,6 +185,12 @@ struct xb_ctx {
 
 // utils.dtype_calc(-n) as a byte width (utils.py:25-37): the narrowest signed type for labels 0..n-1 and -1
 static inline int label_wire_for(long long n) { return 2 * n <= 255 ? 1 : (2 * n <= 65535 ? 2 : 4); }
+// the narrowest signed width that holds each of n labels (host array)
+static inline int labels_fit_wire(const int32_t *lab, long long n) {
+    int32_t lo = 0, hi = 0;
+    for (long long i = 0; i < n; i++) { lo = std::min(lo, lab[i]); hi = std::max(hi, lab[i]); }
+    return (lo >= -128 && hi <= 127) ? 1 : ((lo >= -32768 && hi <= 32767) ? 2 : 4);
+}
 static inline unsigned nblocks(long long n) { return (unsigned)((n + TPB - 1) / TPB); }
 static GridL light(const Grid &g) {
     GridL l;
@@ -353,9 +361,9 @@ int xb_brick_labels(xb_ctx *c, int32_t *out, int64_t capacity, int64_t dims[3]) 
 #ifdef XB_DEBUG_COUNT
 int xb_debug_counts(unsigned long long *out, int reset) {
     hipDeviceSynchronize();
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(xb_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return XB_E_HIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(xb_dbg), sizeof(unsigned long long) * 4096) != hipSuccess) return XB_E_HIP;
     if (reset) {
-        unsigned long long z[16] = {0};
+        static unsigned long long z[4096];
         if (hipMemcpyToSymbol(HIP_SYMBOL(xb_dbg), z, sizeof z) != hipSuccess) return XB_E_HIP;
     }
     return XB_OK;

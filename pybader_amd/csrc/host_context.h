@@ -446,6 +446,7 @@ int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {
     if (dtype == XB_I32) {
         if (int rc = staged_d2h(c, labels_host, c->labels, c->N * 4)) return rc;
     } else {
+        c->chg_n = -1;   // (the narrowing goes through `stage`, whose upper half may list the changed voxels)
         const long long per = std::max<long long>(1, (long long)(c->stage_bytes / sz));
         for (long long o = 0; o < c->N; o += per) {
             const long long n = std::min(per, c->N - o);

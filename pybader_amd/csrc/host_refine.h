@@ -111,6 +111,7 @@ int xb_edge_find(xb_ctx *c, int64_t *edges) {
     NEED_GRID("xb_edge_find");
     const Grid &g = c->g;
     bool dilate_owned = false;
+    c->chg_n = -1;   // `known` is rewritten: the changed-voxel list of an earlier retrace pass no longer describes it
     if (int rc = edge_find_launch(c, &dilate_owned)) return rc;
     int n = 0;
     if (int rc = read_counter(c, 5, &n)) return rc;
@@ -227,7 +228,11 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         c->list_valid = false; c->chg_n = -1;
         c->buni_valid = false; c->regions_labels = false;
         c->zero_outside[0] = -1;
-        c->label_wire = 4;
+        // The halo's wire width is a value every rank must agree on (ncclSend / ncclRecv sizes): a scatter is a per-rank event
+        // (only the ranks with parked retraces scatter), so it does NOT widen it -- the labels it writes are labels
+        // already present on the grid.  Only a label the resident width cannot hold widens it (raw API use); a scheduler then
+        // agrees on the width with xb_label_wire before its next exchange (slab.py does).
+        c->label_wire = std::max(c->label_wire, labels_fit_wire(lab, n));
     } else {
         if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
         if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -484,8 +489,11 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
             k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->known, pend_w, buf[pass & 1], cnt_in, buf[1 - (pass & 1)], cnt_out,
                                                                    cap, c->opt_ec_qcap);
             HIPCHK(hipGetLastError());
+            // (with the first pass's overflow count also k_ec_first's own seed count: k_ec_chase clamps what it reads to the
+            // list's capacity, so a list that was too small must fail HERE, not later as "undecided" -- ADVICE r4)
+            if (pass == 0) HIPCHK(hipMemcpyAsync(c->host_ints + 1, c->counters + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             if (int rc = read_counter(c, (pass & 1) ? 6 : 24, &n_seeds)) return rc;
-            if (n_seeds > cap) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
+            if (n_seeds > cap || (pass == 0 && c->host_ints[1] > cap)) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
             if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d overflowed (%d groups)\n", pass, n_seeds, groups);
         }
     }
@@ -731,7 +739,15 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
     return XB_OK;
 }
 
+static int refine_impl(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters);
 int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
+    const int rc = refine_impl(c, mode, iters, log, log_capacity, n_iters);
+    // the changed-voxel list in `stage` is private to this call's iterations: a later xb_edge_check through the C ABI compacts
+    // known == -2 itself instead of trusting a list that other calls (downloads through `stage`, xb_edge_find) may have clobbered
+    if (c) c->chg_n = -1;
+    return rc;
+}
+static int refine_impl(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
     NEED_GRID("xb_refine");
     if (n_iters) *n_iters = 0;
     if (iters == 0) return XB_OK;  // thread_handlers.py:146-147

@@ -171,13 +171,30 @@ int xb_copy_planes(xb_ctx *c, int which, int to_device, void *host, int64_t xa, 
     char *dev = which == 0 ? (char *)c->labels : (char *)c->known;
     const size_t off = (size_t)xa * c->g.nyz * es, bytes = (size_t)(xb - xa) * c->g.nyz * es;
     // (a slab's halo planes come from peers that ran the same assignment: the regions' labels stay what they are)
-    if (to_device && which == 0) { c->zero_outside[0] = -1; c->label_wire = 4; }   // (planes from outside: any label may arrive)
+    // (planes from outside: any label may arrive -- but the halo's wire width must stay a collectively agreed value, so it is
+    // widened only when a label of these planes does not fit it: never for planes of peers that ran the same assignment)
+    if (to_device && which == 0) {
+        c->zero_outside[0] = -1;
+        c->label_wire = std::max(c->label_wire, labels_fit_wire((const int32_t *)host, (xb - xa) * c->g.nyz));
+    }
     if (to_device) { c->list_valid = false; c->chg_n = -1; c->has_vacuum = c->has_vacuum || c->g.x1 - c->g.x0 == c->g.nx;
                      c->buni_valid = c->buni_valid && c->buni_halo_safe && c->g.x1 - c->g.x0 < c->g.nx;
                      if (c->g.x1 - c->g.x0 == c->g.nx) c->regions_labels = false; }
     if (to_device) HIPCHK(hipMemcpyAsync(dev + off, host, bytes, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(host, dev + off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return XB_OK;
+}
+
+// The narrowest signed width (1 / 2 / 4 bytes) that holds every resident label: what a label halo travels in
+// (xb_comm_exchange_planes).  It changes in calls that every rank of a slab run makes with the same arguments (numbering,
+// uploads, vacuum_assign, volume_assign); `widen_to` (1, 2, 4; 0: only ask) raises it so that a scheduler can make the ranks
+// agree after a per-rank event (max over the ranks) -- send and receive sizes must match.
+int xb_label_wire(xb_ctx *c, int widen_to, int *wire_out) {
+    if (!c) return fail(XB_E_ARG, "xb_label_wire: null context");
+    if (widen_to != 0 && widen_to != 1 && widen_to != 2 && widen_to != 4) return fail(XB_E_ARG, "xb_label_wire: width must be 0, 1, 2 or 4");
+    c->label_wire = std::max(c->label_wire, widen_to);
+    if (wire_out) *wire_out = c->label_wire;
     return XB_OK;
 }
 

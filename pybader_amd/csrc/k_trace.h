@@ -495,6 +495,12 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
     __shared__ int s_w[8], s_mixed;
     constexpr bool CACHE = LEAN >= 3;
     int prev_brick = -1;
+#ifdef XB_DEBUG_COUNT   // time probes (tools/trace_probe.py): where do the waves of the persistent trace spend their cycles?
+    const long long pr_t0 = clock64();
+    long long pr_walk = 0, pr_wait = 0, pr_load = 0;
+    int pr_bricks = 0;
+    if (threadIdx.x == 0) atomicMax(&xb_dbg[20], (1ull << 62) - (unsigned long long)wall_clock64());   // (the earliest start, as a maximum: the counters reset to zero)
+#endif
     const int n_items = fs[FS_N_WALK] * 8;
     const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
     const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
@@ -503,7 +509,13 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
         const int q = (home + r) & 7;
         const int beg = q * per, end = min(beg + per, n_items);
         for (;;) {
+#ifdef XB_DEBUG_COUNT
+            const long long pr_a = clock64();
+#endif
             __syncthreads();   // the previous chunk's readers are done with s_base / s_next
+#ifdef XB_DEBUG_COUNT
+            pr_wait += clock64() - pr_a;
+#endif
             if (threadIdx.x == 0) {
                 if (CACHE && bres) {
                     if (prev_brick >= 0) {
@@ -522,6 +534,10 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
             const int base = s_base;
             if (base >= end) break;   // uniform over the workgroup
             const int stop = min(base + CH, end);
+#ifdef XB_DEBUG_COUNT
+            const long long pr_b = clock64();
+            pr_bricks++;
+#endif
             if (CACHE) {   // (CH == 8, base a multiple of 8: one brick) thread t copies the record of voxel t of the brick
                 const int b = walk[base >> 3];
                 prev_brick = b;
@@ -533,6 +549,9 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 xb_s_rec[t] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
                 __syncthreads();
             }
+#ifdef XB_DEBUG_COUNT
+            pr_load += clock64() - pr_b;
+#endif
             for (;;) {
                 int i = 0;
                 if (lane == 0) i = atomicAdd(&s_next, 1);
@@ -545,8 +564,14 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                 // change nothing, and the brick's verdict below still speaks of its voxels inside the grid only
                 if (PART) { sx = min(sx, g.nx - 1); sy = min(sy, g.ny - 1); sz = min(sz, g.nz - 1); }
                 if (LEAN) {
+#ifdef XB_DEBUG_COUNT
+                    const long long pr_c = clock64();
+#endif
                     const int res = ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                                                 max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
+#ifdef XB_DEBUG_COUNT
+                    pr_walk += clock64() - pr_c;
+#endif
                     if (CACHE && bres) {
                         volatile int *w = s_w;
                         if (lane == 0) w[item & 7] = res;
@@ -559,6 +584,16 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
             }
         }
     }
+#ifdef XB_DEBUG_COUNT
+    if (lane == 0) {
+        atomicAdd(&xb_dbg[16], (unsigned long long)pr_walk);
+        atomicAdd(&xb_dbg[17], (unsigned long long)(clock64() - pr_t0));
+        atomicAdd(&xb_dbg[18], (unsigned long long)pr_wait);
+        atomicAdd(&xb_dbg[19], (unsigned long long)pr_load);
+        atomicAdd(&xb_dbg[21], 1ull);
+        if (threadIdx.x == 0) { atomicAdd(&xb_dbg[22], (unsigned long long)pr_bricks); if (blockIdx.x < 2048) xb_dbg[64 + blockIdx.x] = (unsigned long long)wall_clock64(); }
+    }
+#endif
     if (CACHE && bres) {   // the last brick this workgroup walked
         __syncthreads();
         if (threadIdx.x == 0 && prev_brick >= 0) {

@@ -426,8 +426,18 @@ class SlabRunner:
                       file=sys.stderr, flush=True)
             total += moved
             if self.comm.sum(open_)[0] == 0:
+                self._agree_label_wire()
                 return total
         raise RuntimeError('escaped retraces unresolved after full-length path queries')
+
+    def _agree_label_wire(self):
+        """Only the ranks with parked retraces wrote voxels (scatter_voxels): the width a label halo travels in must be the
+        same on both ends of every send / receive pair, so the ranks take the maximum of theirs (the library
+        widens on such a write only when a label does not fit, so this is normally a no-op)."""
+        wire = getattr(self.be, 'label_wire', None)
+        if wire is None or self.comm.size == 1:
+            return
+        self.be.label_wire(max(int(w) for w in self.comm.allgather(int(wire()))))
 
     def _ask_owners(self, starts, offsets, vox, complete):
         nyz = self.shape[1] * self.shape[2]

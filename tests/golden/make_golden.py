@@ -107,6 +107,37 @@ def own_trajectory(b, main):
     return v
 
 
+def run_default_vs_converged(name, shape, lattice, atoms=synth.ATOMS8, vacuum_tol=None, **_):
+    """Round 5: where the reference's default ('changed', 2) stops unconverged (1024^3: its log ends
+    [377, 4]) the voxels on which its map differs from its own converged ('changed', -1) map are stored -- linear
+    indices, the reference's labels in both maps -- and ADDED to the existing fixture after checking that both maps
+    hash to what the full run of `run_case` recorded.  Only the neargrid leg of run_case is repeated."""
+    t0 = time.time()
+    path = os.path.join(HERE, name + '.npz')
+    out = dict(np.load(path))
+    lattice = np.asarray(lattice, np.float64)
+    rho = synth.synth_density(shape, lattice, atoms)
+    assert sha(rho) == str(out['rho_sha256'])
+    with nostdout():
+        b = make_bader(rho, lattice, synth.atoms_cartesian(atoms, lattice), vacuum_tol=vacuum_tol)
+        b.volumes_init()
+        b.bader_calc()
+        main = b.bader_volumes.copy()
+        assert sha(main) == str(out['ng_main_sha256'])
+        v2 = main.copy()
+        thread_handlers.refine('neargrid', ('changed', 2), b.reference, v2, b.distance_matrix, b.T_grad, 1)
+        assert sha(v2) == str(out['ng_changed_2_sha256'])
+        vc = main
+        thread_handlers.refine('neargrid', ('changed', -1), b.reference, vc, b.distance_matrix, b.T_grad, 1)
+        assert sha(vc) == str(out['ng_changed_inf_sha256'])
+    idx = np.flatnonzero(v2.ravel() != vc.ravel()).astype(np.int64)
+    out['ng_changed_2_vs_inf_idx'] = idx
+    out['ng_changed_2_vs_inf_default_labels'] = v2.ravel()[idx].astype(np.int64)
+    out['ng_changed_2_vs_inf_converged_labels'] = vc.ravel()[idx].astype(np.int64)
+    np.savez_compressed(path, **out)
+    print(f"{name}: default vs converged: {idx.size} voxels differ {idx.tolist()[:16]}; {time.time() - t0:.1f}s", flush=True)
+
+
 def run_case(name, shape, lattice, atoms=synth.ATOMS8, vacuum_tol=None, full_maps=True, do_F=True,
              modes=(('changed', 2), ('changed', -1), ('all', -1), ('all', 2))):
     t0 = time.time()
@@ -476,6 +507,9 @@ CASES = {
     # round 4: the headline size itself (BASELINE configs 3 and 5), hashes only
     'c512_cubic': dict(shape=(512, 512, 512), lattice=synth.CUBIC6, full_maps=False, do_F=True,
                        modes=(('changed', 2),)),
+    # round 5: a large NON-cubic pin -- the generic Grid instantiations (no mirror prefilter, full T_grad) above 128^3
+    'c320_tric': dict(shape=(320, 320, 320), lattice=synth.TRICLINIC, full_maps=False, do_F=True,
+                      modes=(('changed', 2),)),
     # (the reference's default two iterations do not converge here -- its log ends with 33 relabelled voxels -- so the converged
     # ('changed', -1) result is captured as well: that one is the own-trajectory map)
     'c1024_cubic': dict(shape=(1024, 1024, 1024), lattice=synth.CUBIC6, full_maps=False, do_F=False,
@@ -519,5 +553,11 @@ if __name__ == '__main__':
             run_contract_case()
         elif name in ROUGH:
             run_rough_case(name, **ROUGH[name])
+        elif name.endswith(':default_vs_converged'):
+            c = dict(CASES[name.split(':')[0]])
+            run_default_vs_converged(name.split(':')[0], **{k: c[k] for k in ('shape', 'lattice', 'atoms', 'vacuum_tol') if k in c})
         else:
             run_case(name, **CASES[name])
+            if ('changed', 2) in CASES[name].get('modes', ()) and ('changed', -1) in CASES[name].get('modes', ()) \
+                    and not CASES[name].get('full_maps', True):
+                run_default_vs_converged(name, **CASES[name])

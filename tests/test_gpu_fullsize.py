@@ -212,10 +212,11 @@ def test_config4_1024_one_gpu_four_and_eight_slabs():
 def test_config4_1024_against_the_reference():
     """BASELINE config 4's grid against what pybader itself returns on it (tests/golden/c1024_cubic.npz: 1.6 h of the
     reference's numba path, hashes + logs + maxima + charges).  ongrid + refinement: bit for bit.  neargrid: the reference's
-    default two iterations do NOT converge at this size (its log ends with 33 relabelled voxels; iterated on it needs four:
-    [377, 4], [72, 0]), so its ('changed', 2) map is not yet the own-trajectory map this library returns: the basin volumes
-    differ by a handful of voxels of 2^30 (asserted below), the per-basin charges agree far inside north_star's 1e-6 -- and
-    the reference's CONVERGED ('changed', -1) map is this library's map bit for bit (hash)."""
+    default two iterations do NOT converge at this size -- its log ends with 33 relabelled voxels; iterated on it needs four:
+    [377, 4], [72, 0] -- so its ('changed', 2) map is not yet the own-trajectory map this library returns.  Pinned EXACTLY
+    (round 5): the fixture names the 4 voxels (of 2^30) on which the reference's default map differs from its own
+    converged ('changed', -1) map, with its labels in both; this library's map is the converged one bit for bit (hash), and with
+    exactly those 4 voxels set to the reference's default labels it hashes to the reference's default map."""
     g = load_golden('c1024_cubic')
     shape = tuple(int(x) for x in g['shape'])
     ctx = _lib.Context(0)
@@ -231,10 +232,22 @@ def test_config4_1024_against_the_reference():
     log = ctx.refine('changed', 2)
     assert all(c == 0 for _, c in log)
     ch, vo = ctx.charge_sum(vv, n)
-    moved = np.abs(np.round((vo - g['ng_bader_volume']) / vv)).astype(np.int64)
-    assert int(g['ng_changed_2_log'][-1, 1]) == 33 and 0 < moved.sum() <= 66, moved      # (each of the 33 can move two counts)
+    lab = ctx.download_labels(np.int8)
+    assert sha(lab) == str(g['ng_changed_inf_sha256'])                      # == the reference's converged map
+    idx, ref_default, ref_conv = g['ng_changed_2_vs_inf_idx'], g['ng_changed_2_vs_inf_default_labels'], g['ng_changed_2_vs_inf_converged_labels']
+    assert idx.size == 4 and int(g['ng_changed_inf_log'][2, 1]) == 4      # the reference's own log: 4 voxels were still to move
+    flat = lab.reshape(-1)
+    assert np.array_equal(flat[idx], ref_conv)
+    flat[idx] = ref_default.astype(np.int8)
+    assert sha(lab) == str(g['ng_changed_2_sha256'])                        # == the reference's default-mode map, those 4 voxels apart
+    # per-basin volumes differ by exactly those voxels, the charges far inside north_star's 1e-6
+    want = g['ng_bader_volume'] / vv
+    moved = np.zeros(n)
+    np.add.at(moved, ref_default, 1.0)
+    np.add.at(moved, ref_conv, -1.0)
+    np.testing.assert_allclose(vo / vv + moved, want, rtol=0, atol=0.5)
     np.testing.assert_allclose(ch, g['ng_bader_charge'], rtol=1e-6)
-    assert sha(ctx.download_labels(np.int8)) == str(g['ng_changed_inf_sha256'])
+    del lab, flat
     ctx.vacuum_assign(None, vv)
     ctx.assign('ongrid')
     assert np.array_equal(ctx.maxima(), g['og_bader_max'])
@@ -479,3 +492,17 @@ def test_host_waits_of_one_gpu_steps():
             assert w2 - w1 == 1, (method, w2 - w1, log)
     ctx.close()
 
+
+
+def test_size_limits_fail_loudly():
+    """the reference indexes with int64 (refinement.py:409-508, methods.py); this library's voxel indices are
+    int32 and 'changed' refinement keeps two flag bits beside them.  Both limits are stated at the boundary
+    (include/bader_hip.h) and must come back as errors, never as wrapped indices."""
+    ctx = _lib.Context(0)
+    dm, tg = matrices((8, 8, 8), synth.CUBIC6)
+    with pytest.raises(_lib.BaderHipError, match='int32 index range'):
+        ctx.set_grid((2048, 1024, 1024), dm, tg)                      # 2^31 voxels: refused before anything is allocated
+    ctx.set_grid((1032, 1024, 1024), dm, tg)                          # 2^30 + 2^23 voxels: fine for everything ...
+    with pytest.raises(_lib.BaderHipError, match='2\\^30 voxels'):
+        ctx.edge_check()                                              # ... but refinement.edge_check
+    ctx.close()

@@ -140,7 +140,7 @@ def test_ongrid_and_speed_profile(ctx, name):
     assert np.array_equal(ctx.download_labels(np.int8), g['og_atoms_volumes_speed'])
 
 
-@pytest.mark.parametrize('name', ['c128_tric', 'c256_cubic', 'c512_cubic'])
+@pytest.mark.parametrize('name', ['c128_tric', 'c256_cubic', 'c320_tric', 'c512_cubic'])   # (c320_tric, round 5: the generic Grid instantiations above 128^3)
 def test_large_golden_hashes(ctx, name):
     g = load_golden(name)
     shape = tuple(int(s) for s in g['shape'])

@@ -371,6 +371,39 @@ def test_rccl_transport_through_the_c_abi_single_rank():
     ctx.close()
 
 
+def test_label_wire_stays_a_collective_value_across_per_rank_writes():
+    """xb_scatter_voxels / xb_copy_planes are per-rank events (only the ranks with parked retraces scatter), so
+    they must not change the width a label halo travels in unless a label they write does not fit it -- otherwise an int32
+    send meets an int8 receive.  xb_label_wire reads the width and lets a scheduler raise it to the ranks' maximum."""
+    g = load_golden('c64_cubic')
+    rho = case_density(g)
+    ctxs = [_lib.Context(0) for _ in range(2)]
+    for ctx in ctxs:
+        ctx.set_grid(rho.shape, g['dist_mat'], g['T_grad'])
+        ctx.upload_density(rho)
+        ctx.vacuum_assign(None, 1.0)
+        assert ctx.assign('neargrid') == 8
+    a, b = ctxs
+    assert a.label_wire() == 1 and b.label_wire() == 1           # 8 basins: dtype_calc(-8) = int8
+    idx = np.array([5, 77, 4099], np.int64)
+    lab, kn = a.gather_voxels(idx)
+    a.scatter_voxels(idx, lab, kn)                               # one rank scatters labels already on the grid ...
+    assert a.label_wire() == b.label_wire() == 1                 # ... and the ranks still agree
+    planes = a.download_labels(np.int32)[3:5].copy()
+    a.copy_planes(0, True, planes, 3, 5)                         # planes of a peer that ran the same assignment
+    assert a.label_wire() == 1
+    a.scatter_voxels(idx, np.array([300, 1, 2], np.int32), kn)   # a label int8 does not hold: widened (never truncated)
+    assert a.label_wire() == 2 and b.label_wire() == 1
+    assert b.label_wire(max(a.label_wire(), b.label_wire())) == 2   # what SlabRunner._agree_label_wire does
+    planes[0, 0, 0] = 1 << 20
+    b.copy_planes(0, True, planes, 3, 5)
+    assert b.label_wire() == 4
+    with pytest.raises(_lib.BaderHipError):
+        a.label_wire(3)
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` as typed: the script spawns its ranks, they rendezvous over the file/TCP store,
     RCCL refuses two ranks on one device, every rank falls back to the host-staged transport, rank 0 prints ONE

@@ -592,3 +592,71 @@ def test_device_driven_step_scheduling_with_a_mock_backend():
     # status 2: this density goes to the host-driven calls, for good
     be.finishes = [(0, 2)]
     assert runner._assign_device_step() is None
+
+
+def test_label_wire_is_agreed_after_a_one_sided_scatter():
+    """in the path-query fallback only the ranks with parked retraces scatter voxels.  The width a label halo
+    travels in must still be the same on every rank before the next exchange (send / receive sizes): SlabRunner takes the
+    maximum over the ranks after the queries.  Two ranks (threads), a mock backend: rank 1 has one parked retrace and its
+    write widens its width (a label that did not fit), rank 0 has none and returns before the scatter."""
+    import threading
+
+    shape, n = (8, 2, 2), 2
+    nyz = shape[1] * shape[2]
+    ranges = slab.slab_ranges(shape[0], n)
+    barrier = threading.Barrier(n)
+    slots = [None] * n
+
+    class Comm:
+        def __init__(self, rank):
+            self.rank, self.size = rank, n
+
+        def allgather(self, obj):
+            slots[self.rank] = obj
+            barrier.wait()
+            out = list(slots)
+            barrier.wait()
+            return out
+
+        def sum(self, *vals):
+            got = self.allgather([int(v) for v in vals])
+            return [sum(g[i] for g in got) for i in range(len(vals))]
+
+    class Backend:
+        def __init__(self, rank):
+            self.rank, self.wire, self.scattered = rank, 1, []
+
+        def escaped_paths(self, max_len):
+            if self.rank == 0:
+                return np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0, bool)
+            # one path: starts on plane 4 (rank 1's), its second voxel lies on plane 1 (rank 0's) and is known == 2
+            return (np.array([4 * nyz], np.int64), np.array([0, 2], np.int64), np.array([4 * nyz, 1 * nyz], np.int64),
+                    np.array([False]))
+
+        def gather_voxels(self, idx):
+            return np.full(len(idx), 300, np.int32), np.full(len(idx), 2, np.int8)
+
+        def scatter_voxels(self, idx, lab, kn):
+            self.scattered.append((np.asarray(idx).tolist(), np.asarray(lab).tolist()))
+            self.wire = max(self.wire, 2)        # what the library does when a written label does not fit the width
+
+        def label_wire(self, widen_to=0):
+            self.wire = max(self.wire, widen_to)
+            return self.wire
+
+    backends = [Backend(r) for r in range(n)]
+    moved = [None] * n
+
+    def work(rank):
+        runner = slab.SlabRunner.__new__(slab.SlabRunner)
+        runner.be, runner.comm, runner.shape, runner.halo = backends[rank], Comm(rank), shape, 1
+        runner.ranges = ranges
+        moved[rank] = runner._resolve_escaped()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert backends[0].scattered == [] and len(backends[1].scattered) == 1       # only one rank wrote
+    assert [be.wire for be in backends] == [2, 2]                                 # ... and both agree on the width
