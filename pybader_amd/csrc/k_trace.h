@@ -309,6 +309,9 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // this ROCm emit `v_cmp_ne_u32 0, src_shared_base` -- "illegal instruction, operand has incorrect register class" -- for
 // some shapes of the surrounding code)
 __shared__ GradRec xb_s_rec[512];
+#ifdef XB_DEBUG_COUNT
+__shared__ int xb_s_steps;   // probe: the most wave-steps any eighth of the brick in work has taken
+#endif
 template <bool OFF32, bool CACHE, bool WINDOW = false>
 __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
@@ -327,7 +330,13 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key
     int i0 = v, i1 = -1;
     double k0 = rec.key, k1 = -1.7976931348623157e308, m_old = -1.7976931348623157e308;
+#ifdef XB_DEBUG_COUNT
+    int pr_it = 0;
+#endif
     while (__builtin_amdgcn_ballot_w64(moving) != 0) {
+#ifdef XB_DEBUG_COUNT
+        pr_it++;
+#endif
         if (moving) {
             const int bits = key_bits(rec.key);
             // methods.py:345-363: dr += r; corr = rha(dr); q = p + int_grad + corr; dr -= corr (a voxel without a gradient
@@ -382,6 +391,9 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             i0 = lq; k0 = rec.key;
         }
     }
+#ifdef XB_DEBUG_COUNT
+    if ((threadIdx.x & 63) == 0) atomicMax(&xb_s_steps, pr_it);
+#endif
     // a maximum that is itself vacuum hands its -1 to the start voxel (methods.py:449-452)
     if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
     labels[v] = result;
@@ -537,6 +549,9 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
 #ifdef XB_DEBUG_COUNT
             const long long pr_b = clock64();
             pr_bricks++;
+            const unsigned long long pr_w0 = wall_clock64();   // (10 ns units) this brick: from its pull to the workgroup's next pull
+            if (threadIdx.x == 0) xb_s_steps = 0;
+            const long long pr_c0 = clock64();
 #endif
             if (CACHE) {   // (CH == 8, base a multiple of 8: one brick) thread t copies the record of voxel t of the brick
                 const int b = walk[base >> 3];
@@ -582,6 +597,20 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                     ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                            max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
             }
+#ifdef XB_DEBUG_COUNT
+            __syncthreads();
+            if (threadIdx.x == 0) {   // histogram of brick durations (log2 of 10 ns units) and the slow ones with their place in the list
+                const unsigned long long dt = wall_clock64() - pr_w0;
+                atomicAdd(&xb_dbg[2200 + (63 - __clzll(dt | 1))], 1ull);
+                if (dt > 16000) {   // > 160 us
+                    const unsigned long long k = atomicAdd(&xb_dbg[23], 1ull);
+                    if (k < 400) { xb_dbg[2300 + 4 * k] = (unsigned long long)(base >> 3) | ((unsigned long long)xb_s_steps << 32); xb_dbg[2301 + 4 * k] = dt; xb_dbg[2302 + 4 * k] = pr_w0; xb_dbg[2303 + 4 * k] = (unsigned long long)(clock64() - pr_c0); }
+                }
+                atomicAdd(&xb_dbg[24], (unsigned long long)xb_s_steps);   // sum over the bricks of their longest eighth's wave-steps
+                atomicAdd(&xb_dbg[25], dt);
+                atomicAdd(&xb_dbg[26], (unsigned long long)(clock64() - pr_c0));
+            }
+#endif
         }
     }
 #ifdef XB_DEBUG_COUNT
@@ -591,7 +620,7 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
         atomicAdd(&xb_dbg[18], (unsigned long long)pr_wait);
         atomicAdd(&xb_dbg[19], (unsigned long long)pr_load);
         atomicAdd(&xb_dbg[21], 1ull);
-        if (threadIdx.x == 0) { atomicAdd(&xb_dbg[22], (unsigned long long)pr_bricks); if (blockIdx.x < 2048) xb_dbg[64 + blockIdx.x] = (unsigned long long)wall_clock64(); }
+        if (threadIdx.x == 0) { atomicAdd(&xb_dbg[22], (unsigned long long)pr_bricks); if (blockIdx.x < 1024) xb_dbg[64 + blockIdx.x] = (unsigned long long)wall_clock64(); }
     }
 #endif
     if (CACHE && bres) {   // the last brick this workgroup walked
