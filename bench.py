@@ -129,6 +129,68 @@ def traffic_from_profile(kernel, method):
     return None, 'no PMC summary committed for this command'
 
 
+def user_legs(size, steps, warmup, mode, iters, headline_ns_per_voxel, stage_names):
+    """Round 5: what users run, timed like the headline -- the same step (volumes_init + bader_calc + refine) on
+    densities the 8-atom cubic cell flatters: a triclinic cell (the generic Grid instantiations: no mirror prefilter, full
+    T_grad), a 216-atom cell (bricks with several maxima are never certified) and a smooth density with noise in its vacuum
+    (thousands of spurious maxima).  Each leg reports its per-voxel time against the headline's and the certified fraction."""
+    from pybader_amd import _lib, synth
+    from pybader_amd.interface import distance_matrix, gradient_transform
+    shape = (size,) * 3
+    nv = float(size) ** 3
+    legs = {}
+    rng = np.random.default_rng(5)
+    k = 6
+    cells = np.stack(np.meshgrid(*(np.arange(k),) * 3, indexing='ij'), -1).reshape(-1, 3)
+    frac = (cells + 0.5 + 0.18 * (rng.random(cells.shape) - 0.5)) / k
+    atoms216 = np.concatenate([frac, 0.09 + 0.04 * rng.random((len(frac), 1)), 2.0 + 6.0 * rng.random((len(frac), 1))], 1)
+    cases = [('triclinic_8_atoms', synth.TRICLINIC, synth.ATOMS8, None,
+              'triclinic cell [[6,0,0],[1.5,5.5,0],[0.7,1.1,6.2]], the headline\'s 8 atoms'),
+             ('cubic_216_atoms', synth.CUBIC6, atoms216, None, '216 atoms (6 x 6 x 6, jittered) in the cubic cell'),
+             ('noisy_vacuum', synth.CUBIC6, synth.ATOMS8, 2e-3,
+              'the headline\'s density + uniform noise of amplitude 2e-3 wherever it is below 0.2 (tests/test_gpu_fullsize.py::test_noisy_vacuum_keeps_the_atoms_regions at full size)')]
+    for name, lat, atoms, noise, what in cases:
+        vl = np.divide(lat, shape)
+        c = _lib.Context(0)
+        c.set_grid(shape, distance_matrix(vl), gradient_transform(vl))
+        c.synth_density(lat, atoms, synth.BACKGROUND)
+        if noise:
+            rho = c.download_density()
+            nrng = np.random.default_rng(11)
+            rho += np.where(rho < 0.2, noise * nrng.random(shape), 0.0)
+            c.upload_density(rho)
+            del rho
+        vv = abs(np.linalg.det(lat)) / nv
+
+        def step():
+            c.set_option(6, 1)
+            c.vacuum_assign(None, vv)
+            n = c.assign('neargrid')
+            return n, c.refine(mode, iters)
+        for _ in range(max(1, warmup)):
+            step()
+        c.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            n, log = step()
+        c.sync()
+        dt = (time.perf_counter() - t0) / steps
+        c.enable_timing(True)
+        c.kernel_time_reset()
+        for _ in range(2):
+            step()
+        c.sync()
+        legs[name] = {'workload': f'{size}^3, {what}; neargrid assign + neargrid edge refinement {mode}:{iters}',
+                      'value': nv / dt / 1e6, 'unit': 'Mvoxels/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'basins': int(n),
+                      'refine_log': log[:4], 'ns_per_voxel': dt / nv * 1e9, 'ns_per_voxel_headline': headline_ns_per_voxel,
+                      'per_voxel_time_vs_headline': dt / nv * 1e9 / headline_ns_per_voxel,
+                      'trapping_boxes': {'count': c.box_stats()[0], 'voxel_fraction': c.box_stats()[1] / nv},
+                      'slow_path_trajectories(assign,refine)': list(c.slow_path_stats()),
+                      'stage_ms_avg': {nm: (lambda t: t[0] / t[1] if t[1] else 0.0)(c.kernel_time(i)) for i, nm in enumerate(stage_names)}}
+        c.close()
+    return legs
+
+
 def dropin_leg(ctx, size=256, k=6, reps=3):
     """bader_calc + refine through pybader_amd.thread_handlers on a 216-atom density (host numpy arrays at the boundary)"""
     from pybader_amd import _lib, synth, thread_handlers, utils
@@ -231,6 +293,7 @@ def main():
     ap.add_argument('--no-config5', action='store_true', help='skip the ongrid configuration timed after the headline one')
     ap.add_argument('--no-dropin', action='store_true', help='skip the thread_handlers leg on the 216-atom 256^3 density')
     ap.add_argument('--no-stage-steps', action='store_true', help='skip the 3 extra steps that time the other stages (profiler runs: only warm-up + timed steps on the card)')
+    ap.add_argument('--no-user-legs', action='store_true', help='skip the triclinic / 216-atom / noisy-vacuum legs at the headline size')
     ap.add_argument('--no-odd', action='store_true', help='skip the leg on a grid that is not made of whole 8^3 bricks (500 x 504 x 420)')
     ap.add_argument('--halo', type=int, default=None,
                     help='label planes valid each side of a slab (default 16 for N > 1: a retrace stops when it enters a '
@@ -540,6 +603,9 @@ def main():
                                                'sample': f'{hshape[0]} x {hshape[1]} x {hshape[2]} grid, neargrid assign + refine ({mode},{iters}), single thread C port',
                                                'gpu_map_equals_cpu_map': bool(np.array_equal(got_h, want_h) and np.array_equal(ch.maxima(), bmax_h))}
             ch.close()
+
+    if world == 1 and args.method == 'neargrid' and not args.no_user_legs and args.size >= 256:
+        out['user_legs'] = user_legs(args.size, min(args.steps, 10), args.warmup and 2, mode, iters, step_s / nvox * 1e9, stage_names)
 
     # The Python drop-in (pybader_amd.thread_handlers, the reference's call signatures) on a density the headline does not
     # flatter: 216 atoms on a 256^3 grid (more maxima than round 1's 64 seed cubes), host arrays in, host arrays out --

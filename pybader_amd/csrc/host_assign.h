@@ -40,28 +40,47 @@ static int read_counter(xb_ctx *c, int idx, int *out) {
     return XB_OK;
 }
 
-// run the exact slow kernel over ovf_list[0..n) in chunks
+// The exact slow kernel over ovf_list[0..n): whole path in scratch, membership by scanning it (methods.py:411 / refinement.py:200).
+// Round 5: in TIERS -- tier 1 gives every walker 64 path voxels (interleaved storage, up to 2 M walkers per launch), the ones whose
+// path is longer are listed and go on to 2048, then 32768 voxels.  A density with a noisy vacuum hands MILLIONS of walkers over
+// (512^3: 5.8 M); at 2048 walkers x 32768 voxels per launch that took 2800 launches, and the list had a hard cap before.
 static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr) {
     if (!max_count) max_count = c->counters + 0;
     if (!changed) changed = c->counters + 2;
     if (!escaped) escaped = c->counters + 3;
-    const int lmax = 1 << 15, chunk = 2048;
-    DevBuf<int> path;
-    HIPCHK(path.alloc((size_t)chunk * lmax));
-    HIPCHK(hipMemsetAsync(c->counters + 8, 0, sizeof(int), c->stream));  // err
-    for (int o = 0; o < n; o += chunk) {
-        const int m = std::min(chunk, n - o);
-        k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known,
-                                                         c->ovf_list + o, m, path.p, lmax, refine, c->first,
-                                                         c->max_list, max_count, c->max_cap,
-                                                         changed, escaped, c->counters + 8, nullptr, c->has_vacuum ? 1 : 0);
+    if (n <= 0) return XB_OK;
+    const size_t budget = (size_t)128 << 20;   // ints of path scratch per launch (512 MB)
+    static const int tiers[3] = {64, 2048, 1 << 15};
+    DevBuf<int> path, lists;
+    HIPCHK(path.alloc(std::min<size_t>(budget, (size_t)n * tiers[0]) + (size_t)(1 << 15) * 64));
+    HIPCHK(lists.alloc(2 * (size_t)n + 8));
+    int *cnt = lists.p + 2 * (size_t)n;     // [0], [1]: lengths of the two retry lists; [2]: err
+    HIPCHK(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
+    const int *cur = c->ovf_list;
+    int n_cur = n;
+    for (int tier = 0; tier < 3 && n_cur > 0; tier++) {
+        const int lmax = tiers[tier];
+        const bool last = tier == 2;
+        int *next = lists.p + (size_t)(tier & 1) * n, *next_cnt = cnt + (tier & 1);
+        const size_t have = std::min<size_t>(budget, (size_t)n * tiers[0]) + (size_t)(1 << 15) * 64;
+        const int chunk = (int)std::max<size_t>(64, std::min<size_t>(have / lmax, (size_t)n_cur) & ~(size_t)63);
+        for (int o = 0; o < n_cur; o += chunk) {
+            const int m = std::min(chunk, n_cur - o);
+            k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, cur + o, m, path.p, lmax, refine,
+                                                             c->first, c->max_list, max_count, c->max_cap, changed, escaped, cnt + 2, nullptr,
+                                                             c->has_vacuum ? 1 : 0, m, 1, last ? nullptr : next, last ? nullptr : next_cnt);
+        }
+        HIPCHK(hipGetLastError());
+        if (last) break;
+        HIPCHK(hipMemcpyAsync(c->host_ints, next_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        cur = next;
+        n_cur = c->host_ints[0];
+        if (tier == 0) HIPCHK(hipMemsetAsync(cnt + 1, 0, sizeof(int), c->stream));
     }
-    hipError_t e = hipGetLastError();
-    int err = 0;
-    int rc = read_counter(c, 8, &err);   // synchronises the stream: the scratch may go afterwards
-    if (e != hipSuccess) return fail(XB_E_HIP, "k_trace_slow: %s", hipGetErrorString(e));
-    if (rc) return rc;
-    if (err) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", lmax);
+    HIPCHK(hipMemcpyAsync(c->host_ints, cnt + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // (the scratch may go afterwards)
+    if (c->host_ints[0]) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", tiers[2]);
     return XB_OK;
 }
 
@@ -475,7 +494,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                     else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
                 } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
                 else k_ng_trace_g<2, 3><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
-            } else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
+            } else if (c->opt_dbg_window == 3) k_ng_trace_g<3, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);   // EXPERIMENT: window sizes
+            else if (c->opt_dbg_window == 4) k_ng_trace_g<4, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
+            else if (c->opt_dbg_window == 6) k_ng_trace_g<6, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
+            else if (c->opt_dbg_window == 8) k_ng_trace_g<8, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
+            else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
                 k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
 #undef XB_TRACE_ARGS
         }
@@ -518,7 +541,6 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     c->n_walk = h[FS_N_WALK];
     const int novf = h[FS_N_OVF];
     int nmax = h[FS_N_MAX];
-    if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d trajectories need the slow path (cap %d)", novf, c->ovf_cap);
     if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
     c->stat_ovf_assign += novf;
     if (h[FS_SORT_OK] && novf == 0) {
@@ -534,7 +556,19 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     // rare: trajectories for the exact slow kernel and/or more maxima than the device sort takes
     if (novf > 0) {
         g.main_ties = 1;
-        const int rc = run_slow(c, novf, 0, fs + FS_N_MAX);
+        int rc = run_slow(c, std::min(novf, c->ovf_cap), 0, fs + FS_N_MAX);
+        // more walkers than the list holds (a density that is noise almost everywhere): the unlisted ones still carry -2 in the
+        // walk-list bricks -- list and run them a list's worth at a time (round 5: this used to fail the call)
+        for (int left = novf - c->ovf_cap; !rc && left > 0;) {
+            HIPCHK(hipMemsetAsync(c->counters + 1, 0, sizeof(int), c->stream));
+            k_list_unfinished<<<4096, TPB, 0, c->stream>>>(gl, walk, fs + FS_N_WALK, nb1, nb2, c->labels, c->ovf_list, c->counters + 1, c->ovf_cap);
+            HIPCHK(hipGetLastError());
+            int m = 0;
+            if ((rc = read_counter(c, 1, &m))) break;
+            if (m == 0) break;
+            rc = run_slow(c, std::min(m, c->ovf_cap), 0, fs + FS_N_MAX);
+            left = m - c->ovf_cap;
+        }
         g.main_ties = 0;
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_MAX, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -141,7 +141,7 @@ int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], co
         c->max_cap = (int)std::min<long long>(N, 1 << 22);
         HIPCHK(hipMalloc(&c->max_list, c->max_cap * sizeof(int)));
         HIPCHK(hipMalloc(&c->max_aux, c->max_cap * sizeof(int)));
-        c->ovf_cap = (int)std::min<long long>(N, 1 << 22);
+        c->ovf_cap = (int)std::min<long long>(N, std::max<long long>(1 << 22, N / 16));   // (walkers for the exact slow path; beyond it the assignment lists them again, cap by cap)
         HIPCHK(hipMalloc(&c->ovf_list, c->ovf_cap * sizeof(int)));
         c->n_alloc = N;
         c->first_clean = false;

@@ -308,6 +308,9 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // (the cache is a file-scope LDS array, not a pointer argument: handed over as a generic pointer it made the gfx950 backend of
 // this ROCm emit `v_cmp_ne_u32 0, src_shared_base` -- "illegal instruction, operand has incorrect register class" -- for
 // some shapes of the surrounding code)
+#ifndef XB_LEAN_K
+#define XB_LEAN_K 3   // voxels of the lean walker's exact path window (2, 3 or 4): 4 costs the smooth headline 3 % of the trace, 3 half of that
+#endif
 __shared__ GradRec xb_s_rec[512];
 #ifdef XB_DEBUG_COUNT
 __shared__ int xb_s_steps;   // probe: the most wave-steps any eighth of the brick in work has taken
@@ -330,6 +333,17 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key
     int i0 = v, i1 = -1;
     double k0 = rec.key, k1 = -1.7976931348623157e308, m_old = -1.7976931348623157e308;
+    // (round 5: a window of XB_LEAN_K voxels instead of 2 -- the running-maximum test fails wherever a trajectory dips below a key it
+    // passed three or more steps ago: 19 K walkers of a 216-atom cell and 5.8 M of a noisy vacuum went to the exact slow kernel at
+    // 512^3 with two, a third / a half as many with four; free on the smooth headline, the walker waits for its gathers)
+#if XB_LEAN_K >= 3
+    int i2 = -1;
+    double k2 = -1.7976931348623157e308;
+#endif
+#if XB_LEAN_K >= 4
+    int i3 = -1;
+    double k3 = -1.7976931348623157e308;
+#endif
 #ifdef XB_DEBUG_COUNT
     int pr_it = 0;
 #endif
@@ -351,7 +365,13 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
                 px = wrap3(px, g.nx); py = wrap3(py, g.ny); pz = wrap3(pz, g.nz);
             }
             int lq = lin24(g, px, py, pz);
-            const bool og_move = (bits & 63) == XB_STAY_CODE || lq == i0 || lq == i1;   // methods.py:411: already on this path
+            bool og_move = (bits & 63) == XB_STAY_CODE || lq == i0 || lq == i1;   // methods.py:411: already on this path
+#if XB_LEAN_K >= 3
+            og_move = og_move || lq == i2;
+#endif
+#if XB_LEAN_K >= 4
+            og_move = og_move || lq == i3;
+#endif
             bool at_max = false;
             if (__builtin_amdgcn_ballot_w64(og_move) != 0) {   // rare: dr = 0 and one ongrid step from p (methods.py:412-447, tabulated)
                 if (og_move) {
@@ -386,7 +406,16 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             else if (at_max) result = i0;
             else if (undecided) result = -2;
             moving = !(arrived || at_max || undecided);
+#if XB_LEAN_K >= 4
+            m_old = max_raw(m_old, k3);
+            i3 = i2; k3 = k2;
+            i2 = i1; k2 = k1;
+#elif XB_LEAN_K == 3
+            m_old = max_raw(m_old, k2);
+            i2 = i1; k2 = k1;
+#else
             m_old = max_raw(m_old, k1);
+#endif
             i1 = i0; k1 = k0;
             i0 = lq; k0 = rec.key;
         }
@@ -634,6 +663,33 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
     }
 }
 
+// The voxels of the walk-list bricks that still carry -2 ("handed to the exact slow kernel") -- for a density that hands over more
+// walkers than the list holds (round 5: no hard cap any more; the host lists and runs them cap by cap).  A workgroup per brick.
+__global__ __launch_bounds__(TPB) void k_list_unfinished(GridL g, const int *__restrict__ walk, const int *n_walk, int nb1, int nb2,
+                                                         const int *__restrict__ labels, int *out, int *out_count, int out_cap) {
+    __shared__ int s_buf[BlockAppender<2>::CAP], s_n[2];
+    BlockAppender<2> app;
+    app.init(s_buf, s_n, out, out_count, out_cap);
+    const int n = *n_walk;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {   // (uniform per block)
+        const int b = walk[e];
+        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+        int v[2];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int t = threadIdx.x + k * TPB;
+            const int x = b0 * 8 + (t >> 6), y = b1 * 8 + ((t >> 3) & 7), z = b2 * 8 + (t & 7);
+            if (x < g.nx && y < g.ny && z < g.nz) {
+                const int l = (x * g.ny + y) * g.nz + z;
+                if (labels[l] == -2) v[cnt++] = l;
+            }
+        }
+        app.add(cnt, [&](int k) { return v[k]; });
+    }
+    app.finish();
+}
+
 // helpers of the remote path queries (slab scheduler)
 // packed path of walker t: its start voxel, then the voxels from index first[t] on
 __global__ void k_path_pack(const int *__restrict__ path, int lmax, const int *__restrict__ off, const int *__restrict__ len,
@@ -658,28 +714,34 @@ __global__ void k_scatter_voxels(const int *__restrict__ idx, int n, const int *
 // window: the whole path lives in global scratch and is scanned linearly.
 // mode 0: assignment (write maximum index, note it); mode 1: refinement retrace; mode 2: only record the
 // whole trajectory up to its maximum (path + length), for the slab scheduler's remote path queries.
+// Path storage: voxel k of walker t at path[k * sk + t * st] -- (sk, st) = (1, lmax) one walker after the other (the path dumps of
+// the slab scheduler read them like that), or (n, 1) interleaved: the lanes of a wave write neighbouring words (round 5: the
+// exact path runs in TIERS -- every listed walker with 64 path voxels each in a few large launches, the few that need more with
+// 2048 and then 32768 -- `retry`: where a walker whose path does not fit is listed instead of failing the call).
 __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
                              int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
                              int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err,
-                             int *lens, int has_vacuum = 1) {
+                             int *lens, int has_vacuum = 1, long long sk = 1, long long st = -1, int *retry = nullptr, int *retry_count = nullptr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int v = list[t];
-    int *P = path + (size_t)t * lmax;
+    if (st < 0) st = lmax;
+    int *P0 = path + (size_t)t * st;
+#define P(k) P0[(size_t)(k) * sk]
     int np = 0;
     int px = v / g.nyz;
     int r = v - px * g.nyz;
     int py = r / g.nz, pz = r - py * g.nz, lp = v;
     double c = rho[v], dr0 = 0., dr1 = 0., dr2 = 0.;
     const int vol_num = labels[v];
-    P[np++] = v;
+    P(np++) = v;
     int result = -3;
     for (;;) {
         int qx, qy, qz;
         const bool stay = ng_step(rho, g, px, py, pz, lp, c, dr0, dr1, dr2, qx, qy, qz);
         int lq = lin3(g, qx, qy, qz);
         bool on_path = stay;
-        for (int k = np - 1; k >= 0 && !on_path; k--) on_path = (P[k] == lq);
+        for (int k = np - 1; k >= 0 && !on_path; k--) on_path = (P(k) == lq);
         if (on_path) {
             dr0 = dr1 = dr2 = 0.;
             og_step(rho, g, g.dist, px, py, pz, c, qx, qy, qz);
@@ -695,24 +757,26 @@ __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels
                 lens[t] = -np;
                 int fo = np;
                 for (int k = 1; k < np && fo == np; k++)
-                    if (!plane_valid(g, P[k] / g.nyz)) fo = k;
+                    if (!plane_valid(g, P(k) / g.nyz)) fo = k;
                 lens[n + t] = fo;
                 return;
             }
-            atomicExch(err, 1);
+            if (retry) retry[atomicAdd(retry_count, 1)] = v;   // (the list takes every walker of this launch)
+            else atomicExch(err, 1);
             return;
         }
-        P[np++] = lq;
+        P(np++) = lq;
         px = qx; py = qy; pz = qz; lp = lq; c = rho[lq];
     }
     if (refine == 2) {  // length, and where the path first leaves this rank's valid planes (the part before is known
         lens[t] = np;   // to hold no stop voxel: the fast retrace walked it)
         int fo = np;
         for (int k = 1; k < np && fo == np; k++)
-            if (!plane_valid(g, P[k] / g.nyz)) fo = k;
+            if (!plane_valid(g, P(k) / g.nyz)) fo = k;
         lens[n + t] = fo;
         return;
     }
+#undef P
     if (refine) {
         const int nv = labels[result];
         if (nv != vol_num) { labels[v] = nv; known[v] = -2; atomicAdd(changed, 1); }
