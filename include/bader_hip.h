@@ -270,6 +270,11 @@ int xb_set_option(xb_ctx *c, int key, int value);
 /* device bytes held for the grid (density, labels, flags, numbering + the table of the window planes + scratch sized by the
  * slab): what a rank of the slab decomposition costs; the reference's blocks are copies of the block extent
  * (thread_handlers.py:31-47, utils.py:424-458) */
+/* Page-locked host buffers for result arrays (no counterpart in the reference: numpy allocates its own).  A device-to-host
+ * copy into such a buffer is one DMA transfer; into pageable memory it is staged through the library's pinned chunks and copied
+ * again.  pybader_amd._lib hands out the narrowed label arrays of bader_calc (thread_handlers.py:70-74) from a pool of these. */
+int xb_host_alloc(int64_t bytes, void **out);
+int xb_host_free(void *p);
 int xb_memory_stats(xb_ctx *c, int64_t *bytes_total, int64_t *bytes_table, int64_t *bytes_scratch);
 /* statistics of the last assignment: trapping boxes found and voxels they cover */
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);

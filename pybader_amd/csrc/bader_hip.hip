@@ -136,7 +136,6 @@ struct xb_ctx {
     int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
     int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
     long long stat_grow_retries = 0;
-    int opt_dbg_window = 2;    // EXPERIMENT (option 27): path window of the generic group walker
     int opt_lean = 1;          // persistent trace: the lean walker (k_trace.h, ng_walk_lean); 0: ng_walk_wave (tests compare)
     int opt_mirror = 1;        // pass A: mirror prefilter of the ongrid face test (k_masks.h, bm_mirror)
     int grad_rule = 0;         // which tie rule the resident table obeys: 0 refinement.py:111, 1 methods.py:324, 2 both
@@ -298,7 +297,6 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 7) c->opt_fused = value != 0;  // 0: the host-driven orchestration on one GPU too (tests compare the two)
     else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
     else if (key == 14) c->opt_lean = value != 0;
-    else if (key == 27) c->opt_dbg_window = value;
     else if (key == 16) c->opt_chase = value != 0;
     else if (key == 18) c->opt_narrow_halo = value != 0;
     else if (key == 19) c->opt_self_exchange = value != 0;

@@ -494,11 +494,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
                     else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
                 } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
                 else k_ng_trace_g<2, 3><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
-            } else if (c->opt_dbg_window == 3) k_ng_trace_g<3, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);   // EXPERIMENT: window sizes
-            else if (c->opt_dbg_window == 4) k_ng_trace_g<4, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
-            else if (c->opt_dbg_window == 6) k_ng_trace_g<6, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
-            else if (c->opt_dbg_window == 8) k_ng_trace_g<8, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
-            else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
+            } else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
                 k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
 #undef XB_TRACE_ARGS
         }

@@ -255,8 +255,26 @@ static int staged_h2d(xb_ctx *c, void *dst_dev, const void *src_host, size_t byt
     }
     return XB_OK;
 }
+// page-locked host memory for the caller's result arrays (round 5: the Python layer hands out label arrays that live in such
+// buffers and recycles them -- a device-to-host copy lands in them directly, no staging copy, no first-touch page faults)
+int xb_host_alloc(int64_t bytes, void **out) {
+    if (!out || bytes <= 0) return fail(XB_E_ARG, "xb_host_alloc: bad argument");
+    void *p = nullptr;
+    HIPCHK(hipHostMalloc(&p, (size_t)bytes));
+    *out = p;
+    return XB_OK;
+}
+int xb_host_free(void *p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return XB_OK;
+}
+static bool host_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
 static int staged_d2h(xb_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {   // returns with the data on the host
-    if (bytes < (4u << 20)) {
+    if (bytes < (4u << 20) || host_pinned(dst_host)) {
         HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return XB_OK;
@@ -445,6 +463,21 @@ int xb_download_labels(xb_ctx *c, void *labels_host, int dtype) {
     if (!sz) return fail(XB_E_ARG, "xb_download_labels: bad dtype code %d", dtype);
     if (dtype == XB_I32) {
         if (int rc = staged_d2h(c, labels_host, c->labels, c->N * 4)) return rc;
+    } else if (void *dev_view = nullptr; host_pinned(labels_host) && hipHostGetDevicePointer(&dev_view, labels_host, 0) == hipSuccess && dev_view) {
+        // a page-locked destination (pybader_amd's pooled result arrays): the narrowing kernel writes it over the bus itself --
+        // no staging buffer, no second transfer (round 5: 0.8 -> ~0.4 ms for the 16 MB of a 256^3 map)
+        if (dtype == XB_I8 || dtype == XB_I16) {
+            const long long per = 16 / (long long)sz, n16 = c->N / per, done = n16 * per;
+            if (dtype == XB_I8) {
+                if (n16) k_narrow_vec<int8_t><<<nblocks(n16), TPB, 0, c->stream>>>(c->labels, (int8_t *)dev_view, n16);
+                if (done < c->N) k_narrow<int8_t><<<1, TPB, 0, c->stream>>>(c->labels + done, (int8_t *)dev_view + done, c->N - done);
+            } else {
+                if (n16) k_narrow_vec<int16_t><<<nblocks(n16), TPB, 0, c->stream>>>(c->labels, (int16_t *)dev_view, n16);
+                if (done < c->N) k_narrow<int16_t><<<1, TPB, 0, c->stream>>>(c->labels + done, (int16_t *)dev_view + done, c->N - done);
+            }
+        } else
+            k_narrow<long long><<<nblocks(c->N), TPB, 0, c->stream>>>(c->labels, (long long *)dev_view, c->N);
+        HIPCHK(hipGetLastError());
     } else {
         c->chg_n = -1;   // (the narrowing goes through `stage`, whose upper half may list the changed voxels)
         const long long per = std::max<long long>(1, (long long)(c->stage_bytes / sz));

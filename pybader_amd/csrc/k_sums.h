@@ -113,6 +113,22 @@ __global__ __launch_bounds__(TPB) void k_any_equal(const int *__restrict__ a, lo
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) hit |= (a[i] == value);
     if (__any(hit) && threadIdx.x % XB_WAVE == 0) *flag = 1;
 }
+// 16 bytes of narrowed labels per thread: what writes a page-locked host array over the bus (one 16-byte store per lane, a
+// kilobyte per wave store); n16 = the number of whole 16-byte groups, the caller's plain k_narrow does the few labels behind them
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_narrow_vec(const int *__restrict__ in, T *__restrict__ out, long long n16) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    const int *src = in + i * PER;
+    T v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k += 4) {
+        const int4 q = *reinterpret_cast<const int4 *>(src + k);
+        v[k] = (T)q.x; v[k + 1] = (T)q.y; v[k + 2] = (T)q.z; v[k + 3] = (T)q.w;
+    }
+    *reinterpret_cast<uint4 *>(out + i * PER) = *reinterpret_cast<const uint4 *>(v);
+}
 template <typename T>
 __global__ void k_narrow(const int *__restrict__ in, T *__restrict__ out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

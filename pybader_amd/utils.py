@@ -75,7 +75,7 @@ def track_labels(ctx, volumes):
     release_labels(ctx)
     # (a view of a writeable array is not tracked: a write through its base would leave the device copy stale unnoticed)
     if (ctx.pinned_density is not None and isinstance(volumes, np.ndarray) and volumes.flags.c_contiguous
-            and not (isinstance(volumes.base, np.ndarray) and volumes.base.flags.writeable)):
+            and (_lib.pool_owned(volumes) or not (isinstance(volumes.base, np.ndarray) and volumes.base.flags.writeable))):
         ctx._labels_host, ctx._labels_was_writeable = volumes, bool(volumes.flags.writeable)
         volumes.flags.writeable = False
         ctx.resident_labels = _lab_identity(volumes)
@@ -97,7 +97,7 @@ def ensure_labels(ctx, volumes):
 def fetch_labels(ctx, out=None, dtype=None):
     """device labels -> host (in place into `out`, else a new array of `dtype`), and track the result"""
     release_labels(ctx)
-    out = ctx.download_labels(out=out) if out is not None else ctx.download_labels(dtype)
+    out = ctx.download_labels(out=out) if out is not None else ctx.download_labels(dtype, pooled=True)
     track_labels(ctx, out)
     return out
 
@@ -141,7 +141,7 @@ def vacuum_assign(reference, volumes, vac_tol, density, voxel_volume):
         s, n = ctx.label_sum(-1)
         charge, volume = s * voxel_volume, n * voxel_volume
     # the device sets non-vacuum voxels to 0; the reference leaves them untouched
-    if np.any(volumes):
+    if _lib.fast_any(volumes):
         keep = volumes.copy()
         ctx.download_labels(out=volumes)
         np.copyto(volumes, keep, where=volumes != -1)

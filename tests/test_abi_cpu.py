@@ -67,3 +67,21 @@ def test_host_matrices_match_reference(golden):
 def test_synth_sha_is_stable(golden):
     from conftest import case_density
     case_density(golden('c12_cubic'))
+
+
+def test_fast_any_equals_np_any_without_touching_fresh_pages():
+    """_lib.fast_any (round 5): the zero test of utils.vacuum_assign reads the kernel's pagemap instead of faulting in every
+    page of a fresh np.zeros array; every other case must give np.any's answer."""
+    from pybader_amd import _lib
+    shape = (160, 160, 160)                     # 16 MB of int32: above the size from which the pagemap is asked
+    assert _lib.fast_any(np.zeros(shape, np.int32)) is False
+    for where in (0, 12345678 % (160 ** 3), 160 ** 3 - 1):
+        v = np.zeros(shape, np.int32)
+        v.reshape(-1)[where] = -1
+        assert _lib.fast_any(v) is True
+    v = np.zeros(shape, np.int32)
+    v[:] = 0                                    # touched, still zero
+    assert _lib.fast_any(v) is False
+    assert _lib.fast_any(np.ones(shape, np.int8)) is True
+    assert _lib.fast_any(np.zeros((8, 8, 8), np.int32)) is False and _lib.fast_any(np.arange(8)) is True
+    assert _lib.fast_any(np.zeros(shape, np.int32)[:, ::2]) is False     # not contiguous: np.any
