@@ -425,7 +425,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         {
             // seeds: the bricks that hold exactly one maximum (no cubes, no cap on the number of maxima); they are not
             // fixed: the kill iteration certifies them like every other brick
-            k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
+            k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max, box_first);
             if (chase) {   // provisional labels by one chase along the brick potentials instead of ~6 propagation launches
                 k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
                 k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64, fs);
@@ -440,7 +440,6 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)   // each returns at once when the growth has finished (phase on the device)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
-        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0, chase && launches < long_schedule ? 1 : 0);
         HIPCHK(hipGetLastError());
         stage_done("region growth");
@@ -502,7 +501,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         stage_done("trace");
     }
     // numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host)
-    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux, fs + FS_TOTAL);
     int *buni = reinterpret_cast<int *>(c->st);
     if (c->regions_pending) {
         if (g.nz % 4 == 0)
@@ -511,17 +510,18 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         else
             k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                      box_max, fs, fs + FS_SORT_OK);
-        k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
-        if (bres) k_buni_from_walk<<<256, 256, 0, c->stream>>>(walk, fs + FS_N_WALK, bres, c->first, buni, fs + FS_SORT_OK);
-        else k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+        if (bres) k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, walk, fs + FS_N_WALK, bres);
+        else {
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+            k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+        }
     } else
         k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
     k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
     stage_done("numbering + relabel");
     // the ONE host wait of the assignment: state block + the sorted maxima
-    HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->host_ints + FS_COUNT, c->max_aux, XB_SORT_MAX * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs, (FS_TOTAL + XB_SORT_MAX) * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // state block + sorted maxima: one transfer
     HIPCHK(hipStreamSynchronize(c->stream));
     const int *h = c->host_ints;
     g.main_ties = 0;
@@ -540,7 +540,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
     c->stat_ovf_assign += novf;
     if (h[FS_SORT_OK] && novf == 0) {
-        c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+        c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
         c->label_wire = label_wire_for(nmax);
         c->regions_pending = false;
         c->buni_valid = !c->has_vacuum;   // k_buni_from_regions + k_label_uniform_list ran
@@ -618,7 +618,7 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     }
     {
         ScopedTimer t4(c, 4);
-        k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max);
+        k_seed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, bmask, bmaxv, fs, seed, buf0, box_max, box_first);
         k_grow_parent<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nb0, nb1, nb2, bmask, bpot, seed, buf1);
         k_grow_chase<<<(nbr + TPB - 1) / TPB, TPB, 0, c->stream>>>(nbr, buf1, seed, buf0, 4 * (nb0 + nb1 + nb2) + 64, fs);
         const int long_schedule = 2 * ((std::max(std::max(nb0, nb1), nb2) + BG - 1) / BG) + 12;
@@ -626,7 +626,6 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
         const dim3 ggrid((nb2 + BG - 1) / BG, (nb1 + BG - 1) / BG, (nb0 + BG - 1) / BG);
         for (int l = 0; l < launches; l++)
             k_brick_grow_dev<<<ggrid, BG * BG * BG, 0, c->stream>>>(nb0, nb1, nb2, bmask, seed, buf0, buf1, fs, BG, 0);
-        k_fill<int><<<256, 256, 0, c->stream>>>(box_first, XB_INT_MAX, XB_REGIONS_MAX);
         k_grow_finish<<<64, TPB, 0, c->stream>>>(nbr, seed, buf0, buf1, fs, c->blab_buf, box_first, bmask, c->brick_rec, 0, launches < long_schedule ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
@@ -650,7 +649,7 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
                                                         1 << 22);
         HIPCHK(hipGetLastError());
     }
-    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux, fs + FS_TOTAL);
     int *buni = reinterpret_cast<int *>(c->st);
     if (g.nz % 4 == 0)
         k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
@@ -662,8 +661,7 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
     k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->host_ints + FS_COUNT, c->max_aux, XB_SORT_MAX * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->host_ints, fs, (FS_TOTAL + XB_SORT_MAX) * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // state block + sorted maxima: one transfer
     HIPCHK(hipStreamSynchronize(c->stream));
     const int *h = c->host_ints;
     if (h[FS_GROW_RETRY]) {   // the short kill schedule did not reach the fixpoint: once more, with the worst-case one from now on
@@ -678,7 +676,7 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     const int nmax = h[FS_N_MAX];
     if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
     if (h[FS_SORT_OK]) {
-        c->maxima_sorted.assign(h + FS_COUNT, h + FS_COUNT + nmax);
+        c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
         c->label_wire = label_wire_for(nmax);
         c->regions_pending = false;
         c->buni_valid = true;

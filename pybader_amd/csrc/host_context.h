@@ -20,7 +20,7 @@ int xb_create(int device, xb_ctx **out) {
     xb_ctx *c = new xb_ctx();
     c->device = device;
     HIPCHK(hipStreamCreate(&c->stream));
-    HIPCHK(hipMalloc(&c->counters, 1024 * sizeof(int)));
+    HIPCHK(hipMalloc(&c->counters, (1024 + XB_SORT_MAX) * sizeof(int)));   // (counters, the state block fs, and behind it the sorted maxima for the one copy of an assignment's wait)
     c->fs = c->counters + 128;
     HIPCHK(hipMalloc(&c->counters64, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->dsum, 16 * sizeof(double)));

@@ -546,11 +546,20 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: one slab only; slabs use xb_edge_check_local + xb_edge_check_global");
     if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
     int n = 0;
+    bool listed = false;
     if (chg_n >= 0) {   // the last retrace pass listed its relabelled voxels: exactly the known == -2 ones
         n = chg_n;
-        if (n) HIPCHK(hipMemcpyAsync(c->list, (int *)c->stage + c->N, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        if (n) {
+            HIPCHK(hipMemcpyAsync(c->list, (int *)c->stage + c->N, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->host_ints + 8, c->fs + FS_N_CHGLIST, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // (checked below)
+            listed = true;
+        }
     } else if (int rc = compact(c, -2, &n)) return rc;
-    return edge_check_resolve(c, n, nullptr, 0, g.nx, 0, c->N, checked, edges);
+    if (int rc = edge_check_resolve(c, n, nullptr, 0, g.nx, 0, c->N, checked, edges)) return rc;
+    // (the list was launched after the retrace pass's wait, its length taken from the pass's count of relabelled voxels: the
+    // kernel's own count came back with the first wait above and must agree)
+    if (listed && c->host_ints[8] != n) return fail(XB_E_STATE, "xb_edge_check: %d voxels listed for %d relabelled ones", c->host_ints[8], n);
+    return XB_OK;
 }
 
 // ---- 'changed' refinement across slabs ------------------------------------------------------------------------
@@ -712,10 +721,6 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
             k_refine_trace<2, true><<<512, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, (int *)c->stage, 0, fs + FS_R_DEFER,
                                                                fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                                c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, wl);
-        // the relabelled start voxels (known == -2 now), listed for the next edge_check in the upper half of `stage`
-        if (c->stage_bytes >= 8 * (size_t)c->N)
-            k_list_changed<<<1024, TPB, 0, c->stream>>>(c->list, fs + FS_N_EDGES, c->known, (int *)c->stage + c->N, fs + FS_N_CHGLIST,
-                                                        (int)std::min<long long>(c->N, 1LL << 30), fs + FS_CHANGED);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 7 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -723,9 +728,16 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
     *edges = c->host_ints[0];
     *changed = c->host_ints[1];
     const int novf = c->host_ints[3];
-    // the relabelled start voxels are listed (complete: nothing went to the exact slow kernel, the list did not overflow)
-    if (novf == 0 && c->host_ints[6] == c->host_ints[1] && c->stage_bytes >= 8 * (size_t)c->N && c->host_ints[1] <= (int)std::min<long long>(c->N, 1LL << 30))
-        c->chg_n = c->host_ints[1];
+    // The relabelled start voxels (known == -2 now) are listed for the next edge_check in the upper half of `stage` -- launched only
+    // when there are any (round 5: the launch came before the wait and returned at once in the usual case of a neargrid
+    // assignment, nothing changed: 5 us of every step).  The list is complete when nothing went to the exact slow kernel.
+    if (novf == 0 && c->host_ints[1] > 0 && c->stage_bytes >= 8 * (size_t)c->N && c->host_ints[1] <= (int)std::min<long long>(c->N, 1LL << 30)) {
+        k_list_changed<<<1024, TPB, 0, c->stream>>>(c->list, fs + FS_N_EDGES, c->known, (int *)c->stage + c->N, fs + FS_N_CHGLIST,
+                                                    (int)std::min<long long>(c->N, 1LL << 30), fs + FS_CHANGED);
+        HIPCHK(hipGetLastError());
+        c->chg_n = c->host_ints[1];   // (every relabelled voxel is an entry of the edge list: the kernel lists exactly that many)
+    } else if (novf == 0 && c->host_ints[1] == 0)
+        c->chg_n = 0;
     c->stat_deferred += c->host_ints[4];
     if (c->host_ints[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", c->host_ints[2]);
     if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);

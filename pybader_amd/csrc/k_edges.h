@@ -78,17 +78,24 @@ __global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const
     const int l = blab[b];
     if (l > 0) buni[b] = rank[box_max[l - 1]];
 }
-// ... and the walk-list bricks from what their walkers ended on (k_ng_trace_g leaves per brick the one maximum all 512
-// voxels reached, or XB_MIXED): the same entries as k_label_uniform_list's scan of the labels, without reading them
-__global__ void k_buni_from_walk(const int *__restrict__ walk, const int *n_walk, const int *__restrict__ bres,
-                                 const int *__restrict__ rank, int *__restrict__ buni, const int *gate) {
+// Round 5: the two uniformity launches behind the relabel of the one-GPU assignment in one -- the regions' bricks
+// (k_buni_from_regions) and the walk-list bricks from their walkers' verdicts (k_buni_from_walk).  Element-wise, disjoint bricks.
+__global__ __launch_bounds__(256) void k_buni_after_relabel(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
+                                                            const int *__restrict__ rank, int *__restrict__ buni, const int *gate,
+                                                            const int *__restrict__ walk, const int *n_walk, const int *__restrict__ bres) {
     if (gate && !*gate) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int b = t; b < nbr; b += nt) {
+        const int l = blab[b];
+        if (l > 0) buni[b] = rank[box_max[l - 1]];
+    }
     const int n = *n_walk;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    for (int e = t; e < n; e += nt) {
         const int b = walk[e], r = bres[b];
         buni[b] = r == XB_MIXED ? XB_MIXED : rank[r];
     }
 }
+
 // buni3[K] = the label when brick K AND its 26 neighbour bricks all carry that one label, else XB_MIXED: a tile
 // of the edge sweep then needs a handful of lookups instead of one per brick of its surroundings
 __global__ void k_buni3(int nb0, int nb1, int nb2, const int *__restrict__ buni, int *__restrict__ buni3) {

@@ -240,9 +240,11 @@ __global__ __launch_bounds__(XB_BOXES_MAX) void k_note_regions(GridL g, int nb1,
 // maximum starts with that maximum's region id.  No cap but the table size: a density with thousands of maxima (noise in
 // the vacuum of a real CHGCAR) still gets the regions of its atoms, and a brick with several maxima is simply never
 // certified.  Ids are handed out in arrival order (the basin numbering is decided later, by first voxel).
+// (round 5: the launch also presets box_first, the regions' smallest certain brick, for k_grow_finish -- a fill of its own before)
 __global__ void k_seed_bricks(int nbr, const int *__restrict__ bmask, const int *__restrict__ bmaxv, int *fs, int *seed, int *buf0,
-                              int *box_max) {
+                              int *box_max, int *box_first) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = b; i < XB_REGIONS_MAX; i += gridDim.x * blockDim.x) box_first[i] = XB_INT_MAX;
     if (b >= nbr) return;
     int id = 0;
     if (((bmask[b] >> 27) & 3) == 1) {
@@ -264,7 +266,7 @@ __global__ void k_seed_finish(int *fs) {
 // (noisy data) leave FS_SORT_OK = 0 and the host sorts instead.
 #define XB_SORT_MAX 2048
 __global__ __launch_bounds__(1024) void k_number_maxima(int *fs, int *first, const int *__restrict__ max_list, int max_cap,
-                                                        int *sorted) {
+                                                        int *sorted, int *sorted2 = nullptr) {
     __shared__ unsigned long long key[XB_SORT_MAX];
     const int n = fs[FS_N_MAX];
     // trajectories waiting for the exact slow kernel may still discover maxima: number on the host afterwards
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(1024) void k_number_maxima(int *fs, int *first, con
     for (int i = threadIdx.x; i < n; i += 1024) {
         const int m = (int)(key[i] & 0xffffffffu);
         sorted[i] = m;
+        if (sorted2) sorted2[i] = m;   // (a copy next to the state block: the host fetches both with one transfer)
         first[m] = i;
     }
     if (threadIdx.x == 0) fs[FS_SORT_OK] = 1;

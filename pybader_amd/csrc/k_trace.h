@@ -309,7 +309,7 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // this ROCm emit `v_cmp_ne_u32 0, src_shared_base` -- "illegal instruction, operand has incorrect register class" -- for
 // some shapes of the surrounding code)
 #ifndef XB_LEAN_K
-#define XB_LEAN_K 3   // voxels of the lean walker's exact path window (2, 3 or 4): 4 costs the smooth headline 3 % of the trace, 3 half of that
+#define XB_LEAN_K 2   // voxels of the lean walker's exact path window (2, 3 or 4; build-time): 3 and 4 send fewer walkers of rough densities to the exact slow path (see below) but cost the smooth headline 1.5 % / 3 % of the trace
 #endif
 __shared__ GradRec xb_s_rec[512];
 #ifdef XB_DEBUG_COUNT
@@ -333,9 +333,10 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key
     int i0 = v, i1 = -1;
     double k0 = rec.key, k1 = -1.7976931348623157e308, m_old = -1.7976931348623157e308;
-    // (round 5: a window of XB_LEAN_K voxels instead of 2 -- the running-maximum test fails wherever a trajectory dips below a key it
-    // passed three or more steps ago: 19 K walkers of a 216-atom cell and 5.8 M of a noisy vacuum went to the exact slow kernel at
-    // 512^3 with two, a third / a half as many with four; free on the smooth headline, the walker waits for its gathers)
+    // (round 5, measured: the running-maximum test fails wherever a trajectory dips below a key it passed XB_LEAN_K or more steps
+    // ago -- at 512^3 19 K walkers of a 216-atom cell and 5.8 M of a noisy vacuum go to the exact slow path with a window of 2,
+    // 7 K / 2.6 M with 3, 2.3 K / 1.2 M with 4; the headline pays 1.5 % / 3 % of the trace for it, so 2 stays the default and the
+    // slow path got its tiers instead: host_assign.h run_slow)
 #if XB_LEAN_K >= 3
     int i2 = -1;
     double k2 = -1.7976931348623157e308;
