@@ -361,9 +361,9 @@ int xb_brick_labels(xb_ctx *c, int32_t *out, int64_t capacity, int64_t dims[3]) 
 #ifdef XB_DEBUG_COUNT
 int xb_debug_counts(unsigned long long *out, int reset) {
     hipDeviceSynchronize();
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(xb_dbg), sizeof(unsigned long long) * 4096) != hipSuccess) return XB_E_HIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(xb_dbg), sizeof(unsigned long long) * 65536) != hipSuccess) return XB_E_HIP;
     if (reset) {
-        static unsigned long long z[4096];
+        static unsigned long long z[65536];
         if (hipMemcpyToSymbol(HIP_SYMBOL(xb_dbg), z, sizeof z) != hipSuccess) return XB_E_HIP;
     }
     return XB_OK;

@@ -159,7 +159,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     ScopedTimer tw(c, 6);
                     int *redo = (int *)c->stage;
                     const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
-                    k_ng_trace_g<2, 0><<<std::max(1, c->opt_trace_grid / 8), XB_WAVE * 8, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                    k_ng_trace_g<2, 0><<<std::max(1, c->opt_trace_grid / XB_TRACE_WAVES), XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
                                                                                   c->fs, c->labels, c->first, c->max_list, c->max_cap, redo,
                                                                                   redo_cap, maxsteps, c->has_vacuum ? 1 : 0, 8, 1);
                     k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
@@ -484,17 +484,17 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
 #define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
                       maxsteps, c->has_vacuum ? 1 : 0
             // persistent workgroups of eight waves, one brick per pull (per-XCD cursors over the Morton-ordered walk list)
-            const int groups = std::max(1, c->opt_trace_grid / 8);
+            const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
             if (lean) {   // the lean walker, the own brick's records in LDS
                 // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
                 if (!c->has_vacuum) bres = c->list + 6 * nbr;
                 if (part) {
-                    if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
-                    else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
-                } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
-                else k_ng_trace_g<2, 3><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                    if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
+                    else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
+                } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
+                else k_ng_trace_g<2, 3><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
             } else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
-                k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
+                k_ng_trace_g<2, 0><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
 #undef XB_TRACE_ARGS
         }
         HIPCHK(hipGetLastError());

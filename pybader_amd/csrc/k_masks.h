@@ -29,7 +29,7 @@
 #define BM_STAGE 1   // 0: round 3's staging (kept for A/B runs of the two builds)
 #endif
 #ifdef XB_DEBUG_COUNT
-__device__ unsigned long long xb_dbg[4096];   // [0..15] pass A's counters; [16..] the trace's time probes (k_ng_trace_g)
+__device__ unsigned long long xb_dbg[65536];   // [0..15] pass A's counters; [16..] the trace's time probes (k_ng_trace_g)
 #endif
 
 // thread -> (y, z) column of the 8 x 32 tile face, sorted by what a column can contribute to its brick's move mask:

@@ -311,21 +311,25 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 #ifndef XB_LEAN_K
 #define XB_LEAN_K 2   // voxels of the lean walker's exact path window (2, 3 or 4; build-time): 3 and 4 send fewer walkers of rough densities to the exact slow path (see below) but cost the smooth headline 1.5 % / 3 % of the trace
 #endif
-__shared__ GradRec xb_s_rec[512];
-#ifdef XB_DEBUG_COUNT
-__shared__ int xb_s_steps;   // probe: the most wave-steps any eighth of the brick in work has taken
+#ifndef XB_TRACE_NB
+#define XB_TRACE_NB 2   // bricks a workgroup of the group trace pulls at a time (their records in LDS: 16 KB each)
 #endif
+#ifndef XB_TRACE_WAVES
+#define XB_TRACE_WAVES 8   // waves of a workgroup of the group trace
+#endif
+__shared__ GradRec xb_s_rec[512 * XB_TRACE_NB];
 template <bool OFF32, bool CACHE, bool WINDOW = false>
 __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
                                              int *labels, int *first, int *max_list, int *max_count, int max_cap,
-                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum) {
+                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum, int soff = 0) {
+    // (soff: where the own brick's records lie in xb_s_rec -- the workgroup holds XB_TRACE_NB bricks at a time)
     // every start voxel is valid: the walk list holds whole bricks, and the lanes of a brick the grid cuts start from its
     // voxels inside the grid (k_ng_trace_g PART)
     const int v = lin24(g, sx, sy, sz);
     const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
     const int ox8 = sx & ~7, oy8 = sy & ~7, oz8 = sz & ~7;   // origin of the own brick
-    GradRec rec = CACHE ? xb_s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
+    GradRec rec = CACHE ? xb_s_rec[soff + (((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7))] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
     bool moving = lab0 != -1;
     int result = -1;
     int px = sx, py = sy, pz = sz, steps = 0;
@@ -345,13 +349,7 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     int i3 = -1;
     double k3 = -1.7976931348623157e308;
 #endif
-#ifdef XB_DEBUG_COUNT
-    int pr_it = 0;
-#endif
     while (__builtin_amdgcn_ballot_w64(moving) != 0) {
-#ifdef XB_DEBUG_COUNT
-        pr_it++;
-#endif
         if (moving) {
             const int bits = key_bits(rec.key);
             // methods.py:345-363: dr += r; corr = rha(dr); q = p + int_grad + corr; dr -= corr (a voxel without a gradient
@@ -391,7 +389,7 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             int bl = 0;
             const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
             const bool in_win = !WINDOW || own || plane_in_window(g, px);
-            if (own) rec = xb_s_rec[((px & 7) << 6) | ((py & 7) << 3) | (pz & 7)];
+            if (own) rec = xb_s_rec[soff + (((px & 7) << 6) | ((py & 7) << 3) | (pz & 7))];
             else {
                 rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);   // (outside the window: any valid slot, the value is not used)
                 const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
@@ -421,9 +419,6 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             i0 = lq; k0 = rec.key;
         }
     }
-#ifdef XB_DEBUG_COUNT
-    if ((threadIdx.x & 63) == 0) atomicMax(&xb_s_steps, pr_it);
-#endif
     // a maximum that is itself vacuum hands its -1 to the start voxel (methods.py:449-452)
     if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
     labels[v] = result;
@@ -524,7 +519,7 @@ __device__ __forceinline__ int xcc_id() {
 // copied into LDS (16 KB) before the waves start (see ng_walk_lean).  (LEAN 1 / 2, the lean walker without the cache, and the
 // one-wave form k_ng_trace_p were measured against these in round 3 and removed in round 4.)
 template <int K, int LEAN, bool WINDOW = false, bool PART = false>
-__global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
+__global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                        const int *__restrict__ blab, int nb1, int nb2,
                                                        const int *__restrict__ walk, int *fs, int *labels, int *first,
                                                        int *max_list, int max_cap, int *ovf_list, int ovf_cap, int maxsteps,
@@ -534,14 +529,19 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
     // pass over the labels.)  Per eighth the result of its lane 0, and a flag any lane raises whose result differs from it --
     // plain LDS stores and loads in the wave's program order: no atomics (1024 of them on one address per brick cost 0.2 ms
     // at 512^3), no cross-lane operations.
-    __shared__ int s_w[8], s_mixed;
+    // Round 5: a pull is XB_TRACE_NB bricks (CH = 8 * XB_TRACE_NB eighths for the eight waves to share out): the time probes
+    // (tools/trace_probe.py) show a wave waiting a third of its cycles at the barrier for the slowest eighth of ITS brick -- with
+    // sixteen eighths in the pool a wave that got a short one takes another.
+    __shared__ int s_w[8 * XB_TRACE_NB], s_mixed[XB_TRACE_NB];
     constexpr bool CACHE = LEAN >= 3;
-    int prev_brick = -1;
+    int prev_brick[XB_TRACE_NB];
+#pragma unroll
+    for (int j = 0; j < XB_TRACE_NB; j++) prev_brick[j] = -1;
 #ifdef XB_DEBUG_COUNT   // time probes (tools/trace_probe.py): where do the waves of the persistent trace spend their cycles?
     const long long pr_t0 = clock64();
     long long pr_walk = 0, pr_wait = 0, pr_load = 0;
     int pr_bricks = 0;
-    if (threadIdx.x == 0) atomicMax(&xb_dbg[20], (1ull << 62) - (unsigned long long)wall_clock64());   // (the earliest start, as a maximum: the counters reset to zero)
+    const unsigned long long pr_e0 = wall_clock64();
 #endif
     const int n_items = fs[FS_N_WALK] * 8;
     const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
@@ -560,14 +560,17 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
 #endif
             if (threadIdx.x == 0) {
                 if (CACHE && bres) {
-                    if (prev_brick >= 0) {
-                        int r0 = s_mixed ? -1 : s_w[0];
 #pragma unroll
-                        for (int k = 1; k < 8; k++) r0 = (s_w[k] == r0) ? r0 : -1;
-                        bres[prev_brick] = r0 >= 0 ? r0 : (-2147483647 - 1);
+                    for (int j = 0; j < XB_TRACE_NB; j++) {
+                        if (prev_brick[j] >= 0) {
+                            int r0 = s_mixed[j] ? -1 : s_w[8 * j];
+#pragma unroll
+                            for (int k = 1; k < 8; k++) r0 = (s_w[8 * j + k] == r0) ? r0 : -1;
+                            bres[prev_brick[j]] = r0 >= 0 ? r0 : (-2147483647 - 1);
+                        }
+                        prev_brick[j] = -1;   // (written: a pull that finds its range empty must not write it again)
+                        s_mixed[j] = 0;
                     }
-                    prev_brick = -1;   // (written: a pull that finds its range empty must not write it again)
-                    s_mixed = 0;
                 }
                 s_base = beg + atomicAdd(&fs[FS_CURSOR0 + q * FS_CURSOR_STRIDE], CH);
                 s_next = 0;
@@ -579,19 +582,31 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
 #ifdef XB_DEBUG_COUNT
             const long long pr_b = clock64();
             pr_bricks++;
-            const unsigned long long pr_w0 = wall_clock64();   // (10 ns units) this brick: from its pull to the workgroup's next pull
-            if (threadIdx.x == 0) xb_s_steps = 0;
-            const long long pr_c0 = clock64();
 #endif
-            if (CACHE) {   // (CH == 8, base a multiple of 8: one brick) thread t copies the record of voxel t of the brick
-                const int b = walk[base >> 3];
-                prev_brick = b;
-                const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-                const int t = threadIdx.x;
-                int cx = b0 * 8 + (t >> 6), cy = b1 * 8 + ((t >> 3) & 7), cz = b2 * 8 + (t & 7);
-                if (PART) { cx = min(cx, g.nx - 1); cy = min(cy, g.ny - 1); cz = min(cz, g.nz - 1); }   // (beyond the grid: any record, nobody reads the slot)
-                const int lt = lin24(g, cx, cy, cz);
-                xb_s_rec[t] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
+            if (CACHE) {   // (CH == 8 * XB_TRACE_NB, base a multiple of 8) thread t copies the record of voxel t of each brick of the pull
+                constexpr int PER = 512 * XB_TRACE_NB / (XB_WAVE * XB_TRACE_WAVES);   // records a thread copies
+                static_assert(PER * XB_WAVE * XB_TRACE_WAVES == 512 * XB_TRACE_NB, "the threads of a workgroup share out the records of a pull evenly");
+                GradRec tmp[PER];
+#pragma unroll
+                for (int j = 0; j < XB_TRACE_NB; j++)
+                    if (base + 8 * j < stop) prev_brick[j] = walk[(base >> 3) + j];   // (uniform)
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    const int idx = threadIdx.x + k * XB_WAVE * XB_TRACE_WAVES, j = idx >> 9, t = idx & 511;
+                    if (base + 8 * j < stop) {
+                        const int b = walk[(base >> 3) + j];
+                        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
+                        int cx = b0 * 8 + (t >> 6), cy = b1 * 8 + ((t >> 3) & 7), cz = b2 * 8 + (t & 7);
+                        if (PART) { cx = min(cx, g.nx - 1); cy = min(cy, g.ny - 1); cz = min(cz, g.nz - 1); }   // (beyond the grid: any record, nobody reads the slot)
+                        const int lt = lin24(g, cx, cy, cz);
+                        tmp[k] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    const int idx = threadIdx.x + k * XB_WAVE * XB_TRACE_WAVES;
+                    if (base + 8 * (idx >> 9) < stop) xb_s_rec[idx] = tmp[k];
+                }
                 __syncthreads();
             }
 #ifdef XB_DEBUG_COUNT
@@ -613,53 +628,44 @@ __global__ __launch_bounds__(512, 8) void k_ng_trace_g(GridL g, const GradRec *_
                     const long long pr_c = clock64();
 #endif
                     const int res = ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
-                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
+                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0,
+                                                                CACHE ? ((item - base) >> 3) << 9 : 0);
 #ifdef XB_DEBUG_COUNT
                     pr_walk += clock64() - pr_c;
 #endif
                     if (CACHE && bres) {
                         volatile int *w = s_w;
-                        if (lane == 0) w[item & 7] = res;
-                        if (w[item & 7] != res) *(volatile int *)&s_mixed = 1;   // (same wave: the store above is older in its LDS queue)
+                        if (lane == 0) w[item - base] = res;
+                        if (w[item - base] != res) *(volatile int *)&s_mixed[(item - base) >> 3] = 1;   // (same wave: the store above is older in its LDS queue)
                     }
                 }
                 else
                     ng_walk_wave<K, false>(g, G, box_max, blab, nb1, nb2, true, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
                                            max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, nullptr, nullptr, has_vacuum != 0);
             }
-#ifdef XB_DEBUG_COUNT
-            __syncthreads();
-            if (threadIdx.x == 0) {   // histogram of brick durations (log2 of 10 ns units) and the slow ones with their place in the list
-                const unsigned long long dt = wall_clock64() - pr_w0;
-                atomicAdd(&xb_dbg[2200 + (63 - __clzll(dt | 1))], 1ull);
-                if (dt > 16000) {   // > 160 us
-                    const unsigned long long k = atomicAdd(&xb_dbg[23], 1ull);
-                    if (k < 400) { xb_dbg[2300 + 4 * k] = (unsigned long long)(base >> 3) | ((unsigned long long)xb_s_steps << 32); xb_dbg[2301 + 4 * k] = dt; xb_dbg[2302 + 4 * k] = pr_w0; xb_dbg[2303 + 4 * k] = (unsigned long long)(clock64() - pr_c0); }
-                }
-                atomicAdd(&xb_dbg[24], (unsigned long long)xb_s_steps);   // sum over the bricks of their longest eighth's wave-steps
-                atomicAdd(&xb_dbg[25], dt);
-                atomicAdd(&xb_dbg[26], (unsigned long long)(clock64() - pr_c0));
-            }
-#endif
         }
     }
 #ifdef XB_DEBUG_COUNT
-    if (lane == 0) {
-        atomicAdd(&xb_dbg[16], (unsigned long long)pr_walk);
-        atomicAdd(&xb_dbg[17], (unsigned long long)(clock64() - pr_t0));
-        atomicAdd(&xb_dbg[18], (unsigned long long)pr_wait);
-        atomicAdd(&xb_dbg[19], (unsigned long long)pr_load);
-        atomicAdd(&xb_dbg[21], 1ull);
-        if (threadIdx.x == 0) { atomicAdd(&xb_dbg[22], (unsigned long long)pr_bricks); if (blockIdx.x < 1024) xb_dbg[64 + blockIdx.x] = (unsigned long long)wall_clock64(); }
+    // PLAIN stores into a slot per wave (the host adds them up).  Round 5 learnt it the hard way: 50 K atomicAdds on one line as the
+    // workgroups finish stretch the end of the kernel by 0.5 ms, and everything measured in that stretch is the probe itself.
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long *o = xb_dbg + 64 + 6 * (blockIdx.x * 8 + (threadIdx.x >> 6));
+        o[0] = (unsigned long long)pr_walk; o[1] = (unsigned long long)(clock64() - pr_t0); o[2] = (unsigned long long)pr_wait;
+        o[3] = (unsigned long long)pr_load; o[4] = pr_e0; o[5] = (unsigned long long)wall_clock64();
+        if (threadIdx.x == 0) xb_dbg[64 + 6 * 8192 + blockIdx.x] = (unsigned long long)pr_bricks;
     }
 #endif
-    if (CACHE && bres) {   // the last brick this workgroup walked
+    if (CACHE && bres) {   // the last bricks this workgroup walked
         __syncthreads();
-        if (threadIdx.x == 0 && prev_brick >= 0) {
-            int r0 = s_mixed ? -1 : s_w[0];
+        if (threadIdx.x == 0) {
 #pragma unroll
-            for (int k = 1; k < 8; k++) r0 = (s_w[k] == r0) ? r0 : -1;
-            bres[prev_brick] = r0 >= 0 ? r0 : (-2147483647 - 1);
+            for (int j = 0; j < XB_TRACE_NB; j++)
+                if (prev_brick[j] >= 0) {
+                    int r0 = s_mixed[j] ? -1 : s_w[8 * j];
+#pragma unroll
+                    for (int k = 1; k < 8; k++) r0 = (s_w[8 * j + k] == r0) ? r0 : -1;
+                    bres[prev_brick[j]] = r0 >= 0 ? r0 : (-2147483647 - 1);
+                }
         }
     }
 }

@@ -364,15 +364,15 @@ int xb_slab_assign_trace(xb_ctx *c) {
             // (the lean walker in workgroups of eight waves, one brick per pull, its records through LDS -- as on one GPU --
             // when the index products fit 24 bits; 32-bit table offsets up to 2^27 window voxels)
             const bool lean = gl.use24 && c->opt_lean;
-            const int groups = std::max(1, c->opt_trace_grid / 8);
+            const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
             if (lean && (long long)g.wlen * g.nyz <= (1LL << 27))
-                k_ng_trace_g<2, 4, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
-                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);
+                k_ng_trace_g<2, 4, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
+                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8 * XB_TRACE_NB, 1);
             else if (lean)
-                k_ng_trace_g<2, 3, true><<<groups, XB_WAVE * 8, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
-                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);
+                k_ng_trace_g<2, 3, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
+                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8 * XB_TRACE_NB, 1);
             else
-                k_ng_trace_g<2, 0><<<groups, XB_WAVE * 8, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
+                k_ng_trace_g<2, 0><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
                                                                          c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);
             k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, redo, fs + FS_N_OVF, c->labels, c->first, c->max_list,
                                                           fs + FS_N_MAX, c->max_cap, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho,
