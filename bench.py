@@ -476,9 +476,11 @@ def main():
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic,
-                     'traffic_note': 'HBM bytes of ONE step = (FETCH_SIZE + WRITE_SIZE) x 1024 summed over its kernels: ' + str(traffic_src) +
-                                     ' (separate rocprofv3 --pmc passes of this command; 8 B/lane row loads, 32 B gathers and record '
-                                     'stores, so the gfx950 x2 rule for 16 B/lane streams does not apply)',
+                     'traffic_note': 'NOT measured in this run: quoted from the committed PMC summary ' + str(traffic_src) +
+                                     ' -- HBM bytes of ONE steady-state step = (FETCH_SIZE + WRITE_SIZE) x 1024 summed over its kernels, '
+                                     'separate rocprofv3 --pmc passes of this command with the same kernel sources (hash checked; other '
+                                     'sources: null); 8 B/lane row loads, 32 B gathers and record stores, so the gfx950 x2 rule for '
+                                     '16 B/lane streams does not apply',
                      'algorithmic_bytes_per_voxel': BYTES_PATH, 'ms_per_step': ms_per_step,
                      'dominant_kernel': dom, 'kernels': kernels,
                      'kernel_timing': f'HIP events on the library stream: {stage_names[dom_timer]} inside the timed region (the only timer on there); the other stages in 3 extra steps with every timer on',
