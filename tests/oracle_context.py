@@ -48,7 +48,7 @@ class OracleContext:
         assert labels.shape == self.shape
         self.labels = np.array(labels, np.int32, order='C')
 
-    def download_labels(self, dtype=np.int32, out=None):
+    def download_labels(self, dtype=np.int32, out=None, pooled=False):   # (pooled: page-locked result arrays -- the GPU context's business)
         self.calls.append('download_labels')
         if out is None:
             out = np.empty(self.shape, dtype)
