@@ -373,9 +373,11 @@ def main():
     def step():
         ctx.set_option(6, 1)                            # no table carried over from the previous step
         ctx.vacuum_assign(None, voxel_volume)           # Bader.volumes_init: labels := 0 (no vacuum)
-        n = runner.assign(args.method)                  # Bader.bader_calc
-        log = runner.refine(mode, iters)                # Bader.refine_volumes
-        return n, log
+        if os.environ.get('XB_TWO_CALLS'):              # (A/B: the two library calls of rounds 1-4, two host waits)
+            n = runner.assign(args.method)              # Bader.bader_calc
+            log = runner.refine(mode, iters)            # Bader.refine_volumes
+            return n, log
+        return runner.assign_refine(args.method, mode, iters)   # ... both as Bader.__call__ issues them back to back: one host wait (round 5)
 
     def fence():
         ctx.sync()

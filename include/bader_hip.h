@@ -152,6 +152,11 @@ int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64
 /* thread_handlers.refine (thread_handlers.py:128-236): the iteration driver on one GPU.
  * iters < 0 => until nothing changes.  log[2*k] = edges, log[2*k+1] = changed of iteration k+1. */
 int xb_refine(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t log_capacity, int64_t *n_iters);
+/* Bader.bader_calc + Bader.refine_volumes back to back, as Bader.__call__ issues them (interface.py:406-416, 471-490), in ONE call:
+ * the refinement's first iteration is queued behind the assignment and one host wait serves both.  Results, maxima (xb_get_maxima)
+ * and log equal xb_assign followed by xb_refine; combinations other than the one-GPU neargrid path without vacuum, and assignments
+ * that do not end the usual way (tie voxels, walkers for the exact slow path), run as those two calls. */
+int xb_assign_refine(xb_ctx *c, int method, int mode, int64_t iters, int64_t *n_maxima, int64_t *log, int64_t log_capacity, int64_t *n_iters);
 
 /* utils.charge_sum (utils.py:235-252) via Bader.sum_volumes (interface.py:492-525) */
 int xb_charge_sum(xb_ctx *c, double voxel_volume, int64_t n_labels, double *charge, double *volume);

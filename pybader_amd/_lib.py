@@ -54,6 +54,7 @@ SYMBOLS = {
     'xb_edge_check_local_fetch': (_int, [_vp, _vp, _vp]),
     'xb_edge_check_global': (_int, [_vp, _vp, _vp, _i64, _pi64, _pi64]),
     'xb_refine': (_int, [_vp, _int, _i64, _vp, _i64, _pi64]),
+    'xb_assign_refine': (_int, [_vp, _int, _int, _i64, _pi64, _vp, _i64, _pi64]),
     'xb_charge_sum': (_int, [_vp, _dbl, _i64, _vp, _vp]),
     'xb_volume_assign': (_int, [_vp, _vp, _i64]),
     'xb_atom_assign': (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
@@ -482,6 +483,16 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         check(self.lib.xb_edge_check_global(self.h, _ptr(idx), _ptr(cls), idx.size, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def assign_refine(self, method, mode, iters):
+        """bader_calc + refine in one library call (one host wait for both on the fused one-GPU neargrid path); -> (n_maxima, log)"""
+        self.drop_label_token()
+        cap = 4096
+        log = np.zeros(cap, dtype=np.int64)
+        n, k = C.c_int64(), C.c_int64()
+        check(self.lib.xb_assign_refine(self.h, METHODS[method], REFINE_MODES[mode.lower()], int(iters), C.byref(n), _ptr(log), cap, C.byref(k)))
+        m = min(k.value, cap // 2)
+        return n.value, [(int(log[2 * i]), int(log[2 * i + 1])) for i in range(m)]
 
     def refine(self, mode, iters):
         self.drop_label_token()

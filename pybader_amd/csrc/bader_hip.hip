@@ -136,6 +136,9 @@ struct xb_ctx {
     int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
     int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
     long long stat_grow_retries = 0;
+    bool defer_wait = false;     // xb_assign_refine: the assignment queues its result transfer and returns without waiting ...
+    bool pending_assign = false; // ... and its results are still to be read (after the refinement's first wait)
+    int64_t pending_n_maxima = 0;
     int opt_lean = 1;          // persistent trace: the lean walker (k_trace.h, ng_walk_lean); 0: ng_walk_wave (tests compare)
     int opt_mirror = 1;        // pass A: mirror prefilter of the ongrid face test (k_masks.h, bm_mirror)
     int grad_rule = 0;         // which tie rule the resident table obeys: 0 refinement.py:111, 1 methods.py:324, 2 both

@@ -522,6 +522,19 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     stage_done("numbering + relabel");
     // the ONE host wait of the assignment: state block + the sorted maxima
     HIPCHK(hipMemcpyAsync(c->host_ints, fs, (FS_TOTAL + XB_SORT_MAX) * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // state block + sorted maxima: one transfer
+    if (c->defer_wait) {
+        // xb_assign_refine (round 5): the refinement's first iteration is queued right behind this assignment and ONE wait serves
+        // both -- the card no longer idles while the host comes back from this wait and goes into the next call (61 us of a 3.4 ms
+        // step).  The state the refinement reads is set as the usual outcome leaves it (no tie voxel, nothing for the exact slow
+        // path, numbering on the device); assign_neargrid_complete checks the transferred block afterwards and says when it was not so.
+        g.main_ties = 0;
+        c->grad_rule = 2;
+        c->regions_pending = false;
+        c->buni_valid = !c->has_vacuum;
+        c->regions_labels = !c->has_vacuum;
+        c->pending_assign = true;
+        return XB_OK;
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     const int *h = c->host_ints;
     g.main_ties = 0;
@@ -575,6 +588,23 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     return finish_numbering_on_host(c, nmax, n_maxima);
 }
 
+
+// The deferred half of assign_neargrid_fused (xb_assign_refine): the transferred state block is on the host now.  Returns true when
+// the assignment ended the usual way -- what the queued refinement iteration took for granted -- and finishes its bookkeeping.
+static bool assign_neargrid_complete(xb_ctx *c, int64_t *n_maxima) {
+    c->pending_assign = false;
+    const int *h = c->host_ints;
+    const int nmax = h[FS_N_MAX];
+    if (h[FS_GROW_RETRY] || h[FS_TIES] != 0 || h[FS_N_OVF] != 0 || !h[FS_SORT_OK] || nmax > c->max_cap || nmax > XB_SORT_MAX) return false;
+    c->n_boxes = h[FS_N_BOXES];
+    c->box_voxels = (long long)h[FS_N_CERTAIN] * BRK * BRK * BRK;
+    c->n_walk = h[FS_N_WALK];
+    c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
+    c->label_wire = label_wire_for(nmax);
+    c->first_clean = true;
+    if (n_maxima) *n_maxima = nmax;
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The single-GPU ongrid assignment with the control flow on the device (round 4): k_og_masks (pointers + brick masks, maxima,

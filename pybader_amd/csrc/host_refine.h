@@ -641,6 +641,7 @@ int xb_prepare_refine(xb_ctx *c) {
 
 // edge_find + retrace of one refinement iteration on one slab with ONE host wait: the edge count stays on the
 // device (the list kernels stride over it), the counters come back together at the end.
+#define XB_STEP_REDO 1000   // internal (never crosses the ABI): the assignment queued in front of this refinement did not end the usual way
 static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, bool late_records = false) {
     const Grid &g = c->g;
     int *fs = c->fs;
@@ -723,30 +724,32 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
                                                                c->ovf_cap, maxsteps, c->rho, c->dist_dev, c->brick_rec, nullptr, nullptr, 0, nullptr, wl);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_EDGES, 7 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int *hr = c->host_ints + 3000;   // (its own corner: an assignment's block may still wait to be read at the front, xb_assign_refine)
+    HIPCHK(hipMemcpyAsync(hr, fs + FS_N_EDGES, 7 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    *edges = c->host_ints[0];
-    *changed = c->host_ints[1];
-    const int novf = c->host_ints[3];
+    if (c->pending_assign && !assign_neargrid_complete(c, &c->pending_n_maxima)) return XB_STEP_REDO;   // (nothing below is to be trusted)
+    *edges = hr[0];
+    *changed = hr[1];
+    const int novf = hr[3];
     // The relabelled start voxels (known == -2 now) are listed for the next edge_check in the upper half of `stage` -- launched only
     // when there are any (round 5: the launch came before the wait and returned at once in the usual case of a neargrid
     // assignment, nothing changed: 5 us of every step).  The list is complete when nothing went to the exact slow kernel.
-    if (novf == 0 && c->host_ints[1] > 0 && c->stage_bytes >= 8 * (size_t)c->N && c->host_ints[1] <= (int)std::min<long long>(c->N, 1LL << 30)) {
+    if (novf == 0 && hr[1] > 0 && c->stage_bytes >= 8 * (size_t)c->N && hr[1] <= (int)std::min<long long>(c->N, 1LL << 30)) {
         k_list_changed<<<1024, TPB, 0, c->stream>>>(c->list, fs + FS_N_EDGES, c->known, (int *)c->stage + c->N, fs + FS_N_CHGLIST,
                                                     (int)std::min<long long>(c->N, 1LL << 30), fs + FS_CHANGED);
         HIPCHK(hipGetLastError());
-        c->chg_n = c->host_ints[1];   // (every relabelled voxel is an entry of the edge list: the kernel lists exactly that many)
-    } else if (novf == 0 && c->host_ints[1] == 0)
+        c->chg_n = hr[1];   // (every relabelled voxel is an entry of the edge list: the kernel lists exactly that many)
+    } else if (novf == 0 && hr[1] == 0)
         c->chg_n = 0;
-    c->stat_deferred += c->host_ints[4];
-    if (c->host_ints[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", c->host_ints[2]);
+    c->stat_deferred += hr[4];
+    if (hr[2]) return fail(XB_E_STATE, "xb_refine: %d traces left the grid", hr[2]);
     if (novf > c->ovf_cap) return fail(XB_E_LIMIT, "%d retraces need the slow path (cap %d)", novf, c->ovf_cap);
     c->stat_ovf_refine += novf;
     if (novf > 0) {
         if (int rc = run_slow(c, novf, 1, nullptr, fs + FS_CHANGED, fs + FS_ESCAPED)) return rc;
-        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_CHANGED, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hr, fs + FS_CHANGED, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        *changed = c->host_ints[0];
+        *changed = hr[0];
     }
     return XB_OK;
 }
@@ -810,4 +813,36 @@ static int refine_impl(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t
         if (changed == 0) break;
     }
     return XB_OK;
+}
+
+// bader_calc + refine in ONE call (round 5): what Bader.__call__ does back to back (interface.py:471-490), with the refinement's first
+// iteration queued behind the assignment -- one host wait for both instead of two, and no idle card between them.  Same results
+// and the same log as xb_assign followed by xb_refine; whenever the assignment does not end the usual way (a tie voxel, walkers for
+// the exact slow path, the growth's long schedule, numbering on the host) or the combination is not the fused one-GPU neargrid path
+// without vacuum, the two ordinary calls run instead.
+int xb_assign_refine(xb_ctx *c, int method, int mode, int64_t iters, int64_t *n_maxima, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
+    NEED_GRID_RAW("xb_assign_refine");
+    if (n_iters) *n_iters = 0;
+    const bool fused = c->opt_fused && c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
+    if (method == XB_METHOD_NEARGRID && fused && fused_ok(c) && !c->has_vacuum && iters != 0 && (mode == XB_REFINE_ALL || mode == XB_REFINE_CHANGED)) {
+        c->labels_zero_pending = false;   // every label is overwritten, none is read
+        c->defer_wait = true;
+        int rc = assign_neargrid_fused(c, nullptr);
+        c->defer_wait = false;
+        if (rc) { c->pending_assign = false; return rc; }
+        rc = refine_impl(c, mode, iters, log, log_capacity, n_iters);
+        c->chg_n = -1;
+        const bool redo = rc == XB_STEP_REDO || c->pending_assign;   // (pending still: the refinement returned before its first wait)
+        c->pending_assign = false;
+        if (!redo) {
+            if (n_maxima) *n_maxima = c->pending_n_maxima;
+            return rc;
+        }
+        c->grad_valid = false;   // the ordinary way, from the start: the assignment rewrites every label
+        c->first_clean = false;
+        c->buni_valid = false; c->regions_labels = false;
+        if (n_iters) *n_iters = 0;
+    }
+    if (int rc = xb_assign(c, method, n_maxima)) return rc;
+    return xb_refine(c, mode, iters, log, log_capacity, n_iters);
 }

@@ -498,6 +498,17 @@ class SlabRunner:
             edges, = self.comm.sum(edges)
         return edges
 
+    def assign_refine(self, method, mode, iters):
+        """bader_calc + refine back to back, as Bader.__call__ issues them -> (n_maxima, log).  One GPU: ONE library call, the
+        refinement's first iteration queued behind the assignment (xb_assign_refine: one host wait for both); slabs: the two steps."""
+        if self.comm.size == 1 and hasattr(self.be, 'assign_refine') and hasattr(self.be, 'ctx'):
+            self.n_maxima, log = self.be.assign_refine(method, mode, iters)
+            self.n_maxima = int(self.n_maxima)
+            self._maxima = None
+            return self.n_maxima, log
+        n = self.assign(method)
+        return n, self.refine(mode, iters)
+
     def refine(self, mode, iters):
         """thread_handlers.refine (thread_handlers.py:128-236) across slabs.  Returns [(edges, changed)]."""
         log = []

@@ -575,3 +575,39 @@ def test_label_array_stays_on_the_device_inside_resident():
         assert n_in == {'up': 0, 'down': 2, 'rho': 1}, n_in
     finally:
         ctx.upload_labels, ctx.download_labels, ctx.upload_density = real_up, real_down, real_rho
+
+
+@pytest.mark.parametrize('name,mode,iters', [('c64_cubic', 'changed', 2), ('c40x48x56_tric', 'all', -1), ('c48_cubic_vac', 'changed', 2),
+                                              ('r48_sig5', 'changed', -1), ('r40_noise04', 'changed', 2), ('r32_quant8', 'all', -1),
+                                              ('c12_cubic', 'changed', 2)])
+def test_assign_refine_in_one_call_equals_the_two_calls(ctx, name, mode, iters):
+    """xb_assign_refine (round 5: the refinement's first iteration queued behind the assignment, one host wait for both) against
+    xb_assign followed by xb_refine: maxima, log, map and the state left behind (a second refine) must be the same -- on smooth
+    grids (the deferred wait is taken), with a vacuum tolerance (not the fused combination: two calls inside), on 5-digit data
+    with tie voxels, on noise with walkers for the exact slow path and on plateaus (the queued iteration is thrown away and
+    everything runs again the ordinary way) and on a grid too small for the brick pipeline."""
+    from rough_common import load_rough
+    if name.startswith('c'):
+        g = load_golden(name)
+        rho = case_density(g)
+    else:
+        g, rho = load_rough(name)
+    tol = None if np.isnan(float(g['vacuum_tol'])) else float(g['vacuum_tol'])
+    ctx.set_grid(rho.shape, g['dist_mat'], g['T_grad'])
+    ctx.upload_density(rho)
+    out = []
+    for fused in (False, True):
+        ctx.set_option(6, 1)
+        ctx.vacuum_assign(tol, 1.0)
+        if fused:
+            n, log = ctx.assign_refine('neargrid', mode, iters)
+        else:
+            n = ctx.assign('neargrid')
+            log = ctx.refine(mode, iters)
+        lab = ctx.download_labels(np.int32)
+        again = ctx.refine('all', 1)                    # what a later call finds: the flags, table and uniformity state left behind
+        out.append((n, ctx.maxima(), log, lab, again, ctx.download_labels(np.int32)))
+    a, b = out
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[3], b[3])
+    assert a[4] == b[4] and np.array_equal(a[5], b[5])
