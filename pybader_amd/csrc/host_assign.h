@@ -44,7 +44,7 @@ static int read_counter(xb_ctx *c, int idx, int *out) {
 // Round 5: in TIERS -- tier 1 gives every walker 64 path voxels (interleaved storage, up to 2 M walkers per launch), the ones whose
 // path is longer are listed and go on to 2048, then 32768 voxels.  A density with a noisy vacuum hands MILLIONS of walkers over
 // (512^3: 5.8 M); at 2048 walkers x 32768 voxels per launch that took 2800 launches, and the list had a hard cap before.
-static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr) {
+static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr, const int *list_in = nullptr) {
     if (!max_count) max_count = c->counters + 0;
     if (!changed) changed = c->counters + 2;
     if (!escaped) escaped = c->counters + 3;
@@ -56,7 +56,7 @@ static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int 
     HIPCHK(lists.alloc(2 * (size_t)n + 8));
     int *cnt = lists.p + 2 * (size_t)n;     // [0], [1]: lengths of the two retry lists; [2]: err
     HIPCHK(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
-    const int *cur = c->ovf_list;
+    const int *cur = list_in ? list_in : c->ovf_list;
     int n_cur = n;
     for (int tier = 0; tier < 3 && n_cur > 0; tier++) {
         const int lmax = tiers[tier];
@@ -565,7 +565,30 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     // rare: trajectories for the exact slow kernel and/or more maxima than the device sort takes
     if (novf > 0) {
         g.main_ties = 1;
-        int rc = run_slow(c, std::min(novf, c->ovf_cap), 0, fs + FS_N_MAX);
+        // Round 5, a MIDDLE TIER in front of the exact slow kernel: the listed walkers once more on the table, with an exact path
+        // window of eight voxels instead of the lean walker's two (k_ng_trace_list<8>: the generic walker) -- the running-maximum
+        // test fails wherever a trajectory dips below a density it passed a few steps ago, which a wider window mostly absorbs
+        // (216 atoms at 512^3: 19 K walkers listed, 11 left for the slow kernel).  What it cannot decide either goes on to the
+        // slow kernel's tiers.  The second list lives in `stage` (free during an assignment).
+        const GridL glt = light(g);
+        const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
+        int *list2 = (int *)c->stage;
+        const int cap2 = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
+        auto two_tiers = [&](int n_listed) -> int {
+            c->host_ints[3100] = n_listed;
+            HIPCHK(hipMemcpyAsync(c->counters + 15, c->host_ints + 3100, sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemsetAsync(c->counters + 1, 0, sizeof(int), c->stream));
+            k_ng_trace_list<8><<<512, TPB, 0, c->stream>>>(glt, c->grad, box_max, c->blab, nb1, nb2, c->ovf_list, c->counters + 15, c->labels, c->first,
+                                                          c->max_list, fs + FS_N_MAX, c->max_cap, list2, c->counters + 1, cap2, maxsteps, c->rho, c->dist_dev,
+                                                          c->has_vacuum ? 1 : 0);
+            HIPCHK(hipGetLastError());
+            int m2 = 0;
+            if (int rc2 = read_counter(c, 1, &m2)) return rc2;
+            if (m2 > cap2) return fail(XB_E_LIMIT, "%d walkers for the exact slow path exceed its list (%d)", m2, cap2);
+            if (c->opt_dbg & 4) fprintf(stderr, "[assign] %d walkers listed, %d left for the exact slow kernel after the 8-voxel window\n", n_listed, m2);
+            return run_slow(c, m2, 0, fs + FS_N_MAX, nullptr, nullptr, list2);
+        };
+        int rc = two_tiers(std::min(novf, c->ovf_cap));
         // more walkers than the list holds (a density that is noise almost everywhere): the unlisted ones still carry -2 in the
         // walk-list bricks -- list and run them a list's worth at a time (round 5: this used to fail the call)
         for (int left = novf - c->ovf_cap; !rc && left > 0;) {
@@ -575,7 +598,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             int m = 0;
             if ((rc = read_counter(c, 1, &m))) break;
             if (m == 0) break;
-            rc = run_slow(c, std::min(m, c->ovf_cap), 0, fs + FS_N_MAX);
+            rc = two_tiers(std::min(m, c->ovf_cap));
             left = m - c->ovf_cap;
         }
         g.main_ties = 0;
