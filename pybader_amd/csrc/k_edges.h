@@ -753,7 +753,7 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     static_assert(!RESUME || (RHO && K == 2), "walkers are carried on by the from-rho kernel");
     const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
     int n_ch = 0, n_es = 0;
-  for (int base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {   // uniform per block
+  for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {   // uniform per block (any block size up to TPB)
     const int t = base + threadIdx.x;
     bool valid = t < n;
     int v = (valid && !RESUME) ? list[t] : 0;
