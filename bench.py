@@ -191,6 +191,53 @@ def user_legs(size, steps, warmup, mode, iters, headline_ns_per_voxel, stage_nam
     return legs
 
 
+def batch_leg(size, steps, mode, iters, lattice, atoms, background, jobs=2):
+    """Round 5: the SAME step on `jobs` independent densities at once -- a context (own stream, own buffers) and a host thread per
+    job, as a batch of CHGCARs would be run (ctypes releases the GIL inside the library).  The card overlaps one job's latency-bound
+    stretches (the ~20 small launches of the region growth, the tails of the trace kernels, the host's wait) with the other job's
+    kernels.  A throughput number for batches; the headline stays the single job, whose step time is what one `bader` run sees."""
+    import threading
+    from pybader_amd import _lib
+    from pybader_amd.interface import distance_matrix, gradient_transform
+    shape = (size,) * 3
+    vl = np.divide(lattice, shape)
+    vv = abs(np.linalg.det(lattice)) / float(np.prod(shape))
+    ctxs = []
+    for _ in range(jobs):
+        c = _lib.Context(0)
+        c.set_grid(shape, distance_matrix(vl), gradient_transform(vl))
+        c.synth_density(lattice, atoms, background)
+        ctxs.append(c)
+    results = [None] * jobs
+
+    def work(j, k):
+        c = ctxs[j]
+        for _ in range(k):
+            c.set_option(6, 1)
+            c.vacuum_assign(None, vv)
+            results[j] = c.assign_refine('neargrid', mode, iters)
+    for j in range(jobs):
+        work(j, 2)
+        ctxs[j].sync()
+    per_job = max(1, steps // jobs)
+    threads = [threading.Thread(target=work, args=(j, per_job)) for j in range(jobs)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.sync()
+    dt = (time.perf_counter() - t0) / (per_job * jobs)
+    for c in ctxs:
+        c.close()
+    nv = float(size) ** 3
+    return {'workload': f'{jobs} independent {size}^3 densities in flight (a context, a stream and a host thread each), the headline\'s step on each',
+            'jobs_in_flight': jobs, 'steps': per_job * jobs, 'ms_per_step': dt * 1e3, 'value': nv / dt / 1e6, 'unit': 'Mvoxels/s',
+            'whole_path_frac_of_hbm_roofline': BYTES_PATH * nv / dt / 1e9 / HBM_PEAK_GBS,
+            'basins': [int(r[0]) for r in results], 'refine_log': [list(map(list, r[1][:2])) for r in results]}
+
+
 def dropin_leg(ctx, size=256, k=6, reps=3):
     """bader_calc + refine through pybader_amd.thread_handlers on a 216-atom density (host numpy arrays at the boundary)"""
     from pybader_amd import _lib, synth, thread_handlers, utils
@@ -293,6 +340,7 @@ def main():
     ap.add_argument('--no-config5', action='store_true', help='skip the ongrid configuration timed after the headline one')
     ap.add_argument('--no-dropin', action='store_true', help='skip the thread_handlers leg on the 216-atom 256^3 density')
     ap.add_argument('--no-stage-steps', action='store_true', help='skip the 3 extra steps that time the other stages (profiler runs: only warm-up + timed steps on the card)')
+    ap.add_argument('--no-batch', action='store_true', help='skip the two-densities-in-flight throughput leg')
     ap.add_argument('--no-user-legs', action='store_true', help='skip the triclinic / 216-atom / noisy-vacuum legs at the headline size')
     ap.add_argument('--no-odd', action='store_true', help='skip the leg on a grid that is not made of whole 8^3 bricks (500 x 504 x 420)')
     ap.add_argument('--halo', type=int, default=None,
@@ -608,6 +656,9 @@ def main():
                                                'gpu_map_equals_cpu_map': bool(np.array_equal(got_h, want_h) and np.array_equal(ch.maxima(), bmax_h))}
             ch.close()
 
+    if world == 1 and args.method == 'neargrid' and not args.no_batch and args.size <= 640:
+        out['batch_two_in_flight'] = batch_leg(args.size, args.steps, mode, iters, lattice, atoms, background)
+        out['batch_two_in_flight']['vs_single_job'] = out['batch_two_in_flight']['value'] / out['value']
     if world == 1 and args.method == 'neargrid' and not args.no_user_legs and args.size >= 256:
         out['user_legs'] = user_legs(args.size, min(args.steps, 10), args.warmup and 2, mode, iters, step_s / nvox * 1e9, stage_names)
 

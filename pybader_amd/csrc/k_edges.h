@@ -181,6 +181,9 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known
 #define ET_X 4
 #define ET_Y 8
 #define ET_Z 64
+#ifndef XB_EF_XCD
+#define XB_EF_XCD 1   // the sweeps over listed tiles: an eighth of the list per XCD (k_edge_flag_listed); 0: tiles dealt out in turn (A/B)
+#endif
 // one tile at (tx0 planes from xa, y0, z0); `buni` null: no uniformity shortcut (the caller knows the tile is mixed)
 __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restrict__ rho, const int *__restrict__ labels,
                                           int8_t *__restrict__ known, int xa, int nplanes, int *__restrict__ list,
@@ -496,7 +499,9 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_tiles(GridL g, int8_t *know
     __shared__ __attribute__((aligned(16))) int8_t s[(ET_X + 2) * (ET_Y + 2) * ROW];
     static_assert(ET_X * ET_Y * (ET_Z / 8) == TPB && (ET_X + 2) * (ET_Y + 2) * 4 <= TPB, "one 8-voxel chunk per thread");
     const int ntz = g.nz / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y, n = *n_tiles;
-  for (int item = blockIdx.x; item < n; item += gridDim.x) {   // (uniform per block)
+    const int n_xcd = (XB_EF_XCD && gridDim.x % 8 == 0) ? 8 : 1;   // (an eighth of the list per XCD, as in k_edge_flag_listed)
+    const int part = (n + n_xcd - 1) / n_xcd, part0 = (int)(blockIdx.x % n_xcd) * part, part1 = min(n, part0 + part);
+  for (int item = part0 + blockIdx.x / n_xcd; item < part1; item += gridDim.x / n_xcd) {   // (uniform per block)
     const int t = (int)((unsigned)tiles[item] & 0x7fffffffu);
     const int tx0 = (t / (ntz * nty)) * ET_X, y0 = ((t / ntz) % nty) * ET_Y, z0 = (t % ntz) * ET_Z;
     __syncthreads();   // the previous tile's readers are done
@@ -589,8 +594,14 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
     // occupancy, the compiler kept edge_tile's ~60 LDS row addresses alive across iterations; the staging by planes has none.)
     const int n = *n_tiles;
     const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y;
+    // Round 5: workgroups go to the eight XCDs in turn, each XCD has an L2 of its own, and the tile list is in tile order (z fastest):
+    // XCD k sweeps the k-th contiguous eighth of the list, so that the tiles whose halos overlap -- neighbours in z, y and x -- are
+    // staged through ONE L2 at about the same time (round 4 dealt consecutive tiles to different XCDs: 83 % of the sweep's L2
+    // requests missed, every halo line came from HBM once per XCD that touched it).
+    const int n_xcd = (XB_EF_XCD && gridDim.x % 8 == 0) ? 8 : 1;
+    const int part = (n + n_xcd - 1) / n_xcd, part0 = (int)(blockIdx.x % n_xcd) * part, part1 = min(n, part0 + part);
 #pragma unroll 1
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+    for (int item = part0 + blockIdx.x / n_xcd; item < part1; item += gridDim.x / n_xcd) {
         const unsigned entry = (unsigned)tiles[item];
         const int t = (int)(entry & 0x7fffffffu);
         const int tx0 = (t / (ntz * nty)) * ET_X, y0 = ((t / ntz) % nty) * ET_Y, z0 = (t % ntz) * ET_Z;
