@@ -116,6 +116,7 @@ struct xb_ctx {
     long long walk_cap = 0;
     long long stat_deferred = 0;   // retraces redone by the from-rho kernel (sparse table)
     long long stat_ovf_assign = 0, stat_ovf_refine = 0;   // trajectories handed to the exact slow kernel
+    int *bres_last = nullptr;   // the fused neargrid assignment's per-brick trace results (inside `list`), or null
     int *blab = nullptr;        // brick labels of the trapping regions (inside `list`), or null
     int nbk[3] = {0, 0, 0};
     bool grad_valid = false;

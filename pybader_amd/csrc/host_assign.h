@@ -40,43 +40,77 @@ static int read_counter(xb_ctx *c, int idx, int *out) {
     return XB_OK;
 }
 
+#ifndef XB_MID_K
+#define XB_MID_K 32   // voxels of the exact path window of the middle tier (k_ng_trace_list / k_refine_trace over the lean kernels' undecided walkers)
+#endif
 // The exact slow kernel over ovf_list[0..n): whole path in scratch, membership by scanning it (methods.py:411 / refinement.py:200).
 // Round 5: in TIERS -- tier 1 gives every walker 64 path voxels (interleaved storage, up to 2 M walkers per launch), the ones whose
 // path is longer are listed and go on to 2048, then 32768 voxels.  A density with a noisy vacuum hands MILLIONS of walkers over
 // (512^3: 5.8 M); at 2048 walkers x 32768 voxels per launch that took 2800 launches, and the list had a hard cap before.
-static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr, const int *list_in = nullptr) {
+// (round 5, second half) n_dev: the list's length lives on the device and n is only its bound; stage_free: `stage` is nobody's at
+// the moment (a fused assignment, or a fused refinement pass behind its wait) -- the scratch is carved from it behind the list the
+// caller may have put at its front, instead of two allocations per call.  A list of up to 64 K walkers runs its first two tiers
+// BLIND: both launches are sized by the bound, the second reads the first one's retry count on the device, and the host waits
+// once -- for the count of what is left for the third tier (none, almost always) and the error flag.  (216 atoms at 512^3: 11
+// walkers per assignment and 10 per refinement pass reach this function; it used to cost each of them 3 waits, 2 allocations
+// and 2 frees.)
+static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int *changed = nullptr, int *escaped = nullptr, const int *list_in = nullptr,
+                    const int *n_dev = nullptr, bool stage_free = false) {
     if (!max_count) max_count = c->counters + 0;
     if (!changed) changed = c->counters + 2;
     if (!escaped) escaped = c->counters + 3;
     if (n <= 0) return XB_OK;
     const size_t budget = (size_t)128 << 20;   // ints of path scratch per launch (512 MB)
     static const int tiers[3] = {64, 2048, 1 << 15};
-    DevBuf<int> path, lists;
-    HIPCHK(path.alloc(std::min<size_t>(budget, (size_t)n * tiers[0]) + (size_t)(1 << 15) * 64));
-    HIPCHK(lists.alloc(2 * (size_t)n + 8));
-    int *cnt = lists.p + 2 * (size_t)n;     // [0], [1]: lengths of the two retry lists; [2]: err
+    const bool blind = (size_t)n * tiers[1] <= budget;
+    const size_t have = std::max<size_t>(std::min<size_t>(budget, (size_t)n * tiers[0]), blind ? (size_t)n * tiers[1] : 0) + (size_t)(1 << 15) * 64;
+    const size_t n_lists = 2 * (size_t)n + 8;
+    DevBuf<int> path_buf, lists_buf;
+    int *path = nullptr, *lists = nullptr;
+    {
+        const size_t front = (list_in && list_in >= (const int *)c->stage && list_in < (const int *)c->stage + c->stage_bytes / sizeof(int))
+                                 ? (size_t)(list_in - (const int *)c->stage) + (size_t)n : 0;
+        if (stage_free && c->stage && c->stage_bytes / sizeof(int) >= front + have + n_lists) {
+            lists = (int *)c->stage + front;
+            path = lists + n_lists;
+        } else {
+            HIPCHK(path_buf.alloc(have));
+            HIPCHK(lists_buf.alloc(n_lists));
+            path = path_buf.p; lists = lists_buf.p;
+        }
+    }
+    int *cnt = lists + 2 * (size_t)n;     // [0], [1]: lengths of the two retry lists; [2]: err
     HIPCHK(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
     const int *cur = list_in ? list_in : c->ovf_list;
+    const int *cur_n_dev = n_dev;
     int n_cur = n;
+    if (!blind && n_dev) {   // (a long list is sized by its true length)
+        HIPCHK(hipMemcpyAsync(c->host_ints, n_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        n_cur = std::min(n, c->host_ints[0]);
+        cur_n_dev = nullptr;
+    }
     for (int tier = 0; tier < 3 && n_cur > 0; tier++) {
         const int lmax = tiers[tier];
         const bool last = tier == 2;
-        int *next = lists.p + (size_t)(tier & 1) * n, *next_cnt = cnt + (tier & 1);
-        const size_t have = std::min<size_t>(budget, (size_t)n * tiers[0]) + (size_t)(1 << 15) * 64;
-        const int chunk = (int)std::max<size_t>(64, std::min<size_t>(have / lmax, (size_t)n_cur) & ~(size_t)63);
-        for (int o = 0; o < n_cur; o += chunk) {
+        int *next = lists + (size_t)(tier & 1) * n, *next_cnt = cnt + (tier & 1);
+        const int chunk = (blind && !last) ? n_cur : (int)std::max<size_t>(64, std::min<size_t>(have / lmax, (size_t)n_cur) & ~(size_t)63);
+        for (int o = 0; o < n_cur; o += chunk) {   // (blind: one chunk -- the bound times the tier's path length fits)
             const int m = std::min(chunk, n_cur - o);
-            k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, cur + o, m, path.p, lmax, refine,
+            k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, cur + o, m, path, lmax, refine,
                                                              c->first, c->max_list, max_count, c->max_cap, changed, escaped, cnt + 2, nullptr,
-                                                             c->has_vacuum ? 1 : 0, m, 1, last ? nullptr : next, last ? nullptr : next_cnt);
+                                                             c->has_vacuum ? 1 : 0, m, 1, last ? nullptr : next, last ? nullptr : next_cnt, cur_n_dev);
         }
         HIPCHK(hipGetLastError());
         if (last) break;
+        cur = next;
+        if (blind && tier == 0) { cur_n_dev = next_cnt; continue; }   // (tier 1 right behind: its list's length stays on the device)
         HIPCHK(hipMemcpyAsync(c->host_ints, next_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        cur = next;
         n_cur = c->host_ints[0];
+        cur_n_dev = nullptr;
         if (tier == 0) HIPCHK(hipMemsetAsync(cnt + 1, 0, sizeof(int), c->stream));
+        if (tier == 1 && n_cur == 0) return XB_OK;   // (only the last tier can fail: the others list what does not fit)
     }
     HIPCHK(hipMemcpyAsync(c->host_ints, cnt + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));   // (the scratch may go afterwards)
@@ -353,6 +387,37 @@ static bool fused_ok(const xb_ctx *c) {
            g.nx >= 16 && g.ny >= 16 && g.nz >= 16;
 }
 static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
+static int assign_neargrid_tail(xb_ctx *c, int64_t *n_maxima);
+static int fused_numbering_launch(xb_ctx *c);
+
+// numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host), the per-brick
+// uniformity for the edge sweep, `first` left clean, and the state block + the sorted maxima on their way to the host
+static int fused_numbering_launch(xb_ctx *c) {
+    Grid &g = c->g;
+    int *fs = c->fs;
+    const GridL gl = light(g);
+    const int nb1 = c->nbk[1], nb2 = c->nbk[2], nbr = c->nbk[0] * nb1 * nb2;
+    int *walk = c->walk, *box_max = c->box_max_tab, *bres = c->bres_last;
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux, fs + FS_TOTAL);
+    int *buni = reinterpret_cast<int *>(c->st);
+    if (c->regions_pending) {
+        if (g.nz % 4 == 0)
+            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                        box_max, fs, fs + FS_SORT_OK);
+        else
+            k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+                                                                                                     box_max, fs, fs + FS_SORT_OK);
+        if (bres) k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, walk, fs + FS_N_WALK, bres);
+        else {
+            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+            k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
+        }
+    } else
+        k_relabel<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
+    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    HIPCHK(hipGetLastError());
+    return XB_OK;
+}
 
 static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     if (int rc = need_grad(c)) return rc;
@@ -500,25 +565,8 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         HIPCHK(hipGetLastError());
         stage_done("trace");
     }
-    // numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host)
-    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux, fs + FS_TOTAL);
-    int *buni = reinterpret_cast<int *>(c->st);
-    if (c->regions_pending) {
-        if (g.nz % 4 == 0)
-            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
-                                                                                                        box_max, fs, fs + FS_SORT_OK);
-        else
-            k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
-                                                                                                     box_max, fs, fs + FS_SORT_OK);
-        if (bres) k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, walk, fs + FS_N_WALK, bres);
-        else {
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
-            k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
-        }
-    } else
-        k_relabel<<<nblocks(own), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
-    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
-    HIPCHK(hipGetLastError());
+    c->bres_last = bres;
+    if (int rc = fused_numbering_launch(c)) return rc;
     stage_done("numbering + relabel");
     // the ONE host wait of the assignment: state block + the sorted maxima
     HIPCHK(hipMemcpyAsync(c->host_ints, fs, (FS_TOTAL + XB_SORT_MAX) * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // state block + sorted maxima: one transfer
@@ -536,8 +584,19 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         return XB_OK;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    return assign_neargrid_tail(c, n_maxima);
+}
+
+// What the host does once the state block of assign_neargrid_fused has arrived (behind its own wait, or -- xb_assign_refine -- behind
+// the wait of the refinement iteration that was queued after it and found the assignment not to have ended the usual way).
+static int assign_neargrid_tail(xb_ctx *c, int64_t *n_maxima) {
+    Grid &g = c->g;
+    int *fs = c->fs;
+    const int nb1 = c->nbk[1], nb2 = c->nbk[2];
+    int *walk = c->walk, *box_max = c->box_max_tab;
     const int *h = c->host_ints;
     g.main_ties = 0;
+    const GridL gl = light(g);
     if (h[FS_GROW_RETRY]) {   // the short kill schedule did not reach the fixpoint: once more, with the worst-case one from now on
         c->grow_kill_launches = 1 << 20;
         c->stat_grow_retries++;
@@ -566,9 +625,9 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     if (novf > 0) {
         g.main_ties = 1;
         // Round 5, a MIDDLE TIER in front of the exact slow kernel: the listed walkers once more on the table, with an exact path
-        // window of eight voxels instead of the lean walker's two (k_ng_trace_list<8>: the generic walker) -- the running-maximum
+        // window of XB_MID_K = 32 voxels instead of the lean walker's two (k_ng_trace_list: the generic walker) -- the running-maximum
         // test fails wherever a trajectory dips below a density it passed a few steps ago, which a wider window mostly absorbs
-        // (216 atoms at 512^3: 19 K walkers listed, 11 left for the slow kernel).  What it cannot decide either goes on to the
+        // (216 atoms at 512^3: 19 K walkers listed; a window of eight left 11 for the slow kernel -- 0.35 ms of serial path scans per step --, 32 leave none).  What it cannot decide either goes on to the
         // slow kernel's tiers.  The second list lives in `stage` (free during an assignment).
         const GridL glt = light(g);
         const int maxsteps = 8 * (g.nx + g.ny + g.nz) + 64;
@@ -578,15 +637,18 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             c->host_ints[3100] = n_listed;
             HIPCHK(hipMemcpyAsync(c->counters + 15, c->host_ints + 3100, sizeof(int), hipMemcpyHostToDevice, c->stream));
             HIPCHK(hipMemsetAsync(c->counters + 1, 0, sizeof(int), c->stream));
-            k_ng_trace_list<8><<<512, TPB, 0, c->stream>>>(glt, c->grad, box_max, c->blab, nb1, nb2, c->ovf_list, c->counters + 15, c->labels, c->first,
+            k_ng_trace_list<XB_MID_K><<<512, TPB, 0, c->stream>>>(glt, c->grad, box_max, c->blab, nb1, nb2, c->ovf_list, c->counters + 15, c->labels, c->first,
                                                           c->max_list, fs + FS_N_MAX, c->max_cap, list2, c->counters + 1, cap2, maxsteps, c->rho, c->dist_dev,
                                                           c->has_vacuum ? 1 : 0);
             HIPCHK(hipGetLastError());
-            int m2 = 0;
-            if (int rc2 = read_counter(c, 1, &m2)) return rc2;
-            if (m2 > cap2) return fail(XB_E_LIMIT, "%d walkers for the exact slow path exceed its list (%d)", m2, cap2);
-            if (c->opt_dbg & 4) fprintf(stderr, "[assign] %d walkers listed, %d left for the exact slow kernel after the 8-voxel window\n", n_listed, m2);
-            return run_slow(c, m2, 0, fs + FS_N_MAX, nullptr, nullptr, list2);
+            // (what the wider window leaves is a subset of what it was given: the list's length stays on the device, n_listed bounds it)
+            if (c->opt_dbg & 4) {
+                int m2 = 0;
+                if (int rc2 = read_counter(c, 1, &m2)) return rc2;
+                fprintf(stderr, "[assign] %d walkers listed, %d left for the exact slow kernel after the %d-voxel window\n", n_listed, m2, XB_MID_K);
+            }
+            if (n_listed > cap2) return fail(XB_E_LIMIT, "%d walkers for the exact slow path exceed its list (%d)", n_listed, cap2);
+            return run_slow(c, n_listed, 0, fs + FS_N_MAX, nullptr, nullptr, list2, c->counters + 1, true);
         };
         int rc = two_tiers(std::min(novf, c->ovf_cap));
         // more walkers than the list holds (a density that is noise almost everywhere): the unlisted ones still carry -2 in the
@@ -603,10 +665,26 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
         }
         g.main_ties = 0;
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->host_ints, fs + FS_N_MAX, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        // every walker has arrived: the numbering the device declined (k_number_maxima: walkers outstanding) can run there after all
+        // -- relabel, the bricks' uniformity from the trace's notes and the reset of `first` with it (round 5: the host used to
+        // fetch the table, sort it, send the ranks back and relabel with the generic kernels; five waits more, and the edge sweep
+        // of the refinement that follows had to find the uniform bricks by reading them)
+        HIPCHK(hipMemsetAsync(fs + FS_N_OVF, 0, sizeof(int), c->stream));
+        if (int rc2 = fused_numbering_launch(c)) return rc2;
+        HIPCHK(hipMemcpyAsync(c->host_ints, fs, (FS_TOTAL + XB_SORT_MAX) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        nmax = c->host_ints[0];
+        nmax = h[FS_N_MAX];
         if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
+        if (h[FS_SORT_OK]) {
+            c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
+            c->label_wire = label_wire_for(nmax);
+            c->regions_pending = false;
+            c->buni_valid = !c->has_vacuum;
+            c->regions_labels = !c->has_vacuum;
+            c->first_clean = true;
+            if (n_maxima) *n_maxima = nmax;
+            return XB_OK;
+        }
     }
     return finish_numbering_on_host(c, nmax, n_maxima);
 }

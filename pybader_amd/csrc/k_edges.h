@@ -552,8 +552,11 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_tiled(GridL g, const double *
 // uniform VACUUM (its flags are 0, refinement.py:342-343).
 // (tx_lo, tx_n: the tile planes tx_lo, tx_lo + 1, ... modulo nx / ET_X -- a slab lists the tiles of its own planes and of
 // its halo planes separately)
+// (gate: the state block of an assignment whose outcome the host has not seen yet, xb_assign_refine -- no tile is listed unless
+// it ended the usual way: numbered on the device, no tie voxel; the sweep and the retraces then find nothing to do)
 __global__ __launch_bounds__(TPB) void k_edge_tile_list(GridL g, const int *__restrict__ buni3, int *tiles, int *n_tiles, int tx_lo,
-                                                        int tx_n) {
+                                                        int tx_n, const int *gate = nullptr) {
+    if (gate && (gate[FS_SORT_OK] == 0 || gate[FS_TIES] != 0)) return;
     const int ntz = (g.nz + ET_Z - 1) / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y, ntx = (g.nx + ET_X - 1) / ET_X;
     const int i = blockIdx.x * TPB + threadIdx.x;
     bool hit = false;

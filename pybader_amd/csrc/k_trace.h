@@ -728,9 +728,11 @@ __global__ void k_scatter_voxels(const int *__restrict__ idx, int n, const int *
 __global__ void k_trace_slow(Grid g, const double *__restrict__ rho, int *labels, const int8_t *known_ro,
                              int8_t *known, const int *list, int n, int *path, int lmax, int refine, int *first,
                              int *max_list, int *max_count, int max_cap, int *changed, int *escaped, int *err,
-                             int *lens, int has_vacuum = 1, long long sk = 1, long long st = -1, int *retry = nullptr, int *retry_count = nullptr) {
+                             int *lens, int has_vacuum = 1, long long sk = 1, long long st = -1, int *retry = nullptr, int *retry_count = nullptr,
+                             const int *n_dev = nullptr) {
+    // (n_dev: the list's length lives on the device -- the launch is sized by the bound n, the path storage strides by it)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    if (t >= n || (n_dev && t >= *n_dev)) return;
     const int v = list[t];
     if (st < 0) st = lmax;
     int *P0 = path + (size_t)t * st;
