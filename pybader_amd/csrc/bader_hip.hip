@@ -85,6 +85,8 @@ struct xb_ctx {
     int opt_bricks = 1;
     int opt_dbg = 0;
     int opt_ec_groups = 256;    // workgroups of k_ec_chase (at most one per CU)
+    int opt_ec_share = 1;       // k_ec_chase: a long queue sheds its surplus into other workgroups' mailboxes (0: every workgroup keeps what it wakes; A/B, option 29)
+    int *ec_share = nullptr;    // the sharing block of k_ec_chase (activity count, mailbox tails and slots), allocated on first use
     int opt_ec_qcap = EC_Q;     // LDS queue entries used per buffer (smaller only in tests)
     std::vector<int64_t> esc_starts, esc_offsets, esc_vox;  // xb_escaped_paths -> xb_escaped_paths_fetch
     unsigned long long *ec_pend = nullptr;  // edge_check's counter word per voxel (8 N bytes, allocated on first use)
@@ -301,6 +303,7 @@ int xb_set_option(xb_ctx *c, int key, int value) {
     else if (key == 7) c->opt_fused = value != 0;  // 0: the host-driven orchestration on one GPU too (tests compare the two)
     else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
     else if (key == 14) c->opt_lean = value != 0;
+    else if (key == 29) c->opt_ec_share = value != 0;
     else if (key == 16) c->opt_chase = value != 0;
     else if (key == 18) c->opt_narrow_halo = value != 0;
     else if (key == 19) c->opt_self_exchange = value != 0;

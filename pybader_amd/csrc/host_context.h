@@ -33,7 +33,7 @@ int xb_create(int device, xb_ctx **out) {
 
 static void free_grid(xb_ctx *c) {
     hipFree(c->rho); hipFree(c->grad); hipFree(c->labels); hipFree(c->known); hipFree(c->first); hipFree(c->list);
-    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->ec_pflag); c->ec_pflag = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
+    hipFree(c->st); hipFree(c->stage); hipFree(c->ec_pend); c->ec_pend = nullptr; hipFree(c->ec_share); c->ec_share = nullptr; hipFree(c->ec_pflag); c->ec_pflag = nullptr; hipFree(c->max_list); hipFree(c->max_aux); hipFree(c->ovf_list);
     hipFree(c->blab_buf); c->blab_buf = nullptr; c->blab_alloc = 0; c->labels_zero_pending = false;
     hipFree(c->ec_buf); c->ec_buf = nullptr; c->ec_buf_cap = 0; c->grad_cap = 0; c->list_cap = 0;
     c->brick_rec = nullptr; c->grad_cover = 0;

@@ -481,20 +481,57 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
                                                                                          c->counters + 6, cap);
         HIPCHK(hipGetLastError());
         const int groups = std::max(1, std::min(256, c->opt_ec_groups));
+        // (round 5: the workgroups share out a long front through mailboxes -- k_ec_chase)
+        int *share = nullptr;
+        if (c->opt_ec_share && groups >= 2) {
+            if (!c->ec_share) HIPCHK(hipMalloc(&c->ec_share, ec_share_bytes(256)));
+            share = c->ec_share;
+        }
         int n_seeds = 1;
         for (int pass = 0; n_seeds > 0; pass++) {
             if (pass > 256) return fail(XB_E_LIMIT, "xb_edge_check: queue overflow passes did not drain");
             int *cnt_in = c->counters + ((pass & 1) ? 24 : 6), *cnt_out = c->counters + ((pass & 1) ? 6 : 24);
             if (pass) HIPCHK(hipMemsetAsync(cnt_out, 0, sizeof(int), c->stream));
+            if (share) {
+                HIPCHK(hipMemsetAsync(share, 0, ec_share_bytes(groups), c->stream));
+            }
             k_ec_chase<<<groups, EC_CHASE_THREADS, 0, c->stream>>>(g, c->known, pend_w, buf[pass & 1], cnt_in, buf[1 - (pass & 1)], cnt_out,
-                                                                   cap, c->opt_ec_qcap);
+                                                                   cap, c->opt_ec_qcap, share);
             HIPCHK(hipGetLastError());
             // (with the first pass's overflow count also k_ec_first's own seed count: k_ec_chase clamps what it reads to the
             // list's capacity, so a list that was too small must fail HERE, not later as "undecided" -- ADVICE r4)
             if (pass == 0) HIPCHK(hipMemcpyAsync(c->host_ints + 1, c->counters + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             if (int rc = read_counter(c, (pass & 1) ? 6 : 24, &n_seeds)) return rc;
             if (n_seeds > cap || (pass == 0 && c->host_ints[1] > cap)) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
-            if (c->opt_dbg & 4) fprintf(stderr, "edge_check pass %d: %d overflowed (%d groups)\n", pass, n_seeds, groups);
+            if (c->opt_dbg & 4) {
+                fprintf(stderr, "edge_check pass %d: %d overflowed (%d groups)\n", pass, n_seeds, groups);
+                if (share) {
+                    int h[8] = {0};
+                    HIPCHK(hipMemcpy(h, share + 32, sizeof h, hipMemcpyDeviceToHost));
+#ifdef XB_EC_PROBE
+                    {
+                        static unsigned long long hd[256 * 15];
+                        HIPCHK(hipMemcpyFromSymbol(hd, HIP_SYMBOL(xb_dbg), sizeof hd, 1024 * sizeof(unsigned long long)));
+                        int best = 0;
+                        unsigned long long bt = 0;
+                        for (int w = 0; w < groups; w++) {
+                            unsigned long long a = 0;
+                            for (int k = 0; k < 5; k++) a += hd[w * 15 + k];
+                            if (a > bt) { bt = a; best = w; }
+                        }
+                        unsigned long long tot[15] = {0};
+                        for (int w = 0; w < groups; w++) for (int k = 0; k < 15; k++) tot[k] += hd[w * 15 + k];
+                        const char *nm[5] = {"<=8", "<=32", ">32", "shedding", "long"};
+                        for (int k = 0; k < 5; k++)
+                            fprintf(stderr, "  rounds %-8s busiest wg %3d (%.3f ms of rounds): %6llu rounds %8.3f us each (%7.1f entries)   all: %8llu rounds %8.3f us each (%7.1f entries)\n", nm[k], best, bt / 1e5,
+                                    hd[best * 15 + 5 + k], hd[best * 15 + 5 + k] ? hd[best * 15 + k] / 100.0 / hd[best * 15 + 5 + k] : 0.,
+                                    hd[best * 15 + 5 + k] ? (double)hd[best * 15 + 10 + k] / hd[best * 15 + 5 + k] : 0.,
+                                    tot[5 + k], tot[5 + k] ? tot[k] / 100.0 / tot[5 + k] : 0., tot[5 + k] ? (double)tot[10 + k] / tot[5 + k] : 0.);
+                    }
+#endif
+                    fprintf(stderr, "edge_check sharing: %d entries shed, %d received, %d rounds in the busiest workgroup, %d working rounds in all, error %d\n", h[1], h[3], h[2], h[4], h[0]);
+                }
+            }
         }
     }
     HIPCHK(hipMemsetAsync(c->counters + 25, 0, sizeof(int), c->stream));

@@ -1264,22 +1264,67 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word
 // Queue overflows go to `ovf` and seed the next launch.
 #define EC_CHASE_THREADS 1024
 #define EC_Q 6000   // queue entries per buffer (2 buffers of 64-bit entries, 94 KB of LDS)
+// Round 5: SHARING A LONG FRONT.  A workgroup keeps what it wakes, and the fronts are few: without sharing the workgroup that
+// carries the longest one works through 1 082 rounds (the dynamic critical path) of which 550 hold ~70 entries and 180 more than
+// 128 -- 1.9 and 3.4 us each, against 1.3 us for a round of a few entries (the XB_EC_PROBE build) -- because ~7 scattered
+// device-scope atomics per entry go through ONE compute unit's address path, which issues ~600 of them per microsecond
+// (tools/ubench_rtt.hip: one workgroup, 64 / 256 / 640 / 1024 lanes with one atomic each: 0.51 / 0.45 / 1.09 / 1.72 us per round),
+// while most compute units sit idle.  Now the last wave of a workgroup SHEDS up to 64 entries per round of what the queue holds
+// beyond EC_SHARE_KEEP into another workgroup's mailbox: one atomicAdd on the target's tail reserves the slots (each used once per
+// launch), plain device-scope stores fill them; the receiver's last wave looks at a window of its mailbox every round, resolves
+// up to eight arrivals on the spot and queues the rest, and the workgroup keeps what THAT wakes -- a front spreads over as many
+// compute units as it needs within a few rounds.  The result does not depend on who resolves what: the decisions are a function
+// of the words alone.
+// Leaving without a barrier, and without assuming that all workgroups of the launch are resident (several contexts may share
+// the card; a workgroup that waits for one that cannot start until it leaves would wait for ever): a workgroup with nothing to do
+// CLOSES its mailbox -- atomicExch of the tail with EC_MB_CLOSED: the old value says how many slots were ever reserved; it stays
+// until those are filled and consumed, and leaves when it has nothing to do again.  A sender whose reservation falls beyond the
+// capacity -- a full mailbox or a closed one -- simply keeps the entries.  So every entry is resolved by somebody, whatever the
+// order of events.  WHEN to close is only a matter of speed: `active` (a hint: the workgroups that have started and have work)
+// is zero, or EC_LINGER idle rounds have passed -- helpers should be around while fronts are being carried.
+#ifndef EC_SHARE_KEEP
+#define EC_SHARE_KEEP 32
+#endif
+#define EC_MB_CAP 8192            // slots of a workgroup's mailbox (64-bit entries; single use per launch)
+#define EC_MB_CLOSED (1 << 30)    // a tail at or beyond this: the mailbox takes no more entries
+#define EC_LINGER (1 << 15)       // idle rounds (~0.5 us each) after which a workgroup closes whatever the hint says
+// the sharing block: int 0 the hint, int 32 an error flag, ints 33.. statistics, the tails (one int per workgroup) from int 64 on,
+// the slots from byte EC_SLOTS_AT on; all zero at launch
+#define EC_SLOTS_AT 4096
+__host__ __device__ __forceinline__ size_t ec_share_bytes(int groups) { return EC_SLOTS_AT + (size_t)groups * EC_MB_CAP * sizeof(ec_word); }
 __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *known, ec_word *pend,
                                                                const int *__restrict__ seeds, const int *n_seeds_dev, int *ovf,
-                                                               int *n_ovf, int ovf_cap, int qcap) {
+                                                               int *n_ovf, int ovf_cap, int qcap, int *share) {
     __shared__ ec_word q[2][EC_Q];
-    __shared__ int s_n[2];
+    __shared__ int s_n[2], s_stop, s_act, s_closed, s_reserved;
     const int n_seeds = min(*n_seeds_dev, ovf_cap);   // (the count stays on the device: the host does not wait for it)
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
     const int seed_end = min(seed_cur + per, n_seeds);
     if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_stop = 0; s_act = gridDim.x; s_closed = 0; s_reserved = 0; }
     __syncthreads();
     const double inv_nyz = 1.0 / (double)g.nyz, inv_nz = 1.0 / (double)g.nz;
-    for (int cur = 0;; cur ^= 1) {
+    const int G = gridDim.x;
+    int *tails = share ? share + 64 : nullptr;
+    ec_word *slots = share ? reinterpret_cast<ec_word *>(reinterpret_cast<char *>(share) + EC_SLOTS_AT) : nullptr;
+    const int wave = threadIdx.x / XB_WAVE, lane = threadIdx.x % XB_WAVE;
+    const bool last_wave = share && wave == EC_CHASE_THREADS / XB_WAVE - 1;
+    ec_word *my_box = share ? slots + (size_t)blockIdx.x * EC_MB_CAP : nullptr;
+    int head = 0;              // (last wave, uniform over its lanes) the next slot of this workgroup's mailbox
+    bool counted = false;      // (last wave, lane 0) this workgroup is part of the hint
+    unsigned idle_rounds = 0;  // (last wave, lane 0)
+    if (last_wave && lane == 0 && seed_cur < seed_end) { atomicAdd(share, 1); counted = true; }
+    int dbg_shed = 0, dbg_rounds = 0, dbg_got = 0;
+#ifdef XB_EC_PROBE
+    unsigned long long pr_t[5] = {0, 0, 0, 0, 0}, pr_c[5] = {0, 0, 0, 0, 0}, pr_e[5] = {0, 0, 0, 0, 0};   // rounds by class: <= 8, <= 32, more entries, shedding, the long form
+#endif
+    for (int cur = 0, round = 0;; cur ^= 1, round++) {
         const int n = min(s_n[cur], qcap);  // qcap <= EC_Q (smaller only to exercise the overflow path in tests)
         const int take = n <= qcap / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
-        if (n + take == 0) break;
+        if (n + take == 0 && !share) break;
+        if (share && s_stop) break;   // (uniform: set before the previous round's last barrier)
+        const int act_prev = s_act, closed = s_closed, reserved = s_reserved;
         __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
         if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
         ec_word *nq = q[cur ^ 1];
@@ -1292,18 +1337,110 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                 if (o < ovf_cap) ovf[o] = (int)(unsigned int)u;
             }
         };
-        if (n > EC_LONG_N) {   // a long queue (the first rounds): throughput counts, a lane per entry
-            for (int e = threadIdx.x; e < n; e += EC_CHASE_THREADS) ec_resolve<false>(g, known, pend, q[cur][e], push);
+        // what this round gives away: up to 64 entries from the end of the queue -- in the chains' tail whatever it holds beyond
+        // EC_SHARE_KEEP, of a long queue a wave's worth once a quarter of the workgroups are idle
+        const int shed = !share ? 0 : (n <= EC_LONG_N ? min(max(n - EC_SHARE_KEEP, 0), XB_WAVE) : (4 * act_prev < 3 * G ? XB_WAVE : 0));
+        const int n_own = n - shed;
+        const bool work = n + take > 0;
+        dbg_rounds += work ? 1 : 0;
+#ifdef XB_EC_PROBE
+        const unsigned long long pr_t0 = wall_clock64();
+#endif
+        if (last_wave) {
+            // (a) the mailbox: a window from the head on (a closed one: the slots reserved before it closed)
+            const int limit = closed ? reserved : EC_MB_CAP;
+            ec_word got = 0;
+            if (head + lane < limit) got = __hip_atomic_load(my_box + head + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int act = 1;
+            if (lane == 0) act = __hip_atomic_load(share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (b) this round's surplus
+            if (shed) {
+                unsigned h = (unsigned)(blockIdx.x * 977u + (unsigned)round * 131u);
+                h ^= h >> 7;
+                int target = (int)(h % (unsigned)(G - 1));
+                if (target >= (int)blockIdx.x) target++;
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(tails + target, shed);
+                slot = __shfl(slot, 0);
+                if (lane < shed) {
+                    const ec_word e = q[cur][n_own + lane];
+                    if ((unsigned)(slot + lane) < (unsigned)EC_MB_CAP)
+                        __hip_atomic_store(slots + (size_t)target * EC_MB_CAP + slot + lane, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        push(e);   // that mailbox is full or closed: the entry stays here
+                }
+                dbg_shed += shed;
+            }
+            // (a, continued) what arrived: the filled slots in front of the first gap; the first eight are resolved here and now
+            // (eight lanes each, as in the tail form below), the others join the next round's queue
+            const unsigned long long full = __ballot(got != 0);
+            const int k = full == ~0ull ? XB_WAVE : __ffsll((unsigned long long)~full) - 1;
+            if (k) {   // (uniform over the wave)
+                const int now = min(k, XB_WAVE / EC_LANES);
+                if (k > now) {
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(n_next, k - now);
+                    at = __shfl(at, 0);
+                    if (lane >= now && lane < k) {
+                        if (at + lane - now < qcap) nq[at + lane - now] = got;
+                        else {
+                            const int o = atomicAdd(n_ovf, 1);
+                            if (o < ovf_cap) ovf[o] = (int)(unsigned int)got;
+                        }
+                    }
+                }
+                const ec_word mine = __shfl(got, lane / EC_LANES);
+                if (lane / EC_LANES < now) ec_resolve_lanes(g, inv_nyz, inv_nz, known, pend, mine, lane % EC_LANES, push);
+                head += k;
+                dbg_got += k;
+            }
+            // (c) stay, close or leave (one lane decides; the others read the verdict after the round's last barrier)
+            if (lane == 0) {
+                s_act = act;
+                if (work || k) {
+                    idle_rounds = 0;
+                    if (!counted && !closed) { atomicAdd(share, 1); counted = true; }
+                } else {
+                    if (counted) { atomicSub(share, 1); counted = false; }
+                    idle_rounds++;
+                    if (!closed) {
+                        if (act <= 0 || idle_rounds > EC_LINGER) {
+                            const int old = atomicExch(tails + blockIdx.x, EC_MB_CLOSED);
+                            s_reserved = min(old, EC_MB_CAP);
+                            s_closed = 1;
+                        }
+                    } else if (head >= reserved) s_stop = 1;   // closed, everything ever reserved is consumed, nothing to do: leave
+                    else if (idle_rounds > (1u << 24)) { share[32] = 1; s_stop = 1; }   // (a reserved slot that never fills: loud, not endless)
+                }
+            }
+        }
+        if (n_own > EC_LONG_N) {   // a long queue (the first rounds): throughput counts, a lane per entry
+            for (int e = threadIdx.x; e < n_own; e += EC_CHASE_THREADS) ec_resolve<false>(g, known, pend, q[cur][e], push);
         } else {                                       // the chains' tail: latency counts, EC_LANES lanes per entry
-            for (int e0 = 0; e0 < n; e0 += EC_CHASE_THREADS / EC_LANES) {
+            for (int e0 = 0; e0 < n_own; e0 += EC_CHASE_THREADS / EC_LANES) {
                 const int e = e0 + (int)(threadIdx.x / EC_LANES);
-                if (e < n) ec_resolve_lanes(g, inv_nyz, inv_nz, known, pend, q[cur][e], threadIdx.x % EC_LANES, push);
+                if (e < n_own) ec_resolve_lanes(g, inv_nyz, inv_nz, known, pend, q[cur][e], threadIdx.x % EC_LANES, push);
             }
         }
         for (int e = threadIdx.x; e < take; e += EC_CHASE_THREADS)   // seeds: a lane each (they read their word and claim first)
             ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)seeds[seed_cur + e], push);
         seed_cur += take;
+        if (share && !work) __builtin_amdgcn_s_sleep(8);   // nothing to do: wait a little before looking again
         __syncthreads();  // the next round's queue is complete (every atomic's result was used: they have returned)
+#ifdef XB_EC_PROBE
+        if (work) {
+            const unsigned long long dt = wall_clock64() - pr_t0;
+            const int cls = n > EC_LONG_N ? 4 : (shed ? 3 : (n_own <= 8 ? 0 : (n_own <= 32 ? 1 : 2)));
+            pr_t[cls] += dt; pr_c[cls]++; pr_e[cls] += n_own;
+        }
+#endif
+    }
+#ifdef XB_EC_PROBE
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 5; k++) { xb_dbg[1024 + blockIdx.x * 15 + k] = pr_t[k]; xb_dbg[1024 + blockIdx.x * 15 + 5 + k] = pr_c[k]; xb_dbg[1024 + blockIdx.x * 15 + 10 + k] = pr_e[k]; }
+#endif
+    if (last_wave && lane == 0) {   // statistics (debug switch 4 prints them)
+        atomicAdd(share + 33, dbg_shed); atomicAdd(share + 35, dbg_got); atomicMax(share + 34, dbg_rounds); atomicAdd(share + 36, dbg_rounds);
     }
 }
 // the voxels the resolution left undecided (must be none) are counted for a loud failure

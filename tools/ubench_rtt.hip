@@ -50,6 +50,15 @@ int main() {
             if (rep) printf("%s blocks %4d x %d lanes: %.3f us per dependent op\n", cfg < 3 ? "atomicAdd(ret) device scope" : "sc1 load", blocks, threads, ms * 1e3 / n);
         }
     }
+    // one workgroup, more waves: does ONE compute unit's address path limit a round of the chase (k_ec_chase: ~540 scattered atomics
+    // from the workgroup that carries a dependency front)?
+    for (int threads : {64, 256, 640, 1024}) {
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(a); chain_atomic<<<1, threads>>>(p, n, words - 1, out); hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (rep) printf("atomicAdd(ret) device scope, ONE workgroup of %4d lanes: %.3f us per dependent op (every lane one atomic per op)\n", threads, ms * 1e3 / n);
+        }
+    }
     for (int threads : {64, 256, 1024}) {
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(a); chain_barrier<<<256, threads>>>(20000, iout); hipEventRecord(b); hipEventSynchronize(b);
