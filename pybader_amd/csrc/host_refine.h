@@ -505,9 +505,6 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
             if (n_seeds > cap || (pass == 0 && c->host_ints[1] > cap)) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
             if (c->opt_dbg & 4) {
                 fprintf(stderr, "edge_check pass %d: %d overflowed (%d groups)\n", pass, n_seeds, groups);
-                if (share) {
-                    int h[8] = {0};
-                    HIPCHK(hipMemcpy(h, share + 32, sizeof h, hipMemcpyDeviceToHost));
 #ifdef XB_EC_PROBE
                     {
                         static unsigned long long hd[256 * 15];
@@ -529,6 +526,9 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
                                     tot[5 + k], tot[5 + k] ? tot[k] / 100.0 / tot[5 + k] : 0., tot[5 + k] ? (double)tot[10 + k] / tot[5 + k] : 0.);
                     }
 #endif
+                if (share) {
+                    int h[8] = {0};
+                    HIPCHK(hipMemcpy(h, share + 32, sizeof h, hipMemcpyDeviceToHost));
                     fprintf(stderr, "edge_check sharing: %d entries shed, %d received, %d rounds in the busiest workgroup, %d working rounds in all, error %d\n", h[1], h[3], h[2], h[4], h[0]);
                 }
             }
