@@ -166,6 +166,43 @@ def test_large_golden_hashes(ctx, name):
     assert sha(ctx.download_labels(dt)) == str(g['og_ngrefine_changed_2_sha256'])
 
 
+def test_contexts_sharing_the_card_at_the_same_time():
+    """Round 5: the chase of edge_check (k_ec_chase) passes work between its workgroups through mailboxes, and a workgroup may only
+    assume that the OTHERS exist, not that they are running: four contexts (a stream and a host thread each) run config 5 at 256^3 at
+    the same time, three times over -- their 1024-thread workgroups compete for the compute units, launches start piecemeal -- and
+    every one must still give the reference's log and map.  (The first version of the sharing waited for a count that included
+    workgroups which could not start before the waiting ones had left: tests/test_gpu_slabs.py caught it.)"""
+    import threading
+    g = load_golden('c256_cubic')
+    shape = tuple(int(s) for s in g['shape'])
+    errors, results = [], []
+
+    def work(i):
+        try:
+            c = _lib.Context(0)
+            c.set_grid(shape, g['dist_mat'], g['T_grad'])
+            c.synth_density(g['lattice'], g['atoms'], float(g['background']))
+            for _ in range(3):
+                c.set_option(6, 1)
+                c.vacuum_assign(None, float(g['voxel_volume']))
+                c.assign('ongrid')
+                log = c.refine('changed', 2)
+                results.append((np.array(log, np.int64).reshape(-1, 2).tolist(), sha(c.download_labels(np.int8))))
+            c.close()
+        except Exception as e:   # noqa: BLE001 (reported below, in the test's thread)
+            errors.append(repr(e))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 12
+    for log, h in results:
+        assert log == g['og_ngrefine_changed_2_log'].tolist()
+        assert h == str(g['og_ngrefine_changed_2_sha256'])
+
+
 # ---- seeded inputs against the CPU oracle ------------------------------------------------------
 def random_case(seed, shape):
     rng = np.random.default_rng(seed)
@@ -584,8 +621,9 @@ def test_assign_refine_in_one_call_equals_the_two_calls(ctx, name, mode, iters):
     """xb_assign_refine (round 5: the refinement's first iteration queued behind the assignment, one host wait for both) against
     xb_assign followed by xb_refine: maxima, log, map and the state left behind (a second refine) must be the same -- on smooth
     grids (the deferred wait is taken), with a vacuum tolerance (not the fused combination: two calls inside), on 5-digit data
-    with tie voxels, on noise with walkers for the exact slow path and on plateaus (the queued iteration is thrown away and
-    everything runs again the ordinary way) and on a grid too small for the brick pipeline."""
+    with tie voxels, on noise with walkers for the exact slow path and on plateaus (the queued iteration is gated on the assignment's
+    outcome and does nothing; the host part of the assignment takes over, then the refinement as an ordinary call) and on a grid
+    too small for the brick pipeline."""
     from rough_common import load_rough
     if name.startswith('c'):
         g = load_golden(name)
