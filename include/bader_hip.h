@@ -238,6 +238,11 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last);
 /* what travels of a rank's part of blocks 6 / 7 (fixed sizes: no count goes through the host): [0] bytes of a part,
  * [1] header + walkers of the pass itself, [2] header + walkers of a later round, [3] offset and [4] bytes of the results */
 int xb_slab_walk_layout(xb_ctx *c, int64_t out[5]);
+/* (round 5) how many walkers of a rank's part travel in the gather of the NEXT passes (0: the part's capacity).  The scheduler sets it
+ * on every rank to the same value -- a bound on any rank's share it knows from the previous pass's summed export count -- and asks
+ * xb_slab_walk_layout again; a rank that exports more loses the surplus to the host-driven path queries, as with a full part.
+ * Replaces nothing in the reference (its threads share memory, thread_handlers.py:154-232). */
+int xb_slab_walk_send(xb_ctx *c, int64_t walkers);
 /* local[8], global[8]: edges, changed, escaped, walkers still travelling after the last round (all ranks; not summed),
  * retraces redone by the exact slow kernel (then local[1], local[2] are the counts after it and the caller sums once more),
  * walkers lost to a full block or stuck (their voxels stay parked: xb_escaped_paths), this rank's travelling walkers

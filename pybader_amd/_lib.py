@@ -102,6 +102,7 @@ SYMBOLS = {
     'xb_slab_refine_pass': (_int, [_vp]),
     'xb_slab_walkers_round': (_int, [_vp, _int, _int]),
     'xb_slab_walk_layout': (_int, [_vp, _pi64]),
+    'xb_slab_walk_send': (_int, [_vp, _i64]),
     'xb_slab_refine_counts': (_int, [_vp, _pi64, _pi64]),
     'xb_slab_block': (_int, [_vp, _int, C.POINTER(_vp), _pi64, _pi64, _pi64]),
     'xb_slab_block_copy': (_int, [_vp, _int, _int, _vp, _i64, _i64]),
@@ -642,6 +643,10 @@ class Context:
     def slab_walkers_round(self, src, last):
         self.drop_label_token()
         check(self.lib.xb_slab_walkers_round(self.h, int(src), 1 if last else 0))
+
+    def slab_walk_send(self, walkers):
+        """how many walkers of a rank's part travel in the gather of the next passes (0: the capacity); the same value on every rank"""
+        check(self.lib.xb_slab_walk_send(self.h, int(walkers)))
 
     def slab_walk_layout(self):
         """(part bytes, header + walkers of round 0, header + walkers of later rounds, results offset, results bytes)"""

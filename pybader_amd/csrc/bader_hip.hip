@@ -130,6 +130,7 @@ struct xb_ctx {
     void *wbuf[2] = {nullptr, nullptr};   // ... blocks 6 / 7: the walkers of a refinement pass and their results, one part per rank
     void *wk_in = nullptr;                // the walkers this rank carries on in a round (+ their count)
     int wbuf_ranks = 0, walk_last = -1, walk_round = 0, wcap = 0;
+    int walk_send = 0;          // walkers of a rank's part that travel in the pass's own gather (0: the capacity; xb_slab_walk_send)
     int opt_async_comm = 0;    // collectives return without waiting (they are ordered on the context's stream); the device-driven slab step sets it
     int opt_tile_dilate = 1;   // the dilation of the edge sweep tile by tile (k_edge_dilate_tiles) instead of from the edge list (tests compare)
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)

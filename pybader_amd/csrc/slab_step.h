@@ -264,15 +264,32 @@ int xb_slab_block(xb_ctx *c, int which, void **dev_ptr, int64_t *bytes_total, in
 }
 // what travels of a part of blocks 6 / 7: [0] bytes of a part, [1] header + walkers of the pass itself (round 0), [2] header +
 // walkers of a later round, [3] offset and [4] bytes of the results
+// Round 5: what TRAVELS of a part is sized by what the scheduler expects, not by what the part can hold.  The blocks are gathered
+// blind (no count goes through the host), so every rank sends a fixed prefix of its part: `walk_send` walkers in the pass's own
+// gather (the capacity -- ny nz / 8 walkers of 80 bytes, 2.6 MB per rank at 512^3 -- unless xb_slab_walk_send says less: the
+// scheduler knows from the previous pass how many walkers all ranks exported together, which bounds every rank's share), an
+// eighth of the capacity at most in the later rounds, and as many results as that many walkers on every rank can leave behind.
+// A rank that exports more than it may send loses the surplus exactly as it does when the part is full: those retraces stay
+// parked and the host-driven path queries finish them.
+static inline int walk_send_of(const xb_ctx *c, int cap) { return c->walk_send > 0 ? std::min(c->walk_send, cap) : cap; }
+static inline int walk_later_of(const xb_ctx *c, int cap) { return std::min(cap / 8, walk_send_of(c, cap)); }
+static inline int walk_results_of(const xb_ctx *c, int cap) {
+    return (int)std::min<long long>(cap, (long long)walk_send_of(c, cap) * std::max(c->slab_nranks, 1));
+}
+int xb_slab_walk_send(xb_ctx *c, int64_t walkers) {
+    NEED_GRID_RAW("xb_slab_walk_send");
+    c->walk_send = walkers <= 0 ? 0 : (int)std::min<int64_t>(std::max<int64_t>(walkers, 1024), 1 << 20);
+    return XB_OK;
+}
 int xb_slab_walk_layout(xb_ctx *c, int64_t out[5]) {
     NEED_GRID_RAW("xb_slab_walk_layout");
     if (!out) return fail(XB_E_ARG, "xb_slab_walk_layout: null argument");
     const int cap = walk_cap_for(c->g);
     out[0] = (int64_t)walk_part(cap);
-    out[1] = 16 + (int64_t)cap * sizeof(Walker);
-    out[2] = 16 + (int64_t)(cap / 8) * sizeof(Walker);
+    out[1] = 16 + (int64_t)walk_send_of(c, cap) * sizeof(Walker);
+    out[2] = 16 + (int64_t)walk_later_of(c, cap) * sizeof(Walker);
     out[3] = 16 + (int64_t)cap * sizeof(Walker);
-    out[4] = (int64_t)cap * 8;
+    out[4] = (int64_t)walk_results_of(c, cap) * 8;
     return XB_OK;
 }
 // host-staged transports: bytes [off, off + bytes) of a block to / from the host (waits)
@@ -487,7 +504,7 @@ int xb_slab_refine_pass(xb_ctx *c) {
         HIPCHK(hipMemsetAsync(part, 0, 16, c->stream));
         WalkerIO wio{};
         wio.out = (Walker *)(part + 16); wio.out_count = (int *)part;
-        wio.out_cap = c->wcap;
+        wio.out_cap = walk_send_of(c, c->wcap);
         const unsigned grid = (unsigned)std::min<long long>(nblocks((long long)(g.x1 - g.x0) * g.nyz / 16), 1 << 20);
         k_refine_trace<2, false, false, true><<<grid, TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, c->counters + 5, c->counters + 2,
                                                               c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev,
@@ -496,7 +513,8 @@ int xb_slab_refine_pass(xb_ctx *c) {
                                                             c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho, c->dist_dev,
                                                             brec, nullptr, nullptr, 0, slab_regions, wio);
     }
-    k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)((char *)c->wbuf[0] + (size_t)c->slab_rank * walk_part(c->wcap)), c->counters + 20, c->wcap, c->wcap);
+    k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)((char *)c->wbuf[0] + (size_t)c->slab_rank * walk_part(c->wcap)), c->counters + 20, walk_send_of(c, c->wcap),
+                                              walk_results_of(c, c->wcap));
     HIPCHK(hipGetLastError());
     c->slab_stage = 3;
     c->walk_last = -1;
@@ -525,7 +543,7 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last) {
         k_slab_walk_clamp_in<<<1, 1, 0, c->stream>>>(n_in, c->counters + 21, c->walk_round++, cap);
         WalkerIO wio{};
         wio.in = (const Walker *)c->wk_in;
-        wio.out = (Walker *)(part + 16); wio.out_count = (int *)part; wio.out_cap = cap / 8;
+        wio.out = (Walker *)(part + 16); wio.out_count = (int *)part; wio.out_cap = walk_later_of(c, cap);
         wio.res = (int *)(part + 16 + (size_t)cap * sizeof(Walker)); wio.res_count = (int *)part + 1;
         wio.own0 = g.x0; wio.own1 = g.x1;
         const unsigned char *brec = c->grad_cover == 1 ? c->brick_rec : nullptr;
@@ -535,7 +553,7 @@ int xb_slab_walkers_round(xb_ctx *c, int src, int last) {
         k_refine_trace<2, true, true><<<std::min(cap / TPB, 512), TPB, 0, c->stream>>>(gl, c->grad, c->labels, c->known, nullptr, 0, n_in, c->counters + 2,
                                                                               c->counters + 3, c->ovf_list, c->counters + 1, c->ovf_cap, maxsteps, c->rho,
                                                                               c->dist_dev, brec, nullptr, nullptr, 0, slab_regions, wio);
-        k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)part, c->counters + 20, cap / 8, cap);
+        k_slab_walk_clamp<<<1, 1, 0, c->stream>>>((int *)part, c->counters + 20, walk_later_of(c, cap), walk_results_of(c, cap));
     } else {
         k_slab_pack_counts<<<1, 1, 0, c->stream>>>(slab_counts(c), c->counters, blk, c->slab_nranks, c->slab_rank, cap);
         c->walk_last = src;

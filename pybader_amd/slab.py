@@ -241,6 +241,15 @@ class SlabRunner:
         # (or needs the exact slow path) is finished by the host-driven loop.
         rounds = int(os.environ.get('XB_SLAB_WALKER_ROUNDS', 0)) or getattr(self, '_walker_rounds', 3)
         with _Phase(self, 'walkers'):
+            # (round 5) what travels of a part: as many walkers as the previous pass makes us expect (three times the mean share of
+            # its summed export count) instead of the part's capacity (2.6 MB per rank at 512^3, gathered blind on every rank);
+            # every rank computes the same number from the same sums.  No history, or a pass that lost walkers to the limit: the
+            # capacity.  (8 slabs of 512^3: 13 K of 32 K walkers per rank travel -- 12 instead of 21 MB per gather.)
+            want = getattr(self, '_walk_send', 0)
+            if want != getattr(self, '_walk_send_set', None) and hasattr(self.be, 'slab_walk_send'):
+                self.be.slab_walk_send(want)
+                self._walk_send_set = want
+                self._walk_layout = None
             if getattr(self, '_walk_layout', None) is None:
                 self._walk_layout = self.be.slab_walk_layout()
             part, first, later, res_off, res_n = self._walk_layout
@@ -266,6 +275,9 @@ class SlabRunner:
         # -- those went through the host-driven loop below; every rank sees the same sums)
         used = max([k + 1 for k in range(4) if (int(glo[7]) >> (8 * k)) & 0xff] or [0])
         self._walker_rounds = min(6, max(1, used) + (2 if loc[3] else 0))
+        # (glo[2]: retraces that left their rank's planes, all ranks and rounds together; three times the mean share covers the uneven
+        # split between ranks -- the interior slabs of an 8-atom cell export twice the mean; glo[5]: lost or stuck -> the capacity again)
+        self._walk_send = 0 if glo[5] else max(2048, 3 * int(glo[2]) // max(1, self.comm.size))
         if glo[2]:
             self.n_fallbacks += 1
         if loc[3] or glo[5]:

@@ -35,7 +35,7 @@ class LockedBackend(slab.GpuBackend):
     """every library call of this rank runs alone on the card; its wall time is booked to the rank"""
 
     # calls that never touch the card (host-side state of the context): no lock, no device sync, nothing booked
-    HOST_ONLY = {'slab_supported', 'slab_block', 'slab_walk_layout', 'maxima', 'host_waits', 'set_option', 'memory_stats', 'box_stats'}
+    HOST_ONLY = {'slab_supported', 'slab_block', 'slab_walk_layout', 'slab_walk_send', 'maxima', 'host_waits', 'set_option', 'memory_stats', 'box_stats'}
 
     def __init__(self, ctx, book):
         super().__init__(ctx, 0)
