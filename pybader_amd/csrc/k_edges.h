@@ -1209,8 +1209,14 @@ __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, 
         __hip_atomic_fetch_and(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int nl = __popc(later);
-    if (sub >= nl) return;
+    // Round 5: lane `sub` takes the box POSITIONS sub, sub + 8, sub + 16, sub + 24 (one mask operation; round 4 gave it the sub-th and
+    // the (sub + 8)-th SET bit, found by clearing bits one at a time: two loops of up to 7 and 8 dependent steps in front of
+    // the atomics of every hop).  The later neighbours are the 13 positions behind the centre -- 14 .. 26, at most two to a lane --
+    // unless the box wraps around the grid (then any position can be later): a lane issues up to four atomics, all in flight
+    // together.
+    static_assert(EC_LANES == 8, "a lane's positions are sub + 8 k");
+    unsigned int mine = later & (0x01010101u << sub);
+    if (!mine) return;
     // v -> (x, y, z) with two multiplications by reciprocals and a correction step (exact: v < 2^30)
     int x = (int)((double)v * inv_nyz);
     int r = v - x * g.nyz;
@@ -1219,28 +1225,23 @@ __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, 
     int z = r - y * g.nz;
     if (z < 0) { y--; z += g.nz; } else if (z >= g.nz) { y++; z -= g.nz; }
     const ec_word delta = d == 1 ? 0xFFull : ~0ull;  // +0x100 - 1  |  -1
-    // a voxel with more later listed neighbours than lanes (9 to 13 of them is common on a dense sheet): a lane takes the
-    // neighbours sub and sub + EC_LANES TOGETHER, both atomics in flight -- two turns one after the other were two round trips
-    unsigned int m = later;
-    for (int k = 0; k < sub; k++) m &= m - 1;
-    for (int s = sub; s < nl; s += 2 * EC_LANES) {
-        const int j0 = __ffs(m) - 1;
-        unsigned int m1 = m;
-        for (int k = 0; k < EC_LANES; k++) m1 &= m1 - 1;
-        const bool two = s + EC_LANES < nl;
-        const int j1 = two ? __ffs(m1) - 1 : j0;
-        const int u0 = lin3(g, wrapi(x + j0 / 9 - 1, g.nx), wrapi(y + (j0 / 3) % 3 - 1, g.ny), wrapi(z + j0 % 3 - 1, g.nz));
-        const int u1 = lin3(g, wrapi(x + j1 / 9 - 1, g.nx), wrapi(y + (j1 / 3) % 3 - 1, g.ny), wrapi(z + j1 % 3 - 1, g.nz));
-        const ec_word o0 = atomicAdd(pend + u0, delta);
-        ec_word o1 = 0;
-        if (two) o1 = atomicAdd(pend + u1, delta);
-        const unsigned int b0 = (unsigned int)o0 & 0xffffu, b1 = (unsigned int)o1 & 0xffffu;
-        if (!(b0 & (EC_NPROC | EC_CLS1)) && (d == 1 || (b0 & EC_CNT) == 1))
-            push((ec_word)((unsigned int)u0 | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o0 & 0xFFFFFFFF00000000ull));
-        if (two && !(b1 & (EC_NPROC | EC_CLS1)) && (d == 1 || (b1 & EC_CNT) == 1))
-            push((ec_word)((unsigned int)u1 | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o1 & 0xFFFFFFFF00000000ull));
-        m = m1;
-        for (int k = 0; k < EC_LANES; k++) m &= m - 1;
+    ec_word o[4];
+    int u[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = sub + 8 * k;
+        u[k] = -1;
+        o[k] = 0;
+        if (j < 27 && ((mine >> j) & 1u)) {
+            u[k] = lin3(g, wrapi(x + j / 9 - 1, g.nx), wrapi(y + (j / 3) % 3 - 1, g.ny), wrapi(z + j % 3 - 1, g.nz));
+            o[k] = atomicAdd(pend + u[k], delta);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned int b = (unsigned int)o[k] & 0xffffu;
+        if (u[k] >= 0 && !(b & (EC_NPROC | EC_CLS1)) && (d == 1 || (b & EC_CNT) == 1))
+            push((ec_word)((unsigned int)u[k] | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o[k] & 0xFFFFFFFF00000000ull));
     }
 }
 // Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
@@ -1296,12 +1297,12 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                                                                const int *__restrict__ seeds, const int *n_seeds_dev, int *ovf,
                                                                int *n_ovf, int ovf_cap, int qcap, int *share) {
     __shared__ ec_word q[2][EC_Q];
-    __shared__ int s_n[2], s_stop, s_act, s_closed, s_reserved;
+    __shared__ int s_n[3], s_stop, s_act, s_closed, s_reserved;   // (three queue lengths in rotation: this round's, the next one's, and the one being reset)
     const int n_seeds = min(*n_seeds_dev, ovf_cap);   // (the count stays on the device: the host does not wait for it)
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
     const int seed_end = min(seed_cur + per, n_seeds);
-    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_stop = 0; s_act = gridDim.x; s_closed = 0; s_reserved = 0; }
     __syncthreads();
     const double inv_nyz = 1.0 / (double)g.nyz, inv_nz = 1.0 / (double)g.nz;
@@ -1319,16 +1320,18 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
 #ifdef XB_EC_PROBE
     unsigned long long pr_t[5] = {0, 0, 0, 0, 0}, pr_c[5] = {0, 0, 0, 0, 0}, pr_e[5] = {0, 0, 0, 0, 0};   // rounds by class: <= 8, <= 32, more entries, shedding, the long form
 #endif
-    for (int cur = 0, round = 0;; cur ^= 1, round++) {
-        const int n = min(s_n[cur], qcap);  // qcap <= EC_Q (smaller only to exercise the overflow path in tests)
+    // ONE barrier per round (round 5; two before): the length of the queue a round reads, of the one it fills and of the one after
+    // that are three words in rotation -- the third is reset while nobody looks at it (it was read a round ago, before that round's
+    // barrier, and is written from the next round on), so no barrier has to separate the reads of a round from the reset
+    for (int cur = 0, round = 0, ci = 0;; cur ^= 1, round++, ci = ci == 2 ? 0 : ci + 1) {
+        const int n = min(s_n[ci], qcap);  // qcap <= EC_Q (smaller only to exercise the overflow path in tests)
         const int take = n <= qcap / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
         if (n + take == 0 && !share) break;
-        if (share && s_stop) break;   // (uniform: set before the previous round's last barrier)
+        if (share && s_stop) break;   // (uniform: set before the previous round's barrier)
         const int act_prev = s_act, closed = s_closed, reserved = s_reserved;
-        __syncthreads();  // everybody has read s_n[cur] and s_n[1-cur] is no longer in use
-        if (threadIdx.x == 0) s_n[cur] = 0;  // this buffer is the one after next
+        if (threadIdx.x == 0) s_n[ci == 0 ? 2 : ci - 1] = 0;   // the length the round after next will fill
         ec_word *nq = q[cur ^ 1];
-        int *n_next = &s_n[cur ^ 1];
+        int *n_next = &s_n[ci == 2 ? 0 : ci + 1];
         auto push = [&](ec_word u) {
             const int at = atomicAdd(n_next, 1);
             if (at < qcap) nq[at] = u;
