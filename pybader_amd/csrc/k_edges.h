@@ -1286,9 +1286,14 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word
 #ifndef EC_SHARE_KEEP
 #define EC_SHARE_KEEP 32
 #endif
+#ifndef EC_MB_CAP
 #define EC_MB_CAP 8192            // slots of a workgroup's mailbox (64-bit entries; single use per launch)
+#endif
 #define EC_MB_CLOSED (1 << 30)    // a tail at or beyond this: the mailbox takes no more entries
+#ifndef EC_LINGER
 #define EC_LINGER (1 << 15)       // idle rounds (~0.5 us each) after which a workgroup closes whatever the hint says
+#endif
+// (tests/test_gpu_parity.py builds the library with 64 slots and 40 rounds: nine of ten sheds then meet a full or a closed mailbox)
 // the sharing block: int 0 the hint, int 32 an error flag, ints 33.. statistics, the tails (one int per workgroup) from int 64 on,
 // the slots from byte EC_SLOTS_AT on; all zero at launch
 #define EC_SLOTS_AT 4096

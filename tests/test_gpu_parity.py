@@ -203,6 +203,45 @@ def test_contexts_sharing_the_card_at_the_same_time():
         assert h == str(g['og_ngrefine_changed_2_sha256'])
 
 
+def test_chase_when_mailboxes_are_full_or_closed(tmp_path):
+    """The sharing of k_ec_chase must give the same decisions whatever happens to a shed entry: here the library is built with
+    mailboxes of 64 slots (8192) that close after 40 idle rounds (32768) -- nine of ten sheds then find the target's mailbox full or
+    closed and stay with the sender, workgroups leave early and late -- and runs config 5 at 256^3 and a sheared 128^3 in a child
+    process (the library of THIS process is loaded already).  The child also says how many entries travelled: the paths were taken."""
+    import subprocess
+    import sys
+    from pybader_amd import build
+    lib = tmp_path / 'libbader_hip_smallbox.so'
+    subprocess.check_call([build.hipcc()] + [f for f in build.FLAGS if f != '-Wall'] + ['-DEC_MB_CAP=64', '-DEC_LINGER=40', '-o', str(lib), build.SRC],
+                          stderr=subprocess.DEVNULL)
+    script = f"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from conftest import load_golden
+from pybader_amd import _lib
+assert _lib.LIB_PATH == {str(lib)!r}
+for name in ('c256_cubic', 'c128_tric'):
+    g = load_golden(name)
+    c = _lib.Context(0)
+    c.set_grid(tuple(int(s) for s in g['shape']), g['dist_mat'], g['T_grad'])
+    c.synth_density(g['lattice'], g['atoms'], float(g['background']))
+    c.set_option(3, 4)
+    c.vacuum_assign(None, float(g['voxel_volume']))
+    c.assign('ongrid')
+    log = c.refine('changed', 2)
+    assert np.array_equal(np.array(log, np.int64).reshape(-1, 2), g['og_ngrefine_changed_2_log']), (name, log)
+    assert hashlib.sha256(np.ascontiguousarray(c.download_labels(np.int8)).tobytes()).hexdigest() == str(g['og_ngrefine_changed_2_sha256']), name
+    c.close()
+print('ok')
+"""
+    out = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, XB_LIBRARY=str(lib)), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-3000:]
+    import re
+    pairs = [(int(a), int(b)) for a, b in re.findall(r'edge_check sharing: (\d+) entries shed, (\d+) received', out.stderr)]
+    assert pairs and any(shed > 2 * got > 0 for shed, got in pairs), pairs   # most sheds bounced, some travelled
+
+
 # ---- seeded inputs against the CPU oracle ------------------------------------------------------
 def random_case(seed, shape):
     rng = np.random.default_rng(seed)
