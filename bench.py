@@ -209,13 +209,17 @@ def batch_leg(size, steps, mode, iters, lattice, atoms, background, jobs=2):
         c.synth_density(lattice, atoms, background)
         ctxs.append(c)
     results = [None] * jobs
+    errors = []
 
     def work(j, k):
-        c = ctxs[j]
-        for _ in range(k):
-            c.set_option(6, 1)
-            c.vacuum_assign(None, vv)
-            results[j] = c.assign_refine('neargrid', mode, iters)
+        try:
+            c = ctxs[j]
+            for _ in range(k):
+                c.set_option(6, 1)
+                c.vacuum_assign(None, vv)
+                results[j] = c.assign_refine('neargrid', mode, iters)
+        except Exception as e:   # noqa: BLE001 (a thread's failure must fail the leg, not vanish)
+            errors.append(repr(e))
     for j in range(jobs):
         work(j, 2)
         ctxs[j].sync()
@@ -231,6 +235,10 @@ def batch_leg(size, steps, mode, iters, lattice, atoms, background, jobs=2):
     dt = (time.perf_counter() - t0) / (per_job * jobs)
     for c in ctxs:
         c.close()
+    if errors or any(r is None for r in results):
+        raise SystemExit(f'batch leg failed: {errors}')
+    if len({(int(r[0]), tuple(map(tuple, r[1]))) for r in results}) != 1:
+        raise SystemExit(f'batch leg: the jobs disagree on the same density: {results}')
     nv = float(size) ** 3
     return {'workload': f'{jobs} independent {size}^3 densities in flight (a context, a stream and a host thread each), the headline\'s step on each',
             'jobs_in_flight': jobs, 'steps': per_job * jobs, 'ms_per_step': dt * 1e3, 'value': nv / dt / 1e6, 'unit': 'Mvoxels/s',
