@@ -221,9 +221,9 @@ def batch_leg(size, steps, mode, iters, lattice, atoms, background, jobs=2):
         except Exception as e:   # noqa: BLE001 (a thread's failure must fail the leg, not vanish)
             errors.append(repr(e))
     for j in range(jobs):
-        work(j, 2)
+        work(j, 3)
         ctxs[j].sync()
-    per_job = max(1, steps // jobs)
+    per_job = max(10, steps)   # (every job runs as many steps as the headline: a short leg measures the threads' start-up)
     threads = [threading.Thread(target=work, args=(j, per_job)) for j in range(jobs)]
     t0 = time.perf_counter()
     for t in threads:
