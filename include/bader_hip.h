@@ -271,7 +271,8 @@ int xb_enable_timing(xb_ctx *c, int on);
  *   24 collectives return without waiting, 22 slab-sized table / scratch (before xb_set_grid): set by pybader_amd.slab itself;
  *   exactness cross-checks the tests run BOTH ways -- 1 trapping regions (0: plain full trajectories from a record per voxel),
  *   7 device-side control flow (0: the host-driven calls), 13 mirror prefilter of pass A, 14 lean walker (0: the generic one),
- *   16 chase growth (0: propagation launches), 20 diagonal T_grad form, 25 tile-wise dilation;
+ *   16 chase growth (0: propagation launches), 20 diagonal T_grad form, 25 tile-wise dilation,
+ *   29 edge_check's workgroups share long dependency fronts through mailboxes (0: every workgroup keeps what it wakes);
  *   test plumbing -- 4 / 5 workgroups and LDS queue capacity of the edge_check chase (lowered to force the overflow
  *   hand-over), 8 waves of the persistent trace, 17 kill launches scheduled after a chase, 18 narrowed label halos,
  *   19 a rank may exchange planes with itself.

@@ -501,8 +501,10 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
             // (with the first pass's overflow count also k_ec_first's own seed count: k_ec_chase clamps what it reads to the
             // list's capacity, so a list that was too small must fail HERE, not later as "undecided" -- ADVICE r4)
             if (pass == 0) HIPCHK(hipMemcpyAsync(c->host_ints + 1, c->counters + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            if (share) HIPCHK(hipMemcpyAsync(c->host_ints + 2, share + 32, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // (the sharing's error flag)
             if (int rc = read_counter(c, (pass & 1) ? 6 : 24, &n_seeds)) return rc;
             if (n_seeds > cap || (pass == 0 && c->host_ints[1] > cap)) return fail(XB_E_LIMIT, "xb_edge_check: seed list too small");
+            if (share && c->host_ints[2]) return fail(XB_E_STATE, "xb_edge_check: a reserved mailbox slot of the chase was never filled");
             if (c->opt_dbg & 4) {
                 fprintf(stderr, "edge_check pass %d: %d overflowed (%d groups)\n", pass, n_seeds, groups);
 #ifdef XB_EC_PROBE
