@@ -563,8 +563,14 @@ def test_device_driven_step_scheduling_with_a_mock_backend():
         def slab_refine_pass(self):
             calls.append(('pass',))
 
+        send = 0
+
+        def slab_walk_send(self, n):     # (round 5: how many walkers of a part travel; the layout follows)
+            calls.append(('send', int(n)))
+            self.send = int(n)
+
         def slab_walk_layout(self):
-            return [1000, 500, 100, 600, 400]
+            return [1000, 500, 100, 600, 400] if not self.send else [1000, 16 + 4 * self.send // 100, 100, 600, 400]
 
         def slab_walkers_round(self, src, last):
             calls.append(('round', src, bool(last)))
@@ -589,6 +595,17 @@ def test_device_driven_step_scheduling_with_a_mock_backend():
                       ('gather', 6, (0, 100)), ('gather', 6, (600, 400)), ('round', 0, False), ('gather', 7, (0, 100)), ('gather', 7, (600, 400)),
                       ('round', 1, True)]
     assert calls[0] == ('planes', 0) and calls[1] == ('pass',) and ('reduce',) in calls and runner._walker_rounds == 2
+    # ... and what travels of a part in the NEXT pass follows this pass's summed export count (14 walkers on 2 ranks: the floor of
+    # 2048), set on the backend before the layout is asked for again; a pass that lost walkers goes back to the capacity (0)
+    assert [c for c in calls if c[0] == 'send'] == [('send', 0)] and runner._walk_send == 2048   # (no history yet: the capacity)
+    del calls[:]
+    be.counts = (np.array([50, 0, 4000, 0, 0, 0, 0, 0x01]), np.array([100, 0, 9000, 0, 0, 3, 0, 0x01]))
+    runner._finish_escaped = lambda n: 0
+    assert runner.refine('changed', 2)[0] == (100, 0)
+    sends = [c for c in calls if c[0] == 'send']
+    first_gather = next(c for c in calls if c[0] == 'gather')
+    assert sends == [('send', 2048)] and first_gather == ('gather', 6, (0, 16 + 4 * 2048 // 100))
+    assert runner._walk_send == 0      # glo[5] = 3 walkers lost or stuck: the capacity again
     # status 2: this density goes to the host-driven calls, for good
     be.finishes = [(0, 2)]
     assert runner._assign_device_step() is None
