@@ -166,7 +166,7 @@ struct xb_ctx {
     bool labels_zero_pending = false;   // volumes_init without vacuum: labels := 0 is owed (see xb_vacuum_assign)
     int zero_outside[3] = {-1, -1, -1}; // slab (x0, x1, halo) for which every label outside the planes [x0-halo, x1+halo) is known to be 0
     int opt_fused = 1;         // 0: the host-driven round-1 orchestration (kept for slabs and odd grids)
-    int opt_trace_grid = 8192; // waves of the persistent trace (1024 workgroups of eight)
+    int opt_trace_grid = 8192; // waves of the persistent trace (2048 workgroups of XB_TRACE_WAVES = 4)
     unsigned long long *counters64 = nullptr;
     double *dsum = nullptr;
     int *host_ints = nullptr;  // pinned

@@ -548,7 +548,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             const int lean = (gl.use24 && c->opt_lean) ? (c->N <= (1LL << 27) ? 2 : 1) : 0;
 #define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
                       maxsteps, c->has_vacuum ? 1 : 0
-            // persistent workgroups of eight waves, one brick per pull (per-XCD cursors over the Morton-ordered walk list)
+            // persistent workgroups of XB_TRACE_WAVES waves, XB_TRACE_NB bricks per pull (per-XCD cursors over the Morton-ordered walk list)
             const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
             if (lean) {   // the lean walker, the own brick's records in LDS
                 // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)

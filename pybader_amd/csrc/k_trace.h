@@ -311,11 +311,16 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 #ifndef XB_LEAN_K
 #define XB_LEAN_K 2   // voxels of the lean walker's exact path window (2, 3 or 4; build-time): 3 and 4 send fewer walkers of rough densities to the exact slow path (see below) but cost the smooth headline 1.5 % / 3 % of the trace
 #endif
+// The shape of a workgroup of the group trace: XB_TRACE_WAVES waves share out the 8 XB_TRACE_NB eighths of a pull.  What counts is
+// eighths per wave (two: a wave that drew a short one takes another instead of waiting at the barrier) and WAVES PER BARRIER (the
+// slowest of them sets the pace).  Measured at 512^3: 8 waves x 1 brick 1.22 ms (round 4), 8 x 2 1.175 (round 5's first form),
+// 16 x 4 1.29, 8 x 3 1.58 (48 KB of LDS: three workgroups per compute unit), **4 x 1 1.135**, 4 x 2 1.56, 2 x 1 1.45 (the last two
+// lose occupancy to LDS).
 #ifndef XB_TRACE_NB
-#define XB_TRACE_NB 2   // bricks a workgroup of the group trace pulls at a time (their records in LDS: 16 KB each)
+#define XB_TRACE_NB 1   // bricks a workgroup of the group trace pulls at a time (their records in LDS: 16 KB each)
 #endif
 #ifndef XB_TRACE_WAVES
-#define XB_TRACE_WAVES 8   // waves of a workgroup of the group trace
+#define XB_TRACE_WAVES 4   // waves of a workgroup of the group trace
 #endif
 __shared__ GradRec xb_s_rec[512 * XB_TRACE_NB];
 template <bool OFF32, bool CACHE, bool WINDOW = false>
@@ -515,8 +520,8 @@ __device__ __forceinline__ int xcc_id() {
 // different unit.  The trace is bound by exactly that: L2 requests x L2 latency / misses in flight per compute unit
 // (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
 // LEAN 0: the generic walker ng_walk_wave (tests every start voxel, box ids in the keys, table windows); LEAN 3 / 4: the lean
-// walker (4: 32-bit table offsets) -- the workgroup is exactly eight waves, a pull is exactly one brick, and its 512 records are
-// copied into LDS (16 KB) before the waves start (see ng_walk_lean).  (LEAN 1 / 2, the lean walker without the cache, and the
+// walker (4: 32-bit table offsets) -- the workgroup is XB_TRACE_WAVES waves, a pull is XB_TRACE_NB whole bricks, and their records
+// are copied into LDS (16 KB per brick) before the waves start (see ng_walk_lean).  (LEAN 1 / 2, the lean walker without the cache, and the
 // one-wave form k_ng_trace_p were measured against these in round 3 and removed in round 4.)
 template <int K, int LEAN, bool WINDOW = false, bool PART = false>
 __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
@@ -529,9 +534,10 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
     // pass over the labels.)  Per eighth the result of its lane 0, and a flag any lane raises whose result differs from it --
     // plain LDS stores and loads in the wave's program order: no atomics (1024 of them on one address per brick cost 0.2 ms
     // at 512^3), no cross-lane operations.
-    // Round 5: a pull is XB_TRACE_NB bricks (CH = 8 * XB_TRACE_NB eighths for the eight waves to share out): the time probes
-    // (tools/trace_probe.py) show a wave waiting a third of its cycles at the barrier for the slowest eighth of ITS brick -- with
-    // sixteen eighths in the pool a wave that got a short one takes another.
+    // Round 5: a pull is XB_TRACE_NB bricks (CH = 8 * XB_TRACE_NB eighths for the XB_TRACE_WAVES waves to share out): the time probes
+    // (tools/trace_probe.py) showed a wave of the eight-waves-one-brick form waiting a third of its cycles at the barrier for the
+    // slowest eighth of ITS brick -- with two eighths per wave in the pool a wave that got a short one takes another (first as
+    // eight waves and two bricks, then, better, four waves and one brick: half as many waves for the slowest to hold up).
     __shared__ int s_w[8 * XB_TRACE_NB], s_mixed[XB_TRACE_NB];
     constexpr bool CACHE = LEAN >= 3;
     int prev_brick[XB_TRACE_NB];

@@ -239,7 +239,7 @@ print('ok')
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-3000:]
     import re
     pairs = [(int(a), int(b)) for a, b in re.findall(r'edge_check sharing: (\d+) entries shed, (\d+) received', out.stderr)]
-    assert pairs and any(shed > 2 * got > 0 for shed, got in pairs), pairs   # most sheds bounced, some travelled
+    assert pairs and any(shed > got > 0 for shed, got in pairs), pairs   # some sheds bounced off a full or closed mailbox, some travelled
 
 
 # ---- seeded inputs against the CPU oracle ------------------------------------------------------
