@@ -350,6 +350,8 @@ def main():
     ap.add_argument('--no-stage-steps', action='store_true', help='skip the 3 extra steps that time the other stages (profiler runs: only warm-up + timed steps on the card)')
     ap.add_argument('--no-batch', action='store_true', help='skip the two-densities-in-flight throughput leg')
     ap.add_argument('--no-user-legs', action='store_true', help='skip the triclinic / 216-atom / noisy-vacuum legs at the headline size')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the leg that repeats the step for --sustain-s seconds after the timed region')
+    ap.add_argument('--sustain-s', type=float, default=2.5)
     ap.add_argument('--no-odd', action='store_true', help='skip the leg on a grid that is not made of whole 8^3 bricks (500 x 504 x 420)')
     ap.add_argument('--halo', type=int, default=None,
                     help='label planes valid each side of a slab (default 16 for N > 1: a retrace stops when it enters a '
@@ -454,6 +456,20 @@ def main():
     dt = comm.max_float(time.perf_counter() - t0)       # max over ranks
     host_waits = (ctx.host_waits() - waits0 - 2) / args.steps   # waits of this rank for its card inside library calls (less the fence's two)
 
+    # The same step back to back for a few seconds (outside the timed region): the timed K steps above are tens of milliseconds, which
+    # a once-a-second activity sampler never sees; this gives it something to see and shows what the step costs when sustained.
+    sustained = None
+    if not args.no_sustained:
+        n_sus = max(args.steps, min(4000, int(args.sustain_s / max(dt / args.steps, 1e-5))))
+        n_sus = int(comm.max_float(float(n_sus)))       # the same count on every rank
+        fence()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        fence()
+        dts = comm.max_float(time.perf_counter() - ts)
+        sustained = {'steps': n_sus, 'seconds': dts, 'ms_per_step': dts / n_sus * 1e3}
+
     nvox = float(np.prod(shape))
     # N > 1: where a slab step spends its time, from two EXTRA steps with a device sync around every scheduler phase
     # (the timed steps above run without those syncs)
@@ -534,6 +550,7 @@ def main():
                    'trapping_boxes': {'count': ctx.box_stats()[0], 'voxel_fraction': ctx.box_stats()[1] / nvox}},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic,
+                     'hbm_moved_gbs': (traffic / step_s / 1e9) if traffic else None,   # what the memory system actually moves per second (quoted traffic / measured step time)
                      'traffic_note': 'NOT measured in this run: quoted from the committed PMC summary ' + str(traffic_src) +
                                      ' -- HBM bytes of ONE steady-state step = (FETCH_SIZE + WRITE_SIZE) x 1024 summed over its kernels, '
                                      'separate rocprofv3 --pmc passes of this command with the same kernel sources (hash checked; other '
@@ -544,6 +561,9 @@ def main():
                      'kernel_timing': f'HIP events on the library stream: {stage_names[dom_timer]} inside the timed region (the only timer on there); the other stages in 3 extra steps with every timer on',
                      'stage_ms_avg': avg},
     }
+
+    out['sustained'] = sustained
+    cpu_tasks = []     # every CPU-oracle leg runs after the last GPU leg: the card's work stays in one stretch of the run
 
     # BASELINE config 5 (ongrid assign + neargrid edge refinement, the divergent-path stress case) in the same run, so
     # that it is driver-timed too: same grid, same density, K steps, its own HIP-event stage times
@@ -576,7 +596,7 @@ def main():
         t5b, t5src = traffic_from_profile(None, 'ongrid') if args.size == 512 else (None, 'only recorded at 512^3')
         out['config5']['traffic'] = t5b
         out['config5']['traffic_note'] = 'HBM bytes of one step (FETCH_SIZE + WRITE_SIZE over its kernels): ' + str(t5src)
-        if not args.no_cpu:
+        def cpu_config5():
             # ongrid + refinement against the CPU oracle on the same bounded sample as the neargrid leg below
             import oracle
             shp = (args.cpu_size,) * 3
@@ -598,6 +618,8 @@ def main():
                                               'sample': f'{args.cpu_size}^3 grid, ongrid assign + refine ({mode},{iters}), single thread C port',
                                               'gpu_map_equals_cpu_map': bool(np.array_equal(got5, want5) and np.array_equal(c5.maxima(), bmax5))}
             c5.close()
+        if not args.no_cpu:
+            cpu_tasks.append(cpu_config5)
 
     # A grid the 8^3 brick lattice does not divide (round 4: VERDICT r3 #4 -- FFT grids like 60, 84, 108, 140, 180, 500 are
     # everyday CHGCAR sizes): the same pipeline, the bricks the grid cuts handled in place.  Same cell and atoms, K steps,
@@ -642,7 +664,8 @@ def main():
                            'slow_path_trajectories(assign,refine)': list(co.slow_path_stats()),
                            'stage_ms_avg': {name: (lambda t: t[0] / t[1] if t[1] else 0.0)(co.kernel_time(i)) for i, name in enumerate(stage_names)}}
         co.close()
-        if not args.no_cpu:
+
+        def cpu_odd():
             import oracle
             hshape = (250, 252, 210)
             rho_h = oracle.synth_density(hshape, olat, atoms, background)
@@ -663,6 +686,8 @@ def main():
                                                'sample': f'{hshape[0]} x {hshape[1]} x {hshape[2]} grid, neargrid assign + refine ({mode},{iters}), single thread C port',
                                                'gpu_map_equals_cpu_map': bool(np.array_equal(got_h, want_h) and np.array_equal(ch.maxima(), bmax_h))}
             ch.close()
+        if not args.no_cpu:
+            cpu_tasks.append(cpu_odd)
 
     if world == 1 and args.method == 'neargrid' and not args.no_batch and args.size <= 640:
         out['batch_two_in_flight'] = batch_leg(args.size, args.steps, mode, iters, lattice, atoms, background)
@@ -691,6 +716,8 @@ def main():
         infos = comm.allgather([info['nccl_comm_count'], info['nccl_user_rank'], info['nccl_device'], info['rccl_version']])
         out['config']['rccl'] = {'comm_count_per_rank': [int(i[0]) for i in infos], 'user_rank_per_rank': [int(i[1]) for i in infos],
                                  'device_per_rank': [int(i[2]) for i in infos], 'version': int(infos[0][3])}
+    for task in cpu_tasks:
+        task()
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, (rho_s, dm_s, tg_s, want, bmax) = cpu_baseline(args.cpu_size, args.method, mode, iters,
                                                            lattice, atoms, background, args.size)

@@ -1,6 +1,7 @@
 """ctypes binding of libbader_hip.so (include/bader_hip.h).  No PyTorch, no CPU fallback: if the
 library or a GPU is missing, every entry point raises."""
 import ctypes as C
+import threading
 import os
 
 import numpy as np
@@ -145,7 +146,8 @@ def load():
 # 4 KiB (2 ms per call for 16 MB at 256^3 against 0.35 ms on the bus).  pinned_empty() hands out arrays that live in page-locked
 # buffers from a small pool; a buffer returns to the pool when the last reference to its array is gone (weakref.finalize), so a
 # loop of calls stops allocating after its first pass.  The arrays are ordinary ndarrays (picklable, writeable).
-_POOL_KEEP = 4          # free buffers kept per size; more are given back to the driver
+_POOL_KEEP = 4            # free buffers kept per size; more are given back to the driver
+_POOL_MAX_BYTES = 4 << 30  # free page-locked bytes the pool may hold in total (a batch of CHGCARs of many shapes must not pin the host)
 
 
 class _PinnedBuf:
@@ -159,30 +161,68 @@ class _PinnedBuf:
         return {'shape': (self.nbytes,), 'typestr': '|u1', 'data': (self.ptr, False), 'version': 3}
 
 
-_pool = {}
+_pool = {}                 # nbytes -> free pointers of that size (insertion order of the sizes = age)
+_pool_bytes = 0            # bytes of all free buffers
+_pool_lock = threading.Lock()
 
 
-def _pool_release(ptr, nbytes):
-    free = _pool.setdefault(nbytes, [])
-    if len(free) < _POOL_KEEP:
-        free.append(ptr)
-    elif _lib is not None:
+def _host_free(ptr):
+    if _lib is not None:
         _lib.xb_host_free(C.c_void_p(ptr))
 
 
+def _pool_evict(need):
+    """(lock held) give free buffers back to the driver, oldest size first, until `need` more bytes fit under the cap"""
+    global _pool_bytes
+    for size in list(_pool):
+        free = _pool[size]
+        while free and _pool_bytes + need > _POOL_MAX_BYTES:
+            _host_free(free.pop())
+            _pool_bytes -= size
+        if not free:
+            del _pool[size]
+        if _pool_bytes + need <= _POOL_MAX_BYTES:
+            return
+
+
+def _pool_release(ptr, nbytes):
+    global _pool_bytes
+    with _pool_lock:
+        free = _pool.get(nbytes)
+        if nbytes > _POOL_MAX_BYTES or (free is not None and len(free) >= _POOL_KEEP):
+            _host_free(ptr)
+            return
+        _pool_evict(nbytes)
+        _pool.setdefault(nbytes, []).append(ptr)
+        _pool_bytes += nbytes
+
+
 def pinned_empty(shape, dtype):
-    """np.empty(shape, dtype) in page-locked memory from the pool (falls back to np.empty for small arrays)"""
+    """np.empty(shape, dtype) in page-locked memory from the pool (np.empty for small arrays, and when the driver has no more
+    page-locked memory to give: a pageable result is slower, not wrong)"""
     import weakref
+    global _pool_bytes
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape)) * dtype.itemsize
     if nbytes < (1 << 20):
         return np.empty(shape, dtype)
-    free = _pool.get(nbytes)
-    if free:
-        ptr = free.pop()
-    else:
+    ptr = None
+    with _pool_lock:
+        free = _pool.get(nbytes)
+        if free:
+            ptr = free.pop()
+            _pool_bytes -= nbytes
+            if not free:
+                del _pool[nbytes]
+    if ptr is None:
         p = C.c_void_p()
-        check(load().xb_host_alloc(nbytes, C.byref(p)))
+        rc = load().xb_host_alloc(nbytes, C.byref(p))
+        if rc != 0 or not p.value:
+            with _pool_lock:          # make room once (every free buffer of another size) and try again
+                _pool_evict(_POOL_MAX_BYTES)
+            rc = load().xb_host_alloc(nbytes, C.byref(p))
+            if rc != 0 or not p.value:
+                return np.empty(shape, dtype)
         ptr = p.value
     buf = _PinnedBuf(ptr, nbytes)
     weakref.finalize(buf, _pool_release, ptr, nbytes)
@@ -194,14 +234,26 @@ def pool_owned(a):
     return isinstance(a.base, np.ndarray) and isinstance(a.base.base, _PinnedBuf)
 
 
+def _numpy_owned(a):
+    """the memory of `a` was allocated by numpy itself (malloc / calloc: private anonymous pages) -- not a memmap, a shared-memory
+    segment or any other foreign buffer, whose untouched pages are NOT zeros"""
+    owner = a
+    while isinstance(owner, np.ndarray) and owner.base is not None:
+        if isinstance(owner, np.memmap):
+            return False
+        owner = owner.base
+    return isinstance(owner, np.ndarray) and not isinstance(owner, np.memmap) and owner.flags.owndata
+
+
 def fast_any(a):
     """np.any(a) for a C-contiguous array WITHOUT touching pages nobody has touched: a fresh np.zeros() array is untouched
     anonymous memory -- the kernel's pagemap says so per page (neither present nor swapped: it reads as zeros) -- and scanning
     it would fault every page in (4.7 ms for the 64 MB label array of a 256^3 grid, of a 5 ms call pair).  Pages that are in
-    use are scanned; anything unexpected falls back to np.any."""
+    use are scanned.  Only for memory numpy allocated itself: in a file-backed or shared mapping (np.memmap, shared_memory) a
+    page this process has not touched holds data all the same.  Anything else, or anything unexpected, is np.any."""
     import mmap
     n = a.nbytes
-    if n < (1 << 22) or not a.flags.c_contiguous:
+    if n < (1 << 22) or not a.flags.c_contiguous or not _numpy_owned(a):
         return bool(np.any(a))
     try:
         addr = a.ctypes.data
@@ -214,6 +266,8 @@ def fast_any(a):
             f.seek(first * 8)
             flags = np.frombuffer(f.read((last - first) * 8), np.uint64)
         if flags.size != last - first:
+            return bool(np.any(a))
+        if np.any((flags >> np.uint64(61)) & np.uint64(1)):      # bit 61: file-mapped or shared-anonymous page -- not ours to guess about
             return bool(np.any(a))
         used = (flags >> np.uint64(62)) != 0          # bit 63 present, bit 62 swapped
         b = a.reshape(-1).view(np.uint8)
@@ -493,6 +547,7 @@ class Context:
         n, k = C.c_int64(), C.c_int64()
         check(self.lib.xb_assign_refine(self.h, METHODS[method], REFINE_MODES[mode.lower()], int(iters), C.byref(n), _ptr(log), cap, C.byref(k)))
         m = min(k.value, cap // 2)
+        self.n_maxima = n.value
         return n.value, [(int(log[2 * i]), int(log[2 * i + 1])) for i in range(m)]
 
     def refine(self, mode, iters):

@@ -1,8 +1,7 @@
 // bader_hip.hip -- libbader_hip.so: HIP kernels + C ABI (include/bader_hip.h) for gfx950.  ONE translation unit:
-//   kernels    k_common.h k_table.h k_masks.h k_fused.h k_trace.h k_ongrid.h k_edges.h k_sums.h k_text.h
+//   kernels    k_common.h k_masks.h k_fused.h k_trace.h k_ongrid.h k_edges.h k_sums.h k_text.h
 //   host side  this file (context struct, options, statistics, timing) + host_context.h (life cycle, transfers)
-//              + host_table.h (the table outside the fused pipeline: the quarantined round-1 route) + host_assign.h
-//              + host_refine.h + host_sums.h + host_slab_table.h (host-driven slab calls) + comm.h (RCCL through the ABI)
+//              + host_assign.h (the table outside an assignment, the assignments) + host_refine.h + host_sums.h + host_slab_table.h (host-driven slab calls) + comm.h (RCCL through the ABI)
 //              + slab_step.h (the slab step with its control flow on the device)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see pybader_amd/build.py).
 #include "bader_kernels.h"
@@ -26,7 +25,6 @@ static inline hipError_t xb_counted_sync(hipStream_t s) { xb_waits++; return (hi
 // kernels
 // =============================================================================================
 #include "k_common.h"
-#include "k_table.h"
 #include "k_masks.h"
 #include "k_fused.h"
 #include "k_trace.h"
@@ -288,7 +286,6 @@ extern "C" {
 const char *xb_last_error(void) { return g_err.c_str(); }
 
 #include "host_context.h"
-#include "host_table.h"
 #include "host_assign.h"
 #include "host_refine.h"
 #include "host_sums.h"
@@ -367,6 +364,17 @@ int xb_brick_labels(xb_ctx *c, int32_t *out, int64_t capacity, int64_t dims[3]) 
     return XB_OK;
 }
 #ifdef XB_DEBUG_COUNT
+// the lean walkers / the retraces note their step counts per start voxel in a buffer of their own (tools/walk_lengths.py)
+int xb_debug_steps(xb_ctx *c, int on, signed char *host_out) {
+    static signed char *buf = nullptr;
+    if (host_out && buf) {
+        if (hipMemcpy(host_out, buf, (size_t)c->N, hipMemcpyDeviceToHost) != hipSuccess) return XB_E_HIP;
+    }
+    if (on && !buf && hipMalloc(&buf, (size_t)c->N) != hipSuccess) return XB_E_HIP;
+    if (on && hipMemset(buf, 0, (size_t)c->N) != hipSuccess) return XB_E_HIP;
+    signed char *p = on ? buf : nullptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(xb_dbg_steps), &p, sizeof p) == hipSuccess ? XB_OK : XB_E_HIP;
+}
 int xb_debug_counts(unsigned long long *out, int reset) {
     hipDeviceSynchronize();
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(xb_dbg), sizeof(unsigned long long) * 65536) != hipSuccess) return XB_E_HIP;

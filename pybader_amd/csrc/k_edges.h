@@ -818,8 +818,14 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
         }
         w.init(v, rec.key);
     }
+#ifdef XB_DEBUG_COUNT
+    int dbg_it = 0;
+#endif
     while (__any(moving)) {
         if (moving) {
+#ifdef XB_DEBUG_COUNT
+            dbg_it++;
+#endif
             int qx = 0, qy = 0, qz = 0, lq = 0;
             bool og_move = false;
             if (RESUME && arrive) {   // the move was made by the rank the walker comes from
@@ -901,6 +907,9 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
             }
         }
     }
+#ifdef XB_DEBUG_COUNT
+    if (xb_dbg_steps && valid && !RESUME) xb_dbg_steps[v] = (signed char)min(dbg_it + 1, 127);   // (+1: an edge voxel whose retrace ends before its first step still counts)
+#endif
     int ch = 0, es = 0;
     if (RESUME) {
         if (valid) {
@@ -1302,13 +1311,20 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                                                                const int *__restrict__ seeds, const int *n_seeds_dev, int *ovf,
                                                                int *n_ovf, int ovf_cap, int qcap, int *share) {
     __shared__ ec_word q[2][EC_Q];
-    __shared__ int s_n[3], s_stop, s_act, s_closed, s_reserved;   // (three queue lengths in rotation: this round's, the next one's, and the one being reset)
+    __shared__ int s_n[3];   // (three queue lengths in rotation: this round's, the next one's, and the one being reset)
+    // What lane 0 of the last wave tells the workgroup -- leave / the hint it read / this mailbox is closed / the slots reserved
+    // before it closed -- in TWO copies by round parity: a round reads copy [round & 1] at its top and writes copy [(round + 1) & 1]
+    // in (c).  With one copy and one barrier per round a slow wave's read at the top of a round raced with the last wave's write of
+    // the same round (the waves could then disagree on `shed` -- an entry resolved twice or by nobody -- or leave in different
+    // rounds); the copy a round writes was last read a round ago, before that round's barrier.
+    __shared__ int s_bc[2][4];
+    enum { BC_STOP = 0, BC_ACT = 1, BC_CLOSED = 2, BC_RESERVED = 3 };
     const int n_seeds = min(*n_seeds_dev, ovf_cap);   // (the count stays on the device: the host does not wait for it)
     const int per = (n_seeds + gridDim.x - 1) / gridDim.x;
     int seed_cur = blockIdx.x * per;
     const int seed_end = min(seed_cur + per, n_seeds);
     if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_stop = 0; s_act = gridDim.x; s_closed = 0; s_reserved = 0; }
+    if (threadIdx.x < 2) { s_bc[threadIdx.x][BC_STOP] = 0; s_bc[threadIdx.x][BC_ACT] = gridDim.x; s_bc[threadIdx.x][BC_CLOSED] = 0; s_bc[threadIdx.x][BC_RESERVED] = 0; }
     __syncthreads();
     const double inv_nyz = 1.0 / (double)g.nyz, inv_nz = 1.0 / (double)g.nz;
     const int G = gridDim.x;
@@ -1332,8 +1348,9 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
         const int n = min(s_n[ci], qcap);  // qcap <= EC_Q (smaller only to exercise the overflow path in tests)
         const int take = n <= qcap / 2 ? min(EC_CHASE_THREADS, seed_end - seed_cur) : 0;  // uniform
         if (n + take == 0 && !share) break;
-        if (share && s_stop) break;   // (uniform: set before the previous round's barrier)
-        const int act_prev = s_act, closed = s_closed, reserved = s_reserved;
+        const int *bc = s_bc[round & 1];
+        if (share && bc[BC_STOP]) break;   // (uniform: written in the previous round, before its barrier; nobody writes this copy in this round)
+        const int act_prev = bc[BC_ACT], closed = bc[BC_CLOSED], reserved = bc[BC_RESERVED];
         if (threadIdx.x == 0) s_n[ci == 0 ? 2 : ci - 1] = 0;   // the length the round after next will fill
         ec_word *nq = q[cur ^ 1];
         int *n_next = &s_n[ci == 2 ? 0 : ci + 1];
@@ -1402,9 +1419,9 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                 head += k;
                 dbg_got += k;
             }
-            // (c) stay, close or leave (one lane decides; the others read the verdict after the round's last barrier)
+            // (c) stay, close or leave (one lane decides; the others read the verdict at the top of the next round, after this round's barrier)
             if (lane == 0) {
-                s_act = act;
+                int n_stop = 0, n_closed = closed, n_reserved = reserved;
                 if (work || k) {
                     idle_rounds = 0;
                     if (!counted && !closed) { atomicAdd(share, 1); counted = true; }
@@ -1414,12 +1431,14 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                     if (!closed) {
                         if (act <= 0 || idle_rounds > EC_LINGER) {
                             const int old = atomicExch(tails + blockIdx.x, EC_MB_CLOSED);
-                            s_reserved = min(old, EC_MB_CAP);
-                            s_closed = 1;
+                            n_reserved = min(old, EC_MB_CAP);
+                            n_closed = 1;
                         }
-                    } else if (head >= reserved) s_stop = 1;   // closed, everything ever reserved is consumed, nothing to do: leave
-                    else if (idle_rounds > (1u << 24)) { share[32] = 1; s_stop = 1; }   // (a reserved slot that never fills: loud, not endless)
+                    } else if (head >= reserved) n_stop = 1;   // closed, everything ever reserved is consumed, nothing to do: leave
+                    else if (idle_rounds > (1u << 24)) { share[32] = 1; n_stop = 1; }   // (a reserved slot that never fills: loud, not endless)
                 }
+                int *nb = s_bc[(round + 1) & 1];
+                nb[BC_STOP] = n_stop; nb[BC_ACT] = act; nb[BC_CLOSED] = n_closed; nb[BC_RESERVED] = n_reserved;
             }
         }
         if (n_own > EC_LONG_N) {   // a long queue (the first rounds): throughput counts, a lane per entry

@@ -16,6 +16,28 @@
 // 83 % of them for voxels inside trapping regions whose records nobody reads.
 #pragma once
 
+// ---- tile / brick geometry shared by the kernels of the brick pipeline ----
+// the density tile of passes A (k_brick_masks) and of the ongrid pass (k_og_masks): GT_Z / 8 whole 8^3 bricks in a row along z
+#define GT_X 8
+#define GT_Y 8
+#define GT_Z 32
+
+#define BRK 8   // edge of a brick (voxels)
+#define BG 8    // edge of the chunk of bricks a workgroup of the region growth iterates in LDS (k_brick_grow_dev)
+
+__device__ __forceinline__ int wrap_any(int v, int n) { v %= n; return v < 0 ? v + n : v; }
+
+// brick_rec[b] := flag for the bricks whose x-brick index lies in [b0, b0 + nb) modulo nb0 (the table window of a slab; the
+// whole lattice on one GPU), 0 elsewhere: k_brick_records(walk == nullptr) then writes the records of exactly those bricks
+__global__ void k_flag_window_bricks(int nb0, int per_plane, int b0, int nb, unsigned char flag, unsigned char *brick_rec) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb0 * per_plane) return;
+    int d = b / per_plane - b0;
+    if (d < 0) d += nb0;
+    brick_rec[b] = d < nb ? flag : (unsigned char)0;
+}
+
+
 // Conservative move interval of one axis without the division (see move_ranges_raw for the exact form):
 // with d = grad_dir component, m = max |component| (>= 1e-14), the reference steps int_grad + rha(dr + r),
 // int_grad = rha(d/m), r = d/m - int_grad, |dr| <= 1/2:
@@ -30,6 +52,7 @@
 #endif
 #ifdef XB_DEBUG_COUNT
 __device__ unsigned long long xb_dbg[65536];   // [0..15] pass A's counters; [16..] the trace's time probes (k_ng_trace_g)
+__device__ signed char *xb_dbg_steps;          // per start voxel: the steps its walker took (tools/walk_lengths.py), else nullptr
 #endif
 
 // thread -> (y, z) column of the 8 x 32 tile face, sorted by what a column can contribute to its brick's move mask:
@@ -607,7 +630,7 @@ __global__ __launch_bounds__(TPB, 4) void k_brick_records(GT g, const double *__
                 o.r0 = d0 - (double)i0;
                 o.r1 = d1 - (double)i1;
                 o.r2 = d2 - (double)i2;
-                code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
+                code = step_code(i0, i1, i2);
             }
             o.key = pack_key(c, code, og);
             // (a brick the grid cuts: only its voxels inside the grid have a record)

@@ -292,6 +292,11 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {   // a * b + c, a an
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ int add3(int a, int b, int c) {   // a + b + c as ONE instruction the optimiser cannot split again (it would share b + c with the rare branch that undoes the move)
+    int r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int lin24(const GridL &g, int x, int y, int z) { return mad24(mad24(x, g.ny, y), g.nz, z); }
 // OFF32: every byte offset into the table (32 B per voxel) fits 32 bits (N <= 2^27): scalar base + 32-bit lane offset
 template <bool OFF32>
@@ -322,7 +327,13 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 #ifndef XB_TRACE_WAVES
 #define XB_TRACE_WAVES 4   // waves of a workgroup of the group trace
 #endif
-__shared__ GradRec xb_s_rec[512 * XB_TRACE_NB];
+#ifndef XB_WALK_LOOP
+#define XB_WALK_LOOP 0
+#endif
+#ifndef XB_TRACE_CACHE
+#define XB_TRACE_CACHE 1   // (experiment) 0: no copy of the own brick's records in LDS
+#endif
+__shared__ GradRec xb_s_rec[XB_TRACE_CACHE ? 512 * XB_TRACE_NB : 1];
 template <bool OFF32, bool CACHE, bool WINDOW = false>
 __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
@@ -335,10 +346,119 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
     const int ox8 = sx & ~7, oy8 = sy & ~7, oz8 = sz & ~7;   // origin of the own brick
     GradRec rec = CACHE ? xb_s_rec[soff + (((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7))] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
+#if XB_WALK_LOOP >= 2
+    {
+        // Round 6: the loop in its natural divergent form (the lanes that have arrived drop out of the execution mask: no per-lane
+        // `moving` flag to materialise and test at the loop head, the step count is a scalar), unrolled by two so that the two
+        // voxel indices of the exact path window swap roles instead of being copied, ONE copy of a key per step.
+        int result = -1;
+        int px = sx, py = sy, pz = sz, steps = 0;
+        double dr0 = 0., dr1 = 0., dr2 = 0.;
+        int ia = v, ib = -1;   // current / previous voxel of the path (roles swap every step)
+        double kp = -1.7976931348623157e308, m_old = -1.7976931348623157e308;   // key of the previous voxel; the largest older key
+#ifdef XB_DEBUG_COUNT
+        int dbg_lane_steps = 0;
+#define XB_DBG_LANE_STEP dbg_lane_steps++;
+#else
+#define XB_DBG_LANE_STEP
+#endif
+#if XB_WALK_LOOP == 4
+        // the brick index of the new voxel serves the brick-label lookup AND the test "still in the own brick" (one comparison
+        // with the scalar own index instead of three xors, an or and a comparison on top of the index arithmetic)
+        const unsigned own_b = (unsigned)__builtin_amdgcn_readfirstlane(mad24(mad24(sx >> 3, nb1, sy >> 3), nb2, sz >> 3));
+#define XB_OWN_TEST const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3); const bool own = CACHE && bidx == own_b;
+#define XB_OWN_BIDX
+#else
+#define XB_OWN_TEST const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
+#define XB_OWN_BIDX const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
+#endif
+#define XB_LEAN_STEP(CUR, PREV)                                                                                                   \
+        {                                                                                                                         \
+            const double kc = rec.key;                                                                                            \
+            const int bits = key_bits(kc);                                                                                        \
+            const double t0 = dr0 + rec.r0, t1 = dr1 + rec.r1, t2 = dr2 + rec.r2;                                                 \
+            const int id0 = rha_cs(t0), id1 = rha_cs(t1), id2 = rha_cs(t2);                                                       \
+            const int g0 = code_step(bits, 0), g1 = code_step(bits, 1), g2 = code_step(bits, 2);                                  \
+            px = add3(px, id0, g0); py = add3(py, id1, g1); pz = add3(pz, id2, g2);                                               \
+            dr0 = t0 - (double)id0; dr1 = t1 - (double)id1; dr2 = t2 - (double)id2;                                               \
+            if ((__builtin_amdgcn_ballot_w64((unsigned)px >= (unsigned)g.nx) | __builtin_amdgcn_ballot_w64((unsigned)py >= (unsigned)g.ny) | \
+                 __builtin_amdgcn_ballot_w64((unsigned)pz >= (unsigned)g.nz)) != 0) {                                             \
+                px = wrap3(px, g.nx); py = wrap3(py, g.ny); pz = wrap3(pz, g.nz);                                                 \
+            }                                                                                                                     \
+            int lq = lin24(g, px, py, pz);                                                                                        \
+            const bool stay = (bits & 63) == XB_STAY_CODE, back0 = lq == CUR, back1 = lq == PREV;   /* methods.py:411 */          \
+            const bool og_move = stay || back0 || back1;                                                                          \
+            bool at_max = false;                                                                                                  \
+            if ((__builtin_amdgcn_ballot_w64(stay) | __builtin_amdgcn_ballot_w64(back0) | __builtin_amdgcn_ballot_w64(back1)) != 0) { \
+                if (og_move) {   /* rare: dr = 0 and one ongrid step from p (methods.py:412-447, tabulated) */                    \
+                    const int og = (bits >> 6) & 31;                                                                              \
+                    int ox, oy, oz;                                                                                               \
+                    og_offsets(og, ox, oy, oz);                                                                                   \
+                    at_max = og == XB_OG_SELF;                                                                                    \
+                    dr0 = dr1 = dr2 = 0.;                                                                                         \
+                    px = wrap3(wrap3((px - id0) - g0, g.nx) + ox, g.nx);   /* (back to p: the move is undone from its parts) */   \
+                    py = wrap3(wrap3((py - id1) - g1, g.ny) + oy, g.ny);                                                          \
+                    pz = wrap3(wrap3((pz - id2) - g2, g.nz) + oz, g.nz);                                                          \
+                    lq = lin24(g, px, py, pz);                                                                                    \
+                }                                                                                                                 \
+            }                                                                                                                     \
+            int bl = 0;                                                                                                           \
+            XB_OWN_TEST                                                                                                           \
+            const bool in_win = !WINDOW || own || plane_in_window(g, px);                                                         \
+            if (own) rec = xb_s_rec[soff + (((((px & 7) << 3) | (py & 7)) << 3) | (pz & 7))];                                     \
+            else {                                                                                                                \
+                rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);                                        \
+                XB_OWN_BIDX                                                                                                       \
+                bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));                          \
+            }                                                                                                                     \
+            steps++;                                                                                                              \
+            XB_DBG_LANE_STEP                                                                                                      \
+            const bool arrived = bl > 0 && !at_max;                                                                               \
+            const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps || (WINDOW && !in_win);                     \
+            if (arrived) result = box_max[bl - 1];                                                                                \
+            else if (at_max) result = CUR;                                                                                        \
+            else if (undecided) result = -2;                                                                                      \
+            m_old = max_raw(m_old, kp);                                                                                           \
+            kp = kc;                                                                                                              \
+            PREV = lq;                                                                                                            \
+            if (arrived || at_max || undecided) break;                                                                            \
+        }
+#if XB_WALK_LOOP == 2
+        if (lab0 != -1)
+            for (;;) {
+                XB_LEAN_STEP(ia, ib)
+                XB_LEAN_STEP(ib, ia)
+            }
+#else
+        if (lab0 != -1)
+            for (;;) {
+                XB_LEAN_STEP(ia, ib)
+                const int t = ia; ia = ib; ib = t;
+            }
+#endif
+#undef XB_LEAN_STEP
+#undef XB_OWN_TEST
+#undef XB_OWN_BIDX
+#undef XB_DBG_LANE_STEP
+#ifdef XB_DEBUG_COUNT
+        if (xb_dbg_steps) xb_dbg_steps[v] = (signed char)min(dbg_lane_steps, 127);   // tools/walk_lengths.py
+#endif
+        if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
+        labels[v] = result;
+        note_maximum_wave(result >= 0, result, v, first, max_list, max_count, max_cap);
+        if (result == -2) {
+            const int k = atomicAdd(ovf_count, 1);
+            if (k < ovf_cap) ovf_list[k] = v;
+        }
+        return result;
+    }
+#endif
     bool moving = lab0 != -1;
     int result = -1;
     int px = sx, py = sy, pz = sz, steps = 0;
     double dr0 = 0., dr1 = 0., dr2 = 0.;
+    const unsigned own_b = (unsigned)__builtin_amdgcn_readfirstlane(mad24(mad24(sx >> 3, nb1, sy >> 3), nb2, sz >> 3));   // the own brick (wave uniform)
+    (void)own_b;
     // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key
     int i0 = v, i1 = -1;
     double k0 = rec.key, k1 = -1.7976931348623157e308, m_old = -1.7976931348623157e308;
@@ -354,15 +474,31 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     int i3 = -1;
     double k3 = -1.7976931348623157e308;
 #endif
+#if XB_WALK_LOOP
+    if (moving) for (;;) {
+        {
+#else
     while (__builtin_amdgcn_ballot_w64(moving) != 0) {
         if (moving) {
+#endif
             const int bits = key_bits(rec.key);
             // methods.py:345-363: dr += r; corr = rha(dr); q = p + int_grad + corr; dr -= corr (a voxel without a gradient
             // step has code 63 and r = 0: the move below is garbage for it and replaced by the ongrid step)
             const double t0 = dr0 + rec.r0, t1 = dr1 + rec.r1, t2 = dr2 + rec.r2;
             const int id0 = rha_cs(t0), id1 = rha_cs(t1), id2 = rha_cs(t2);
-            const int m0 = (bits & 3) + id0 - 1, m1 = ((bits >> 2) & 3) + id1 - 1, m2 = ((bits >> 4) & 3) + id2 - 1;
+#ifndef XB_WALK_TWEAK
+#define XB_WALK_TWEAK 0
+#endif
+#if XB_WALK_TWEAK & 2
+            const int g0 = code_step(bits, 0), g1 = code_step(bits, 1), g2 = code_step(bits, 2);
+            px = add3(px, id0, g0); py = add3(py, id1, g1); pz = add3(pz, id2, g2);
+#define m0 (id0 + g0)
+#define m1 (id1 + g1)
+#define m2 (id2 + g2)
+#else
+            const int m0 = code_step(bits, 0) + id0, m1 = code_step(bits, 1) + id1, m2 = code_step(bits, 2) + id2;
             px += m0; py += m1; pz += m2;
+#endif
             dr0 = t0 - (double)id0; dr1 = t1 - (double)id1; dr2 = t2 - (double)id2;
             // the periodic wrap only for the waves that touch the faces of the grid
             if (__builtin_amdgcn_ballot_w64((unsigned)px >= (unsigned)g.nx || (unsigned)py >= (unsigned)g.ny || (unsigned)pz >= (unsigned)g.nz) != 0) {
@@ -392,14 +528,24 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             }
             // both loads in flight together; a lane at its maximum reloads its own record (harmless)
             int bl = 0;
+#if XB_WALK_TWEAK & 1
+            const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
+            const bool own = CACHE && bidx == own_b;
+#else
             const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
+#endif
             const bool in_win = !WINDOW || own || plane_in_window(g, px);
             if (own) rec = xb_s_rec[soff + (((px & 7) << 6) | ((py & 7) << 3) | (pz & 7))];
             else {
                 rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);   // (outside the window: any valid slot, the value is not used)
+#if !(XB_WALK_TWEAK & 1)
                 const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
+#endif
                 bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
             }
+#undef m0
+#undef m1
+#undef m2
             steps++;
             // arrived inside a trapping region (q cannot be an old path voxel: the trajectory would have stopped there
             // already); membership undecidable from the window: exact slow kernel (ongrid moves are appended without a
@@ -423,6 +569,9 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
             i1 = i0; k1 = k0;
             i0 = lq; k0 = rec.key;
         }
+#if XB_WALK_LOOP
+        if (!moving) break;
+#endif
     }
     // a maximum that is itself vacuum hands its -1 to the start voxel (methods.py:449-452)
     if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
@@ -539,7 +688,8 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
     // slowest eighth of ITS brick -- with two eighths per wave in the pool a wave that got a short one takes another (first as
     // eight waves and two bricks, then, better, four waves and one brick: half as many waves for the slowest to hold up).
     __shared__ int s_w[8 * XB_TRACE_NB], s_mixed[XB_TRACE_NB];
-    constexpr bool CACHE = LEAN >= 3;
+    constexpr bool CACHE = LEAN >= 3 && XB_TRACE_CACHE;
+    constexpr bool BRES = LEAN >= 3;
     int prev_brick[XB_TRACE_NB];
 #pragma unroll
     for (int j = 0; j < XB_TRACE_NB; j++) prev_brick[j] = -1;
@@ -565,7 +715,7 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
             pr_wait += clock64() - pr_a;
 #endif
             if (threadIdx.x == 0) {
-                if (CACHE && bres) {
+                if (BRES && bres) {
 #pragma unroll
                     for (int j = 0; j < XB_TRACE_NB; j++) {
                         if (prev_brick[j] >= 0) {
@@ -589,6 +739,11 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
             const long long pr_b = clock64();
             pr_bricks++;
 #endif
+            if (BRES && !CACHE) {
+#pragma unroll
+                for (int j = 0; j < XB_TRACE_NB; j++)
+                    if (base + 8 * j < stop) prev_brick[j] = walk[(base >> 3) + j];   // (uniform)
+            }
             if (CACHE) {   // (CH == 8 * XB_TRACE_NB, base a multiple of 8) thread t copies the record of voxel t of each brick of the pull
                 constexpr int PER = 512 * XB_TRACE_NB / (XB_WAVE * XB_TRACE_WAVES);   // records a thread copies
                 static_assert(PER * XB_WAVE * XB_TRACE_WAVES == 512 * XB_TRACE_NB, "the threads of a workgroup share out the records of a pull evenly");
@@ -639,7 +794,7 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
 #ifdef XB_DEBUG_COUNT
                     pr_walk += clock64() - pr_c;
 #endif
-                    if (CACHE && bres) {
+                    if (BRES && bres) {
                         volatile int *w = s_w;
                         if (lane == 0) w[item - base] = res;
                         if (w[item - base] != res) *(volatile int *)&s_mixed[(item - base) >> 3] = 1;   // (same wave: the store above is older in its LDS queue)
@@ -661,7 +816,7 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
         if (threadIdx.x == 0) xb_dbg[64 + 6 * 8192 + blockIdx.x] = (unsigned long long)pr_bricks;
     }
 #endif
-    if (CACHE && bres) {   // the last bricks this workgroup walked
+    if (BRES && bres) {   // the last bricks this workgroup walked
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll

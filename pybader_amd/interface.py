@@ -8,7 +8,7 @@ numpy operations, in the same order, as the reference (they are inputs of every 
 bit-identical)."""
 import numpy as np
 
-from .thread_handlers import assign_to_atoms, bader_calc, dtype_calc, refine, surface_distance
+from .thread_handlers import assign_to_atoms, bader_calc, bader_calc_refine, dtype_calc, refine, surface_distance
 from .utils import charge_sum, resident, vacuum_assign
 
 
@@ -188,10 +188,23 @@ class Bader:
         else:
             self._run()
 
+    def bader_calc_refine(self):
+        """bader_calc() + refine_volumes(self.bader_volumes) (interface.py:406-409) in one library call
+        (thread_handlers.bader_calc_refine): what __call__ runs when it owns both steps."""
+        self.bader_maxima, self.bader_volumes = bader_calc_refine(
+            self.method, self.refine_method, self.refine_mode, self.reference, self.bader_volumes,
+            self.distance_matrix, self.T_grad, self.threads)
+
+    fused = True      # _run issues bader_calc + refine as one call where the two are adjacent (False: the reference's two calls)
+
     def _run(self):
         self.volumes_init()
-        self.bader_calc()
-        if not self.speed_flag:
+        if not self.speed_flag and self.fused:
+            self.bader_calc_refine()
+            self.sum_volumes(bader=True)
+        else:
+            self.bader_calc()
+        if not self.speed_flag and not self.fused:
             self.refine_volumes(self.bader_volumes)
             self.sum_volumes(bader=True)
         self.bader_to_atom_distance()

@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib, methods, refinement
 from .utils import atom_assign, dtype_calc, ensure_density, ensure_labels, fetch_labels, track_labels
 
-__all__ = ['bader_calc', 'refine', 'assign_to_atoms', 'surface_distance', 'dtype_calc']
+__all__ = ['bader_calc', 'refine', 'bader_calc_refine', 'assign_to_atoms', 'surface_distance', 'dtype_calc']
 
 VERBOSE = True
 
@@ -58,11 +58,46 @@ def refine(method, refine_mode, density, volumes, dist_mat, T_grad, threads):
         fetch_labels(ctx, volumes)
     else:
         volumes.__setitem__(Ellipsis, ctx.download_labels(volumes.dtype))
+    _say_log(log)
+
+
+def _say_log(log):
     if not log:
-        _say("  No edges found.")                  # lines 151-153
+        _say("  No edges found.")                  # thread_handlers.py:151-153
         return
     for k, (edges, changed) in enumerate(log):
         _say(f"  Iteration {k + 1}:\n  Refining {edges} edges: {changed} points changed.")
+
+
+def bader_calc_refine(method, refine_method, refine_mode, density, volumes, dist_mat, T_grad, threads):
+    """bader_calc followed by refine on its result -- what Bader.__call__ issues back to back (interface.py:406-409) -- as ONE
+    library call (xb_assign_refine: the refinement's first iteration is queued behind the assignment on the device, one host wait
+    for both, one label download instead of two).  Not a function of the reference: an entry point for callers that own both
+    steps (pybader_amd.interface.Bader._run).  Same maxima, same final volumes and the same refinement log as the two calls
+    (tests/test_gpu_parity.py::test_assign_refine_in_one_call_equals_the_two_calls); the pre-refinement map is never brought
+    to the host.  Falls back to the two calls where the reference's refine returns silently.
+
+    returns (bader_max int64[N,3], refined volumes narrowed to dtype_calc(-N))."""
+    if method not in methods.__contains__:
+        raise AttributeError(f"module 'pybader.methods' has no attribute '{method}'")
+    check_mode, iters = tuple(refine_mode)
+    if refine_method not in refinement.__contains__ or iters == 0:     # refine would return silently (140-147)
+        return bader_calc(method, density, volumes, dist_mat, T_grad, threads)
+    ctx = _lib.default_context()
+    ctx.set_grid(density.shape, dist_mat, T_grad)
+    ensure_density(ctx, density)
+    ensure_labels(ctx, volumes)
+    n, log = ctx.assign_refine(method, check_mode, iters)
+    _say(f"\n  Refining {check_mode} edges:")
+    refine.last_log = log
+    bader_max = ctx.maxima()
+    dtype = np.dtype(dtype_calc(-n))
+    if volumes.dtype == dtype and volumes.flags.c_contiguous:
+        fetch_labels(ctx, volumes)
+    else:
+        volumes = fetch_labels(ctx, dtype=dtype)
+    _say_log(log)
+    return bader_max, volumes
 
 
 def assign_to_atoms(bader_max, atoms, lattice, volumes, threads):

@@ -85,3 +85,76 @@ def test_fast_any_equals_np_any_without_touching_fresh_pages():
     assert _lib.fast_any(np.ones(shape, np.int8)) is True
     assert _lib.fast_any(np.zeros((8, 8, 8), np.int32)) is False and _lib.fast_any(np.arange(8)) is True
     assert _lib.fast_any(np.zeros(shape, np.int32)[:, ::2]) is False     # not contiguous: np.any
+
+
+def test_fast_any_does_not_guess_about_memory_numpy_did_not_allocate(tmp_path):
+    """an untouched page of a file-backed or shared mapping is not present in this process and holds data all the
+    same -- the pagemap shortcut is only for memory numpy allocated itself; everything else is np.any."""
+    from multiprocessing import shared_memory
+    from pybader_amd import _lib
+    n = 2 << 20                                  # 8 MB of int32: above the size from which the pagemap is asked
+    path = tmp_path / 'ones.bin'
+    np.ones(n, np.int32).tofile(path)
+    for mode in ('r', 'c', 'r+'):                # read-only, copy-on-write, shared
+        m = np.memmap(path, dtype=np.int32, mode=mode)
+        assert _lib.fast_any(m) is True
+        assert _lib.fast_any(m.reshape(128, -1)) is True          # a view of a memmap
+        assert _lib.fast_any(np.asarray(m)) is True               # a plain ndarray over the mapping
+        del m
+    shm = shared_memory.SharedMemory(create=True, size=4 * n)
+    try:
+        np.ndarray((n,), np.int32, buffer=shm.buf)[:] = 1
+        other = shared_memory.SharedMemory(name=shm.name)        # a second mapping: none of its pages touched here
+        try:
+            assert _lib.fast_any(np.ndarray((n,), np.int32, buffer=other.buf)) is True
+        finally:
+            other.close()
+    finally:
+        shm.close()
+        shm.unlink()
+    assert _lib._numpy_owned(np.zeros(8)) and _lib._numpy_owned(np.zeros((4, 4))[1:]) and not _lib._numpy_owned(np.frombuffer(bytearray(64), np.uint8))
+
+
+def test_pinned_pool_is_capped_and_falls_back(monkeypatch):
+    """the pool of page-locked result buffers holds a bounded number of bytes, gives the oldest sizes back first and a
+    failed allocation yields a pageable array instead of an error.  (A fake allocator: no GPU here.)"""
+    import ctypes
+    import gc
+    from pybader_amd import _lib
+    live, freed, fail = {}, [], {'on': False}
+
+    class FakeLib:
+        def xb_host_alloc(self, nbytes, pp):
+            if fail['on']:
+                return -3
+            buf = ctypes.create_string_buffer(nbytes)
+            addr = ctypes.addressof(buf)
+            live[addr] = buf
+            ctypes.cast(pp, ctypes.POINTER(ctypes.c_void_p))[0] = addr
+            return 0
+
+        def xb_host_free(self, p):
+            freed.append(p.value)
+            live.pop(p.value, None)
+            return 0
+
+    fake = FakeLib()
+    monkeypatch.setattr(_lib, 'load', lambda: fake)
+    monkeypatch.setattr(_lib, '_lib', fake)
+    monkeypatch.setattr(_lib, '_pool', {})
+    monkeypatch.setattr(_lib, '_pool_bytes', 0)
+    monkeypatch.setattr(_lib, '_POOL_MAX_BYTES', 5 << 20)
+    a = _lib.pinned_empty((1 << 20,), np.int16)          # 2 MB
+    assert _lib.pool_owned(a)
+    del a
+    gc.collect()
+    assert _lib._pool_bytes == 2 << 20 and not freed
+    b = _lib.pinned_empty((1 << 20,), np.int16)          # reuses the free buffer
+    assert _lib._pool_bytes == 0 and len(live) == 1
+    c = _lib.pinned_empty((1 << 20,), np.int32)          # 4 MB
+    del b, c
+    gc.collect()
+    assert _lib._pool_bytes <= 5 << 20 and len(freed) == 1      # 2 + 4 MB exceed the cap: the older size went back to the driver
+    fail['on'] = True
+    d = _lib.pinned_empty((3 << 20,), np.int8)           # no page-locked memory to be had: a pageable array, not an error
+    assert isinstance(d, np.ndarray) and d.shape == (3 << 20,) and not _lib.pool_owned(d)

@@ -405,6 +405,33 @@ def test_python_mirror_api(ctx):
     assert np.array_equal(v, g['ng_main'])
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(vacuum_tol=1e-3), dict(method='ongrid'), dict(refine_mode=('all', 1)),
+                                dict(refine_mode=('changed', 0)), dict(refine_mode=('changed', -1), vacuum_tol=1e-3)])
+def test_bader_run_fused_equals_the_two_calls(ctx, kw):
+    """Bader._run issues bader_calc + refine as ONE library call (thread_handlers.bader_calc_refine) -- every result
+    slot must equal what the reference's two calls leave."""
+    from pybader_amd import thread_handlers
+    from pybader_amd.interface import Bader
+    thread_handlers.VERBOSE = False
+    g = load_golden('c48_cubic_vac' if 'vacuum_tol' in kw else 'c64_cubic')
+    rho = case_density(g)
+    atoms_cart = synth.atoms_cartesian(g['atoms'], g['lattice'])
+    out = []
+    for fused in (True, False):
+        b = Bader({'charge': rho}, g['lattice'], atoms_cart, **kw)
+        b.fused = fused
+        b()
+        out.append(b)
+    a, b = out
+    assert a.bader_volumes.dtype == b.bader_volumes.dtype and np.array_equal(a.bader_volumes, b.bader_volumes)
+    assert np.array_equal(a.atoms_volumes, b.atoms_volumes) and np.array_equal(a.bader_atoms, b.bader_atoms)
+    for slot in ('bader_maxima', 'bader_charge', 'bader_volume', 'atoms_charge', 'atoms_volume', 'bader_distance', 'atoms_surface_distance'):
+        assert np.array_equal(getattr(a, slot), getattr(b, slot)), slot
+    assert (a.vacuum_charge, a.vacuum_volume) == (b.vacuum_charge, b.vacuum_volume)
+    if not kw:
+        assert np.array_equal(a.bader_volumes, g['ng_changed_2'])
+
+
 @pytest.mark.parametrize('name', FULL)
 def test_surface_distance(ctx, name):
     """thread_handlers.surface_distance on the reference's atom map."""
