@@ -146,20 +146,7 @@ __device__ __forceinline__ bool ng_step(const double *__restrict__ rho, const Gr
 // `key` orders path voxels for the window test only (any fixed per-voxel function keeps that test
 // sound, see PathWindow); exact densities are never taken from it.
 struct __attribute__((aligned(32))) GradRec { double r0, r1, r2, key; };
-#ifndef XB_CODE_SIGNED
-#define XB_CODE_SIGNED 0
-#endif
-#if XB_CODE_SIGNED
-// the integer step of each axis as a SIGNED 2-bit field (-1, 0, 1: one v_bfe_i32 to decode, the step then folds into the
-// three-operand addition of the move); the unused value -2 in all three fields says "no gradient step"
-#define XB_STAY_CODE 42
-__device__ __forceinline__ int step_code(int i0, int i1, int i2) { return (i0 & 3) | ((i1 & 3) << 2) | ((i2 & 3) << 4); }
-__device__ __forceinline__ int code_step(int code, int axis) { return (int)((unsigned)code << (30 - 2 * axis)) >> 30; }
-#else
 #define XB_STAY_CODE 63
-__device__ __forceinline__ int step_code(int i0, int i1, int i2) { return (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4); }
-__device__ __forceinline__ int code_step(int code, int axis) { return ((code >> (2 * axis)) & 3) - 1; }
-#endif
 #define XB_OG_SELF 13
 #define XB_MAX_BOXES 1023
 __device__ __forceinline__ GradRec fetch_rec(const GradRec *__restrict__ G, int l) {
@@ -203,9 +190,9 @@ __device__ __forceinline__ int lin3f(const GridL &g, int x, int y, int z) {
 __device__ __forceinline__ void ng_move_t(const GridL &g, int px, int py, int pz, const GradRec &rec, int code,
                                           double &dr0, double &dr1, double &dr2, int &qx, int &qy, int &qz) {
     int id;
-    dr0 += rec.r0; id = rha_cs(dr0); qx = px + code_step(code, 0) + id; dr0 -= (double)id;
-    dr1 += rec.r1; id = rha_cs(dr1); qy = py + code_step(code, 1) + id; dr1 -= (double)id;
-    dr2 += rec.r2; id = rha_cs(dr2); qz = pz + code_step(code, 2) + id; dr2 -= (double)id;
+    dr0 += rec.r0; id = rha_cs(dr0); qx = px + ((code & 3) - 1) + id; dr0 -= (double)id;
+    dr1 += rec.r1; id = rha_cs(dr1); qy = py + (((code >> 2) & 3) - 1) + id; dr1 -= (double)id;
+    dr2 += rec.r2; id = rha_cs(dr2); qz = pz + ((code >> 4) - 1) + id; dr2 -= (double)id;
     qx = wrap_u(qx, g.nx); qy = wrap_u(qy, g.ny); qz = wrap_u(qz, g.nz);
 }
 
@@ -304,7 +291,7 @@ __device__ __noinline__ GradRec make_rec_rho(const GridL &g, const double *__res
         o.r0 = d0 - (double)i0;
         o.r1 = d1 - (double)i1;
         o.r2 = d2 - (double)i2;
-        code = step_code(i0, i1, i2);
+        code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
     }
     o.key = pack_key(c, code, og);
     return o;

@@ -656,16 +656,16 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             const int lean = (gl.use24 && c->opt_lean) ? (c->N <= (1LL << 27) ? 2 : 1) : 0;
 #define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
                       maxsteps, c->has_vacuum ? 1 : 0
-            // persistent workgroups of XB_TRACE_WAVES waves, XB_TRACE_NB bricks per pull (per-XCD cursors over the Morton-ordered walk list)
+            // persistent workgroups of XB_TRACE_WAVES waves, one brick per pull (per-XCD cursors over the Morton-ordered walk list)
             const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
             if (lean) {   // the lean walker, the own brick's records in LDS
                 // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
                 if (!c->has_vacuum) bres = c->list + 6 * nbr;
                 if (part) {
-                    if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
-                    else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
-                } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
-                else k_ng_trace_g<2, 3><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8 * XB_TRACE_NB, 1, bres);
+                    if (lean == 2) k_ng_trace_g<2, 4, false, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                    else k_ng_trace_g<2, 3, false, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                } else if (lean == 2) k_ng_trace_g<2, 4><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
+                else k_ng_trace_g<2, 3><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1, bres);
             } else   // the generic walker (option 14 = 0: the tests' cross-check; planes or rows beyond 2^24 voxels); it tests every start voxel
                 k_ng_trace_g<2, 0><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(XB_TRACE_ARGS, 8, 1);
 #undef XB_TRACE_ARGS

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(TPB, 4) void k_brick_records(GT g, const double *__
                 o.r0 = d0 - (double)i0;
                 o.r1 = d1 - (double)i1;
                 o.r2 = d2 - (double)i2;
-                code = step_code(i0, i1, i2);
+                code = (i0 + 1) | ((i1 + 1) << 2) | ((i2 + 1) << 4);
             }
             o.key = pack_key(c, code, og);
             // (a brick the grid cuts: only its voxels inside the grid have a record)

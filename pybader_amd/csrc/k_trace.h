@@ -292,11 +292,6 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {   // a * b + c, a an
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ int add3(int a, int b, int c) {   // a + b + c as ONE instruction the optimiser cannot split again (it would share b + c with the rare branch that undoes the move)
-    int r;
-    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 __device__ __forceinline__ int lin24(const GridL &g, int x, int y, int z) { return mad24(mad24(x, g.ny, y), g.nz, z); }
 // OFF32: every byte offset into the table (32 B per voxel) fits 32 bits (N <= 2^27): scalar base + 32-bit lane offset
 template <bool OFF32>
@@ -313,266 +308,100 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // (the cache is a file-scope LDS array, not a pointer argument: handed over as a generic pointer it made the gfx950 backend of
 // this ROCm emit `v_cmp_ne_u32 0, src_shared_base` -- "illegal instruction, operand has incorrect register class" -- for
 // some shapes of the surrounding code)
-#ifndef XB_LEAN_K
-#define XB_LEAN_K 2   // voxels of the lean walker's exact path window (2, 3 or 4; build-time): 3 and 4 send fewer walkers of rough densities to the exact slow path (see below) but cost the smooth headline 1.5 % / 3 % of the trace
-#endif
-// The shape of a workgroup of the group trace: XB_TRACE_WAVES waves share out the 8 XB_TRACE_NB eighths of a pull.  What counts is
-// eighths per wave (two: a wave that drew a short one takes another instead of waiting at the barrier) and WAVES PER BARRIER (the
-// slowest of them sets the pace).  Measured at 512^3: 8 waves x 1 brick 1.22 ms (round 4), 8 x 2 1.175 (round 5's first form),
-// 16 x 4 1.29, 8 x 3 1.58 (48 KB of LDS: three workgroups per compute unit), **4 x 1 1.135**, 4 x 2 1.56, 2 x 1 1.45 (the last two
-// lose occupancy to LDS).
-#ifndef XB_TRACE_NB
-#define XB_TRACE_NB 1   // bricks a workgroup of the group trace pulls at a time (their records in LDS: 16 KB each)
-#endif
-#ifndef XB_TRACE_WAVES
-#define XB_TRACE_WAVES 4   // waves of a workgroup of the group trace
-#endif
-#ifndef XB_WALK_LOOP
-#define XB_WALK_LOOP 0
-#endif
-#ifndef XB_TRACE_CACHE
-#define XB_TRACE_CACHE 1   // (experiment) 0: no copy of the own brick's records in LDS
-#endif
-__shared__ GradRec xb_s_rec[XB_TRACE_CACHE ? 512 * XB_TRACE_NB : 1];
+// The shape of a workgroup of the group trace: XB_TRACE_WAVES waves share out the eight 4x4x4 eighths of ONE brick.  What counts
+// is eighths per wave (two: a wave that drew a short one takes another instead of waiting at the barrier) and WAVES PER BARRIER
+// (the slowest of them sets the pace).  Measured at 512^3 (round 5): 8 waves x 1 brick 1.22 ms, 8 x 2 1.175, 16 x 4 1.29, 8 x 3 1.58
+// (48 KB of LDS: three workgroups per compute unit), **4 x 1 1.135**, 4 x 2 1.56, 2 x 1 1.45 (the last two lose occupancy to LDS).
+constexpr int XB_TRACE_WAVES = 4;
+__shared__ GradRec xb_s_rec[512];   // the records of the brick a workgroup of the group trace walks (16 KB)
 template <bool OFF32, bool CACHE, bool WINDOW = false>
 __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                              const int *__restrict__ blab, int nb1, int nb2, int sx, int sy, int sz,
                                              int *labels, int *first, int *max_list, int *max_count, int max_cap,
-                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum, int soff = 0) {
-    // (soff: where the own brick's records lie in xb_s_rec -- the workgroup holds XB_TRACE_NB bricks at a time)
+                                             int *ovf_list, int *ovf_count, int ovf_cap, int maxsteps, bool has_vacuum) {
     // every start voxel is valid: the walk list holds whole bricks, and the lanes of a brick the grid cuts start from its
     // voxels inside the grid (k_ng_trace_g PART)
     const int v = lin24(g, sx, sy, sz);
     const int lab0 = has_vacuum ? labels[v] : 0;   // without vacuum `labels` is write-only here
     const int ox8 = sx & ~7, oy8 = sy & ~7, oz8 = sz & ~7;   // origin of the own brick
-    GradRec rec = CACHE ? xb_s_rec[soff + (((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7))] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
-#if XB_WALK_LOOP >= 2
-    {
-        // Round 6: the loop in its natural divergent form (the lanes that have arrived drop out of the execution mask: no per-lane
-        // `moving` flag to materialise and test at the loop head, the step count is a scalar), unrolled by two so that the two
-        // voxel indices of the exact path window swap roles instead of being copied, ONE copy of a key per step.
-        int result = -1;
-        int px = sx, py = sy, pz = sz, steps = 0;
-        double dr0 = 0., dr1 = 0., dr2 = 0.;
-        int ia = v, ib = -1;   // current / previous voxel of the path (roles swap every step)
-        double kp = -1.7976931348623157e308, m_old = -1.7976931348623157e308;   // key of the previous voxel; the largest older key
-#ifdef XB_DEBUG_COUNT
-        int dbg_lane_steps = 0;
-#define XB_DBG_LANE_STEP dbg_lane_steps++;
-#else
-#define XB_DBG_LANE_STEP
-#endif
-#if XB_WALK_LOOP == 4
-        // the brick index of the new voxel serves the brick-label lookup AND the test "still in the own brick" (one comparison
-        // with the scalar own index instead of three xors, an or and a comparison on top of the index arithmetic)
-        const unsigned own_b = (unsigned)__builtin_amdgcn_readfirstlane(mad24(mad24(sx >> 3, nb1, sy >> 3), nb2, sz >> 3));
-#define XB_OWN_TEST const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3); const bool own = CACHE && bidx == own_b;
-#define XB_OWN_BIDX
-#else
-#define XB_OWN_TEST const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
-#define XB_OWN_BIDX const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
-#endif
-#define XB_LEAN_STEP(CUR, PREV)                                                                                                   \
-        {                                                                                                                         \
-            const double kc = rec.key;                                                                                            \
-            const int bits = key_bits(kc);                                                                                        \
-            const double t0 = dr0 + rec.r0, t1 = dr1 + rec.r1, t2 = dr2 + rec.r2;                                                 \
-            const int id0 = rha_cs(t0), id1 = rha_cs(t1), id2 = rha_cs(t2);                                                       \
-            const int g0 = code_step(bits, 0), g1 = code_step(bits, 1), g2 = code_step(bits, 2);                                  \
-            px = add3(px, id0, g0); py = add3(py, id1, g1); pz = add3(pz, id2, g2);                                               \
-            dr0 = t0 - (double)id0; dr1 = t1 - (double)id1; dr2 = t2 - (double)id2;                                               \
-            if ((__builtin_amdgcn_ballot_w64((unsigned)px >= (unsigned)g.nx) | __builtin_amdgcn_ballot_w64((unsigned)py >= (unsigned)g.ny) | \
-                 __builtin_amdgcn_ballot_w64((unsigned)pz >= (unsigned)g.nz)) != 0) {                                             \
-                px = wrap3(px, g.nx); py = wrap3(py, g.ny); pz = wrap3(pz, g.nz);                                                 \
-            }                                                                                                                     \
-            int lq = lin24(g, px, py, pz);                                                                                        \
-            const bool stay = (bits & 63) == XB_STAY_CODE, back0 = lq == CUR, back1 = lq == PREV;   /* methods.py:411 */          \
-            const bool og_move = stay || back0 || back1;                                                                          \
-            bool at_max = false;                                                                                                  \
-            if ((__builtin_amdgcn_ballot_w64(stay) | __builtin_amdgcn_ballot_w64(back0) | __builtin_amdgcn_ballot_w64(back1)) != 0) { \
-                if (og_move) {   /* rare: dr = 0 and one ongrid step from p (methods.py:412-447, tabulated) */                    \
-                    const int og = (bits >> 6) & 31;                                                                              \
-                    int ox, oy, oz;                                                                                               \
-                    og_offsets(og, ox, oy, oz);                                                                                   \
-                    at_max = og == XB_OG_SELF;                                                                                    \
-                    dr0 = dr1 = dr2 = 0.;                                                                                         \
-                    px = wrap3(wrap3((px - id0) - g0, g.nx) + ox, g.nx);   /* (back to p: the move is undone from its parts) */   \
-                    py = wrap3(wrap3((py - id1) - g1, g.ny) + oy, g.ny);                                                          \
-                    pz = wrap3(wrap3((pz - id2) - g2, g.nz) + oz, g.nz);                                                          \
-                    lq = lin24(g, px, py, pz);                                                                                    \
-                }                                                                                                                 \
-            }                                                                                                                     \
-            int bl = 0;                                                                                                           \
-            XB_OWN_TEST                                                                                                           \
-            const bool in_win = !WINDOW || own || plane_in_window(g, px);                                                         \
-            if (own) rec = xb_s_rec[soff + (((((px & 7) << 3) | (py & 7)) << 3) | (pz & 7))];                                     \
-            else {                                                                                                                \
-                rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);                                        \
-                XB_OWN_BIDX                                                                                                       \
-                bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));                          \
-            }                                                                                                                     \
-            steps++;                                                                                                              \
-            XB_DBG_LANE_STEP                                                                                                      \
-            const bool arrived = bl > 0 && !at_max;                                                                               \
-            const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps || (WINDOW && !in_win);                     \
-            if (arrived) result = box_max[bl - 1];                                                                                \
-            else if (at_max) result = CUR;                                                                                        \
-            else if (undecided) result = -2;                                                                                      \
-            m_old = max_raw(m_old, kp);                                                                                           \
-            kp = kc;                                                                                                              \
-            PREV = lq;                                                                                                            \
-            if (arrived || at_max || undecided) break;                                                                            \
-        }
-#if XB_WALK_LOOP == 2
-        if (lab0 != -1)
-            for (;;) {
-                XB_LEAN_STEP(ia, ib)
-                XB_LEAN_STEP(ib, ia)
-            }
-#else
-        if (lab0 != -1)
-            for (;;) {
-                XB_LEAN_STEP(ia, ib)
-                const int t = ia; ia = ib; ib = t;
-            }
-#endif
-#undef XB_LEAN_STEP
-#undef XB_OWN_TEST
-#undef XB_OWN_BIDX
-#undef XB_DBG_LANE_STEP
-#ifdef XB_DEBUG_COUNT
-        if (xb_dbg_steps) xb_dbg_steps[v] = (signed char)min(dbg_lane_steps, 127);   // tools/walk_lengths.py
-#endif
-        if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
-        labels[v] = result;
-        note_maximum_wave(result >= 0, result, v, first, max_list, max_count, max_cap);
-        if (result == -2) {
-            const int k = atomicAdd(ovf_count, 1);
-            if (k < ovf_cap) ovf_list[k] = v;
-        }
-        return result;
-    }
-#endif
-    bool moving = lab0 != -1;
+    GradRec rec = CACHE ? xb_s_rec[((sx & 7) << 6) | ((sy & 7) << 3) | (sz & 7)] : fetch_rec_o<OFF32>(G, WINDOW ? rec_slot(g, v) : v);
     int result = -1;
     int px = sx, py = sy, pz = sz, steps = 0;
     double dr0 = 0., dr1 = 0., dr2 = 0.;
-    const unsigned own_b = (unsigned)__builtin_amdgcn_readfirstlane(mad24(mad24(sx >> 3, nb1, sy >> 3), nb2, sz >> 3));   // the own brick (wave uniform)
-    (void)own_b;
-    // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key
+    // PathWindow<2> by hand: (i0, k0) the current voxel and its key, (i1, k1) the one before, m_old the largest older key.
+    // (Round 5, measured: the running-maximum test fails wherever a trajectory dips below a key it passed two or more steps ago --
+    // at 512^3 19 K walkers of a 216-atom cell and 5.8 M of a noisy vacuum go to the exact slow path with this window of 2, 7 K /
+    // 2.6 M with 3, 2.3 K / 1.2 M with 4; the headline pays 1.5 % / 3 % of the trace for a wider one, so 2 it is and the slow path
+    // got its tiers instead: host_assign.h run_slow.)
     int i0 = v, i1 = -1;
     double k0 = rec.key, k1 = -1.7976931348623157e308, m_old = -1.7976931348623157e308;
-    // (round 5, measured: the running-maximum test fails wherever a trajectory dips below a key it passed XB_LEAN_K or more steps
-    // ago -- at 512^3 19 K walkers of a 216-atom cell and 5.8 M of a noisy vacuum go to the exact slow path with a window of 2,
-    // 7 K / 2.6 M with 3, 2.3 K / 1.2 M with 4; the headline pays 1.5 % / 3 % of the trace for it, so 2 stays the default and the
-    // slow path got its tiers instead: host_assign.h run_slow)
-#if XB_LEAN_K >= 3
-    int i2 = -1;
-    double k2 = -1.7976931348623157e308;
+#ifdef XB_DEBUG_COUNT
+    int dbg_lane_steps = 0;
 #endif
-#if XB_LEAN_K >= 4
-    int i3 = -1;
-    double k3 = -1.7976931348623157e308;
-#endif
-#if XB_WALK_LOOP
-    if (moving) for (;;) {
-        {
-#else
-    while (__builtin_amdgcn_ballot_w64(moving) != 0) {
-        if (moving) {
-#endif
-            const int bits = key_bits(rec.key);
-            // methods.py:345-363: dr += r; corr = rha(dr); q = p + int_grad + corr; dr -= corr (a voxel without a gradient
-            // step has code 63 and r = 0: the move below is garbage for it and replaced by the ongrid step)
-            const double t0 = dr0 + rec.r0, t1 = dr1 + rec.r1, t2 = dr2 + rec.r2;
-            const int id0 = rha_cs(t0), id1 = rha_cs(t1), id2 = rha_cs(t2);
-#ifndef XB_WALK_TWEAK
-#define XB_WALK_TWEAK 0
-#endif
-#if XB_WALK_TWEAK & 2
-            const int g0 = code_step(bits, 0), g1 = code_step(bits, 1), g2 = code_step(bits, 2);
-            px = add3(px, id0, g0); py = add3(py, id1, g1); pz = add3(pz, id2, g2);
-#define m0 (id0 + g0)
-#define m1 (id1 + g1)
-#define m2 (id2 + g2)
-#else
-            const int m0 = code_step(bits, 0) + id0, m1 = code_step(bits, 1) + id1, m2 = code_step(bits, 2) + id2;
-            px += m0; py += m1; pz += m2;
-#endif
-            dr0 = t0 - (double)id0; dr1 = t1 - (double)id1; dr2 = t2 - (double)id2;
-            // the periodic wrap only for the waves that touch the faces of the grid
-            if (__builtin_amdgcn_ballot_w64((unsigned)px >= (unsigned)g.nx || (unsigned)py >= (unsigned)g.ny || (unsigned)pz >= (unsigned)g.nz) != 0) {
-                px = wrap3(px, g.nx); py = wrap3(py, g.ny); pz = wrap3(pz, g.nz);
-            }
-            int lq = lin24(g, px, py, pz);
-            bool og_move = (bits & 63) == XB_STAY_CODE || lq == i0 || lq == i1;   // methods.py:411: already on this path
-#if XB_LEAN_K >= 3
-            og_move = og_move || lq == i2;
-#endif
-#if XB_LEAN_K >= 4
-            og_move = og_move || lq == i3;
-#endif
-            bool at_max = false;
-            if (__builtin_amdgcn_ballot_w64(og_move) != 0) {   // rare: dr = 0 and one ongrid step from p (methods.py:412-447, tabulated)
-                if (og_move) {
-                    const int og = (bits >> 6) & 31;
-                    int ox, oy, oz;
-                    og_offsets(og, ox, oy, oz);
-                    at_max = og == XB_OG_SELF;   // break_flag: p is the maximum
-                    dr0 = dr1 = dr2 = 0.;
-                    px = wrap3(wrap3(px - m0, g.nx) + ox, g.nx);
-                    py = wrap3(wrap3(py - m1, g.ny) + oy, g.ny);
-                    pz = wrap3(wrap3(pz - m2, g.nz) + oz, g.nz);
-                    lq = lin24(g, px, py, pz);   // (== i0 at a maximum)
-                }
-            }
-            // both loads in flight together; a lane at its maximum reloads its own record (harmless)
-            int bl = 0;
-#if XB_WALK_TWEAK & 1
-            const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
-            const bool own = CACHE && bidx == own_b;
-#else
-            const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
-#endif
-            const bool in_win = !WINDOW || own || plane_in_window(g, px);
-            if (own) rec = xb_s_rec[soff + (((px & 7) << 6) | ((py & 7) << 3) | (pz & 7))];
-            else {
-                rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);   // (outside the window: any valid slot, the value is not used)
-#if !(XB_WALK_TWEAK & 1)
-                const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
-#endif
-                bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
-            }
-#undef m0
-#undef m1
-#undef m2
-            steps++;
-            // arrived inside a trapping region (q cannot be an old path voxel: the trajectory would have stopped there
-            // already); membership undecidable from the window: exact slow kernel (ongrid moves are appended without a
-            // membership test, methods.py:513-521)
-            const bool arrived = bl > 0 && !at_max;
-            const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps || (WINDOW && !in_win);
-            if (arrived) result = box_max[bl - 1];
-            else if (at_max) result = i0;
-            else if (undecided) result = -2;
-            moving = !(arrived || at_max || undecided);
-#if XB_LEAN_K >= 4
-            m_old = max_raw(m_old, k3);
-            i3 = i2; k3 = k2;
-            i2 = i1; k2 = k1;
-#elif XB_LEAN_K == 3
-            m_old = max_raw(m_old, k2);
-            i2 = i1; k2 = k1;
-#else
-            m_old = max_raw(m_old, k1);
-#endif
-            i1 = i0; k1 = k0;
-            i0 = lq; k0 = rec.key;
+    // Round 6: the loop in its natural divergent form -- a lane that has arrived leaves the loop and drops out of the execution
+    // mask.  The round-3 form `while (ballot(moving)) if (moving) {...}` kept `moving` as a per-lane flag that was materialised and
+    // tested at the head of every step, and -- what cost more -- kept every lane's `result` live across the back edge: the load of
+    // box_max[] for the lanes that had just arrived was waited for at the head of the NEXT step, a second memory round trip in
+    // the chain of every step in which some lane arrived.  Now that load is waited for after the loop (1.14 -> 1.05 ms at 512^3).
+    if (lab0 != -1) for (;;) {
+        const int bits = key_bits(rec.key);
+        // methods.py:345-363: dr += r; corr = rha(dr); q = p + int_grad + corr; dr -= corr (a voxel without a gradient
+        // step has code 63 and r = 0: the move below is garbage for it and replaced by the ongrid step)
+        const double t0 = dr0 + rec.r0, t1 = dr1 + rec.r1, t2 = dr2 + rec.r2;
+        const int id0 = rha_cs(t0), id1 = rha_cs(t1), id2 = rha_cs(t2);
+        const int m0 = (bits & 3) + id0 - 1, m1 = ((bits >> 2) & 3) + id1 - 1, m2 = ((bits >> 4) & 3) + id2 - 1;
+        px += m0; py += m1; pz += m2;
+        dr0 = t0 - (double)id0; dr1 = t1 - (double)id1; dr2 = t2 - (double)id2;
+        // the periodic wrap only for the waves that touch the faces of the grid
+        if (__builtin_amdgcn_ballot_w64((unsigned)px >= (unsigned)g.nx || (unsigned)py >= (unsigned)g.ny || (unsigned)pz >= (unsigned)g.nz) != 0) {
+            px = wrap3(px, g.nx); py = wrap3(py, g.ny); pz = wrap3(pz, g.nz);
         }
-#if XB_WALK_LOOP
-        if (!moving) break;
+        int lq = lin24(g, px, py, pz);
+        const bool og_move = (bits & 63) == XB_STAY_CODE || lq == i0 || lq == i1;   // methods.py:411: already on this path
+        bool at_max = false;
+        if (__builtin_amdgcn_ballot_w64(og_move) != 0) {   // rare: dr = 0 and one ongrid step from p (methods.py:412-447, tabulated)
+            if (og_move) {
+                const int og = (bits >> 6) & 31;
+                int ox, oy, oz;
+                og_offsets(og, ox, oy, oz);
+                at_max = og == XB_OG_SELF;   // break_flag: p is the maximum
+                dr0 = dr1 = dr2 = 0.;
+                px = wrap3(wrap3(px - m0, g.nx) + ox, g.nx);
+                py = wrap3(wrap3(py - m1, g.ny) + oy, g.ny);
+                pz = wrap3(wrap3(pz - m2, g.nz) + oz, g.nz);
+                lq = lin24(g, px, py, pz);   // (== i0 at a maximum)
+            }
+        }
+        // both loads in flight together; a lane at its maximum reloads its own record (harmless)
+        int bl = 0;
+        const bool own = CACHE && (unsigned)((px ^ ox8) | (py ^ oy8) | (pz ^ oz8)) < 8u;
+        const bool in_win = !WINDOW || own || plane_in_window(g, px);
+        if (own) rec = xb_s_rec[((px & 7) << 6) | ((py & 7) << 3) | (pz & 7)];
+        else {
+            rec = fetch_rec_o<OFF32>(G, WINDOW ? (in_win ? rec_slot(g, lq) : 0) : lq);   // (outside the window: any valid slot, the value is not used)
+            const unsigned bidx = (unsigned)mad24(mad24(px >> 3, nb1, py >> 3), nb2, pz >> 3);
+            bl = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(blab) + (bidx << 2));
+        }
+        steps++;
+#ifdef XB_DEBUG_COUNT
+        dbg_lane_steps++;
 #endif
+        // arrived inside a trapping region (q cannot be an old path voxel: the trajectory would have stopped there
+        // already); membership undecidable from the window: exact slow kernel (ongrid moves are appended without a
+        // membership test, methods.py:513-521)
+        const bool arrived = bl > 0 && !at_max;
+        const bool undecided = (!og_move && rec.key <= m_old) || steps > maxsteps || (WINDOW && !in_win);
+        if (arrived) result = box_max[bl - 1];
+        else if (at_max) result = i0;
+        else if (undecided) result = -2;
+        if (arrived || at_max || undecided) break;
+        m_old = max_raw(m_old, k1);
+        i1 = i0; k1 = k0;
+        i0 = lq; k0 = rec.key;
     }
+#ifdef XB_DEBUG_COUNT
+    if (xb_dbg_steps) xb_dbg_steps[v] = (signed char)min(dbg_lane_steps, 127);   // tools/walk_lengths.py
+#endif
     // a maximum that is itself vacuum hands its -1 to the start voxel (methods.py:449-452)
     if (has_vacuum && result >= 0 && result != v && labels[result] == -1) result = -1;
     labels[v] = result;
@@ -662,16 +491,16 @@ __device__ __forceinline__ int xcc_id() {
     return x & 7;
 }
 
-// Group form of the persistent trace: a workgroup of W waves pulls CH consecutive items (CH / 8 whole bricks of the Morton
-// ordered walk list) and its waves take them one by one from a counter in LDS, so that the eight 4x4x4 eighths of a brick --
+// Group form of the persistent trace: a workgroup of XB_TRACE_WAVES waves pulls ONE brick (eight consecutive items) of the Morton
+// ordered walk list and its waves take the brick's eight 4x4x4 eighths one by one from a counter in LDS, so that the eighths --
 // whose walkers converge onto the same voxels within a few steps -- run on ONE compute unit at the same time: their record
 // loads meet in that unit's L1 (hit, or merged with the miss in flight) instead of each occupying a miss slot of a
 // different unit.  The trace is bound by exactly that: L2 requests x L2 latency / misses in flight per compute unit
-// (profiles/r3_*: TCP_PENDING_STALL 62 % of the kernel, TA busy 89 %, 0.64 L2 requests per lane-step).
+// (profiles/r5_final_pmc_sq_512_neargrid.txt: 9.1e7 L2 requests x 370 cycles = 50 requests in flight per compute unit on
+// average, TCP_PENDING_STALL 55 % of the kernel; DESIGN.md 4.3 has what round 6 measured around that bound).
 // LEAN 0: the generic walker ng_walk_wave (tests every start voxel, box ids in the keys, table windows); LEAN 3 / 4: the lean
-// walker (4: 32-bit table offsets) -- the workgroup is XB_TRACE_WAVES waves, a pull is XB_TRACE_NB whole bricks, and their records
-// are copied into LDS (16 KB per brick) before the waves start (see ng_walk_lean).  (LEAN 1 / 2, the lean walker without the cache, and the
-// one-wave form k_ng_trace_p were measured against these in round 3 and removed in round 4.)
+// walker (4: 32-bit table offsets), the brick's 512 records copied into LDS (16 KB) before the waves start (see ng_walk_lean).
+// CH: items per pull (8: one brick).
 template <int K, int LEAN, bool WINDOW = false, bool PART = false>
 __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(GridL g, const GradRec *__restrict__ G, const int *__restrict__ box_max,
                                                        const int *__restrict__ blab, int nb1, int nb2,
@@ -683,16 +512,9 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
     // pass over the labels.)  Per eighth the result of its lane 0, and a flag any lane raises whose result differs from it --
     // plain LDS stores and loads in the wave's program order: no atomics (1024 of them on one address per brick cost 0.2 ms
     // at 512^3), no cross-lane operations.
-    // Round 5: a pull is XB_TRACE_NB bricks (CH = 8 * XB_TRACE_NB eighths for the XB_TRACE_WAVES waves to share out): the time probes
-    // (tools/trace_probe.py) showed a wave of the eight-waves-one-brick form waiting a third of its cycles at the barrier for the
-    // slowest eighth of ITS brick -- with two eighths per wave in the pool a wave that got a short one takes another (first as
-    // eight waves and two bricks, then, better, four waves and one brick: half as many waves for the slowest to hold up).
-    __shared__ int s_w[8 * XB_TRACE_NB], s_mixed[XB_TRACE_NB];
-    constexpr bool CACHE = LEAN >= 3 && XB_TRACE_CACHE;
-    constexpr bool BRES = LEAN >= 3;
-    int prev_brick[XB_TRACE_NB];
-#pragma unroll
-    for (int j = 0; j < XB_TRACE_NB; j++) prev_brick[j] = -1;
+    __shared__ int s_w[8], s_mixed;
+    constexpr bool CACHE = LEAN >= 3;
+    int prev_brick = -1;
 #ifdef XB_DEBUG_COUNT   // time probes (tools/trace_probe.py): where do the waves of the persistent trace spend their cycles?
     const long long pr_t0 = clock64();
     long long pr_walk = 0, pr_wait = 0, pr_load = 0;
@@ -703,6 +525,16 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
     const int per = (((n_items + 7) >> 3) + 7) & ~7;   // whole bricks per XCD range
     const int home = xcd_split ? xcc_id() : (blockIdx.x & 7);
     const int lane = threadIdx.x & (XB_WAVE - 1);
+    // the verdict of the brick this workgroup walked last (thread 0, after a barrier)
+    auto verdict = [&]() {
+        if (CACHE && bres && prev_brick >= 0) {
+            int r0 = s_mixed ? -1 : s_w[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) r0 = (s_w[k] == r0) ? r0 : -1;
+            bres[prev_brick] = r0 >= 0 ? r0 : (-2147483647 - 1);
+        }
+        prev_brick = -1;   // (written: a pull that finds its range empty must not write it again)
+    };
     for (int r = 0; r < 8; r++) {
         const int q = (home + r) & 7;
         const int beg = q * per, end = min(beg + per, n_items);
@@ -710,24 +542,13 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
 #ifdef XB_DEBUG_COUNT
             const long long pr_a = clock64();
 #endif
-            __syncthreads();   // the previous chunk's readers are done with s_base / s_next
+            __syncthreads();   // the previous brick's readers are done with s_base / s_next and the records
 #ifdef XB_DEBUG_COUNT
             pr_wait += clock64() - pr_a;
 #endif
             if (threadIdx.x == 0) {
-                if (BRES && bres) {
-#pragma unroll
-                    for (int j = 0; j < XB_TRACE_NB; j++) {
-                        if (prev_brick[j] >= 0) {
-                            int r0 = s_mixed[j] ? -1 : s_w[8 * j];
-#pragma unroll
-                            for (int k = 1; k < 8; k++) r0 = (s_w[8 * j + k] == r0) ? r0 : -1;
-                            bres[prev_brick[j]] = r0 >= 0 ? r0 : (-2147483647 - 1);
-                        }
-                        prev_brick[j] = -1;   // (written: a pull that finds its range empty must not write it again)
-                        s_mixed[j] = 0;
-                    }
-                }
+                verdict();
+                s_mixed = 0;
                 s_base = beg + atomicAdd(&fs[FS_CURSOR0 + q * FS_CURSOR_STRIDE], CH);
                 s_next = 0;
             }
@@ -739,35 +560,22 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
             const long long pr_b = clock64();
             pr_bricks++;
 #endif
-            if (BRES && !CACHE) {
-#pragma unroll
-                for (int j = 0; j < XB_TRACE_NB; j++)
-                    if (base + 8 * j < stop) prev_brick[j] = walk[(base >> 3) + j];   // (uniform)
-            }
-            if (CACHE) {   // (CH == 8 * XB_TRACE_NB, base a multiple of 8) thread t copies the record of voxel t of each brick of the pull
-                constexpr int PER = 512 * XB_TRACE_NB / (XB_WAVE * XB_TRACE_WAVES);   // records a thread copies
-                static_assert(PER * XB_WAVE * XB_TRACE_WAVES == 512 * XB_TRACE_NB, "the threads of a workgroup share out the records of a pull evenly");
+            if (CACHE) {   // (CH == 8, base a multiple of 8: one brick) thread t copies the records of voxels t, t + 256 of the brick
+                constexpr int PER = 512 / (XB_WAVE * XB_TRACE_WAVES);
+                const int b = walk[base >> 3];
+                prev_brick = b;
+                const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
                 GradRec tmp[PER];
 #pragma unroll
-                for (int j = 0; j < XB_TRACE_NB; j++)
-                    if (base + 8 * j < stop) prev_brick[j] = walk[(base >> 3) + j];   // (uniform)
-#pragma unroll
                 for (int k = 0; k < PER; k++) {
-                    const int idx = threadIdx.x + k * XB_WAVE * XB_TRACE_WAVES, j = idx >> 9, t = idx & 511;
-                    if (base + 8 * j < stop) {
-                        const int b = walk[(base >> 3) + j];
-                        const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-                        int cx = b0 * 8 + (t >> 6), cy = b1 * 8 + ((t >> 3) & 7), cz = b2 * 8 + (t & 7);
-                        if (PART) { cx = min(cx, g.nx - 1); cy = min(cy, g.ny - 1); cz = min(cz, g.nz - 1); }   // (beyond the grid: any record, nobody reads the slot)
-                        const int lt = lin24(g, cx, cy, cz);
-                        tmp[k] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
-                    }
+                    const int t = threadIdx.x + k * XB_WAVE * XB_TRACE_WAVES;
+                    int cx = b0 * 8 + (t >> 6), cy = b1 * 8 + ((t >> 3) & 7), cz = b2 * 8 + (t & 7);
+                    if (PART) { cx = min(cx, g.nx - 1); cy = min(cy, g.ny - 1); cz = min(cz, g.nz - 1); }   // (beyond the grid: any record, nobody reads the slot)
+                    const int lt = lin24(g, cx, cy, cz);
+                    tmp[k] = fetch_rec(G, WINDOW ? rec_slot(g, lt) : lt);
                 }
 #pragma unroll
-                for (int k = 0; k < PER; k++) {
-                    const int idx = threadIdx.x + k * XB_WAVE * XB_TRACE_WAVES;
-                    if (base + 8 * (idx >> 9) < stop) xb_s_rec[idx] = tmp[k];
-                }
+                for (int k = 0; k < PER; k++) xb_s_rec[threadIdx.x + k * XB_WAVE * XB_TRACE_WAVES] = tmp[k];
                 __syncthreads();
             }
 #ifdef XB_DEBUG_COUNT
@@ -788,16 +596,15 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
 #ifdef XB_DEBUG_COUNT
                     const long long pr_c = clock64();
 #endif
-                    const int res = ng_walk_lean<LEAN == 2 || LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
-                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0,
-                                                                CACHE ? ((item - base) >> 3) << 9 : 0);
+                    const int res = ng_walk_lean<LEAN == 4, CACHE, WINDOW>(g, G, box_max, blab, nb1, nb2, sx, sy, sz, labels, first, max_list, &fs[FS_N_MAX],
+                                                                max_cap, ovf_list, &fs[FS_N_OVF], ovf_cap, maxsteps, has_vacuum != 0);
 #ifdef XB_DEBUG_COUNT
                     pr_walk += clock64() - pr_c;
 #endif
-                    if (BRES && bres) {
+                    if (CACHE && bres) {
                         volatile int *w = s_w;
                         if (lane == 0) w[item - base] = res;
-                        if (w[item - base] != res) *(volatile int *)&s_mixed[(item - base) >> 3] = 1;   // (same wave: the store above is older in its LDS queue)
+                        if (w[item - base] != res) *(volatile int *)&s_mixed = 1;   // (same wave: the store above is older in its LDS queue)
                     }
                 }
                 else
@@ -809,25 +616,16 @@ __global__ __launch_bounds__(XB_WAVE * XB_TRACE_WAVES, 8) void k_ng_trace_g(Grid
 #ifdef XB_DEBUG_COUNT
     // PLAIN stores into a slot per wave (the host adds them up).  Round 5 learnt it the hard way: 50 K atomicAdds on one line as the
     // workgroups finish stretch the end of the kernel by 0.5 ms, and everything measured in that stretch is the probe itself.
-    if (lane == 0 && blockIdx.x < 1024) {
-        unsigned long long *o = xb_dbg + 64 + 6 * (blockIdx.x * 8 + (threadIdx.x >> 6));
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long *o = xb_dbg + 64 + 6 * (blockIdx.x * XB_TRACE_WAVES + (threadIdx.x >> 6));
         o[0] = (unsigned long long)pr_walk; o[1] = (unsigned long long)(clock64() - pr_t0); o[2] = (unsigned long long)pr_wait;
         o[3] = (unsigned long long)pr_load; o[4] = pr_e0; o[5] = (unsigned long long)wall_clock64();
         if (threadIdx.x == 0) xb_dbg[64 + 6 * 8192 + blockIdx.x] = (unsigned long long)pr_bricks;
     }
 #endif
-    if (BRES && bres) {   // the last bricks this workgroup walked
+    if (CACHE && bres) {   // the last brick this workgroup walked
         __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int j = 0; j < XB_TRACE_NB; j++)
-                if (prev_brick[j] >= 0) {
-                    int r0 = s_mixed[j] ? -1 : s_w[8 * j];
-#pragma unroll
-                    for (int k = 1; k < 8; k++) r0 = (s_w[8 * j + k] == r0) ? r0 : -1;
-                    bres[prev_brick[j]] = r0 >= 0 ? r0 : (-2147483647 - 1);
-                }
-        }
+        if (threadIdx.x == 0) verdict();
     }
 }
 

@@ -384,10 +384,10 @@ int xb_slab_assign_trace(xb_ctx *c) {
             const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
             if (lean && (long long)g.wlen * g.nyz <= (1LL << 27))
                 k_ng_trace_g<2, 4, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
-                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8 * XB_TRACE_NB, 1);
+                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);
             else if (lean)
                 k_ng_trace_g<2, 3, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
-                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8 * XB_TRACE_NB, 1);
+                                                                               c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);
             else
                 k_ng_trace_g<2, 0><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
                                                                          c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);

@@ -44,13 +44,15 @@ for rep in range(3):
     ctx.assign('neargrid')
     raw.xb_debug_counts(out, 0)
 o = np.array(out[:], np.float64)
-w = o[64:64 + 6 * 8192].reshape(8192, 6)
-w = w[w[:, 1] > 0]
-bricks = int(o[64 + 6 * 8192:64 + 6 * 8192 + 1024].sum())
-walk, total, wait, load = (w[:, k].sum() for k in range(4))
-start = w[:, 4].min()
-ends = (w[:, 5].reshape(-1, 8).max(axis=1) - start) / 100.0          # wall_clock64: 100 MHz -> microseconds
-print(f'waves {len(w)} bricks {bricks}: cycles per wave {total / len(w):.0f}; walking {walk / total:.3f}, barrier wait {wait / total:.3f}, '
+WAVES = 4                                     # XB_TRACE_WAVES (k_trace.h): waves of a workgroup of the group trace
+w = o[64:64 + 6 * 8192].reshape(8192 // WAVES, WAVES, 6)      # the kernel records its first 2048 workgroups, a slot per wave
+w = w[(w[:, :, 1] > 0).all(axis=1)]          # workgroups of which every wave reported
+bricks = int(o[64 + 6 * 8192:64 + 6 * 8192 + 2048].sum())
+walk, total, wait, load = (w[:, :, k].sum() for k in range(4))
+start = w[:, :, 4].min()
+ends = (w[:, :, 5].max(axis=1) - start) / 100.0          # wall_clock64: 100 MHz -> microseconds; a workgroup ends with its last wave
+n_waves = w.shape[0] * WAVES
+print(f'waves {n_waves} bricks {bricks}: cycles per wave {total / n_waves:.0f}; walking {walk / total:.3f}, barrier wait {wait / total:.3f}, '
       f'record load {load / total:.3f}, rest {1 - (walk + wait + load) / total:.3f}')
 print(f'workgroups {ends.size}: finish times (us after the first start) min {ends.min():.0f} p10 {np.percentile(ends, 10):.0f} '
       f'median {np.median(ends):.0f} p90 {np.percentile(ends, 90):.0f} max {ends.max():.0f}')

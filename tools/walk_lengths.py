@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How long are the walkers of the group trace, and what would a different dealing of a brick's 512 walkers to its eight
-wave-loads save?  Diagnostic build (-DXB_DEBUG_COUNT -DXB_WALK_LOOP=3 -> pybader_amd/libbader_hip_dbg.so, never loaded by the
+wave-loads save?  Diagnostic build (-DXB_DEBUG_COUNT -> pybader_amd/libbader_hip_dbg.so, never loaded by the
 product): every lean walker notes its step count in `known`.  A wave-load lasts as long as its longest walker, so the cost of a
 dealing is the sum over its eight loads of the largest count.  GPU box only; `--build` only compiles.
 
@@ -21,7 +21,7 @@ from pybader_amd.interface import distance_matrix, gradient_transform   # noqa: 
 dbg = os.path.join(ROOT, 'pybader_amd', 'libbader_hip_dbg.so')
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 if '--build' in sys.argv or not os.path.exists(dbg):
-    subprocess.check_call([build.hipcc()] + build.FLAGS + ['-DXB_DEBUG_COUNT', '-DXB_WALK_LOOP=3', '-o', dbg, build.SRC])
+    subprocess.check_call([build.hipcc()] + build.FLAGS + ['-DXB_DEBUG_COUNT', '-o', dbg, build.SRC])
     if '--build' in sys.argv:
         sys.exit(0)
 _lib.LIB_PATH = dbg
@@ -56,6 +56,40 @@ for name, order in (('C order, 64 consecutive edge voxels a wave', rl), ('sorted
     pad = (-len(order)) % 64
     w = np.concatenate([order, np.zeros(pad, order.dtype)]).reshape(-1, 64)
     print(f'  retraces, {name}: wave-iterations {w.max(1).sum()}, lanes {rl.sum() / max(1, w.max(1).sum()):.1f} of 64')
+# would the assignment walker's step count of the same voxel predict the retrace's length?  (edge lists binned by that hint)
+hint = steps.reshape(-1)[edges]
+print(f'hint (assignment steps of the edge voxel): {np.mean(hint == 0) * 100:.1f}% without a walker; correlation with the retrace length {np.corrcoef(hint, rl)[0, 1]:.3f}')
+
+
+def lanes_of(groups):
+    it = 0
+    for g_ in groups:
+        if len(g_) == 0:
+            continue
+        pad = (-len(g_)) % 64
+        w = np.concatenate([g_, np.zeros(pad, g_.dtype)]).reshape(-1, 64)
+        it += w.max(1).sum()
+    return rl.sum() / max(1, it), it
+
+
+for bins in ([1, 4, 8, 16], [1, 3, 6, 10, 16, 24], [1, 2, 4, 6, 8, 12, 16, 24, 32]):
+    cls = np.digitize(hint, bins)
+    ln, it = lanes_of([rl[cls == k] for k in range(len(bins) + 1)])
+    print(f'  retraces binned by the hint at {bins}: wave-iterations {it}, lanes {ln:.1f} of 64')
+order = np.argsort(hint, kind='stable')
+ln, it = lanes_of([rl[order]])
+print(f'  retraces sorted by the hint: wave-iterations {it}, lanes {ln:.1f} of 64')
+# tile order (4 x 8 x 64 tiles as the edge sweep lists them) instead of C order
+n3 = size
+ex, ey, ez = np.unravel_index(edges, shape)
+tile = ((ex // 4) * (n3 // 8) + ey // 8) * (n3 // 64) + ez // 64
+o2 = np.argsort(tile, kind='stable')
+ln, it = lanes_of([rl[o2]])
+print(f'  retraces in tile order: wave-iterations {it}, lanes {ln:.1f} of 64')
+for bins in ([1, 4, 8, 16], [1, 2, 4, 6, 8, 12, 16, 24, 32]):
+    cls = np.digitize(hint[o2], bins)
+    ln, it = lanes_of([rl[o2][cls == k] for k in range(len(bins) + 1)])
+    print(f'  tile order, binned by the hint at {bins}: wave-iterations {it}, lanes {ln:.1f} of 64')
 nb = size // 8
 B = steps.reshape(nb, 8, nb, 8, nb, 8).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 8, 8, 8)
 B = B[B.reshape(len(B), -1).max(1) > 0]                     # the walk-list bricks
