@@ -422,7 +422,7 @@ def main():
     ctx.enable_timing(only=[dom_timer])
     if 'XB_OPT_DBG' in os.environ:
         ctx.set_option(3, int(os.environ['XB_OPT_DBG']))
-    for key in range(7, 33):
+    for key in (1, 2, 17):                              # (A/B runs: regions, the cross-check bits, the kill schedule)
         if f'XB_OPT_{key}' in os.environ:
             ctx.set_option(key, int(os.environ[f'XB_OPT_{key}']))
     if 'XB_OPT_EC_GROUPS' in os.environ:

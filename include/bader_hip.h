@@ -264,19 +264,20 @@ int xb_kernel_time_reset(xb_ctx *c);
 /* on: 0 off, 1 every timer, otherwise a mask: bit k + 1 switches timer `which` = k on (event pairs between dependent kernels
  * cost stream time: a benchmark keeps only the dominant kernel's timer on inside its timed region) */
 int xb_enable_timing(xb_ctx *c, int on);
-/* Switches.  A USER of the library sets none of them: every default is the measured best, and no switch changes a result.
- * What each is for:
- *   6  drop the cached gradient-field table (benchmarks: a table kept from an earlier step would hide 1.6 ms per step);
- *   3  debug prints (bit 2 edge_check passes, bit 4 slab statistics, bit 5 wait after every stage of an assignment);
- *   24 collectives return without waiting, 22 slab-sized table / scratch (before xb_set_grid): set by pybader_amd.slab itself;
- *   exactness cross-checks the tests run BOTH ways -- 1 trapping regions (0: plain full trajectories from a record per voxel),
- *   7 device-side control flow (0: the host-driven calls), 13 mirror prefilter of pass A, 14 lean walker (0: the generic one),
- *   16 chase growth (0: propagation launches), 20 diagonal T_grad form, 25 tile-wise dilation,
- *   29 edge_check's workgroups share long dependency fronts through mailboxes (0: every workgroup keeps what it wakes);
+/* Switches (nine keys).  A USER of the library sets none of them: every default is the measured best, and no switch changes a
+ * result.  What each is for:
+ *   6   drop the cached gradient-field table (benchmarks: a table kept from an earlier step would hide 1.6 ms per step);
+ *   3   debug prints (bit 2 edge_check passes, bit 4 slab statistics, bit 5 wait after every stage of an assignment);
+ *   24  collectives return without waiting (set by pybader_amd.slab itself);
+ *   1   trapping regions (0: plain full trajectories from a record per voxel) -- the exactness cross-check of the whole design;
+ *   2   cross-check bits, each selecting the second implementation of one step so that a test can compare the two:
+ *       1 no mirror prefilter in pass A, 2 the generic walker instead of the lean one, 4 the full T_grad . grad product on
+ *       orthogonal lattices, 8 dilation from the edge list instead of tile by tile, 16 int32 label halos, 32 no front sharing
+ *       in the edge_check chase;
  *   test plumbing -- 4 / 5 workgroups and LDS queue capacity of the edge_check chase (lowered to force the overflow
- *   hand-over), 8 waves of the persistent trace, 17 kill launches scheduled after a chase, 18 narrowed label halos,
- *   19 a rank may exchange planes with itself.
- * (Round 4 removed 0, 2, 9-12, 15, 21: launch shapes and routes that no shipped configuration used.) */
+ *   hand-over), 17 kill launches scheduled after a chase (1 forces the repeat), 19 a rank may exchange planes with itself.
+ * (Round 4 removed 0, 2, 9-12, 15, 21; round 6 removed 7, 8, 16, 22 -- routes and launch shapes nobody set -- and folded 13, 14,
+ * 18, 20, 25, 29 into the bits of key 2.) */
 int xb_set_option(xb_ctx *c, int key, int value);
 /* device bytes held for the grid (density, labels, flags, numbering + the table of the window planes + scratch sized by the
  * slab): what a rank of the slab decomposition costs; the reference's blocks are copies of the block extent

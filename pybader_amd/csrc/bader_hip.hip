@@ -132,10 +132,8 @@ struct xb_ctx {
     int opt_async_comm = 0;    // collectives return without waiting (they are ordered on the context's stream); the device-driven slab step sets it
     int opt_tile_dilate = 1;   // the dilation of the edge sweep tile by tile (k_edge_dilate_tiles) instead of from the edge list (tests compare)
     int opt_self_exchange = 0; // tests only: xb_comm_exchange_planes accepts this rank as its own peer (one GPU exercises pack / send / recv / unpack)
-    int opt_lean_mem = 1;      // slabs: table, `list` and `stage` sized by the slab instead of the grid (0: everything full size)
     int opt_mask_diag = 1;     // pass A: the three-product form of T_grad . grad on orthogonal lattices (tests compare)
     int opt_narrow_halo = 1;   // label halos travel as dtype_calc(-n_maxima) (int8 / int16) instead of int32 (comm.h)
-    int opt_chase = 1;         // region growth: provisional labels by k_grow_parent / k_grow_chase (0: propagation launches)
     int grow_kill_launches = 6;   // kill launches scheduled after a chase (raised to the worst case by the first assignment that needs more)
     long long stat_grow_retries = 0;
     bool defer_wait = false;     // xb_assign_refine: the assignment queues its result transfer and returns without waiting ...
@@ -163,8 +161,7 @@ struct xb_ctx {
     long long blab_alloc = 0;
     bool labels_zero_pending = false;   // volumes_init without vacuum: labels := 0 is owed (see xb_vacuum_assign)
     int zero_outside[3] = {-1, -1, -1}; // slab (x0, x1, halo) for which every label outside the planes [x0-halo, x1+halo) is known to be 0
-    int opt_fused = 1;         // 0: the host-driven round-1 orchestration (kept for slabs and odd grids)
-    int opt_trace_grid = 8192; // waves of the persistent trace (2048 workgroups of XB_TRACE_WAVES = 4)
+    static constexpr int trace_waves = 8192;   // waves of the persistent trace: 2048 workgroups of XB_TRACE_WAVES = 4, eight per compute unit
     unsigned long long *counters64 = nullptr;
     double *dsum = nullptr;
     int *host_ints = nullptr;  // pinned
@@ -294,23 +291,21 @@ const char *xb_last_error(void) { return g_err.c_str(); }
 int xb_set_option(xb_ctx *c, int key, int value) {
     if (!c) return fail(XB_E_ARG, "null ctx");
     if (key == 1) { c->opt_boxes = value & 1; c->opt_bricks = (value >> 1) & 1; }
+    else if (key == 2) {   // cross-checks: a second implementation of the same step, for the tests that compare the two
+        c->opt_mirror = !(value & 1);        // 1: pass A runs the exact ongrid plane test for every open face (no mirror prefilter)
+        c->opt_lean = !(value & 2);          // 2: the generic walker ng_walk_wave instead of the lean one
+        c->opt_mask_diag = !(value & 4);     // 4: the full T_grad . grad product on orthogonal lattices too
+        c->opt_tile_dilate = !(value & 8);   // 8: the dilation of the edge sweep from the edge list instead of tile by tile
+        c->opt_narrow_halo = !(value & 16);  // 16: label halos travel as int32
+        c->opt_ec_share = !(value & 32);     // 32: every workgroup of the edge_check chase keeps what it wakes
+    }
     else if (key == 3) c->opt_dbg = value;
     else if (key == 4 && value >= 1 && value <= 4096) c->opt_ec_groups = value;
     else if (key == 5 && value >= 2 && value <= EC_Q) c->opt_ec_qcap = value;
     else if (key == 6) { c->grad_valid = false; if (value == 2) c->brick_max_valid = false; }  // drop the cached gradient-field table (a refinement rebuilds it)
-    else if (key == 7) c->opt_fused = value != 0;  // 0: the host-driven orchestration on one GPU too (tests compare the two)
-    else if (key == 8 && value >= 64 && value <= (1 << 22)) c->opt_trace_grid = value;
-    else if (key == 14) c->opt_lean = value != 0;
-    else if (key == 29) c->opt_ec_share = value != 0;
-    else if (key == 16) c->opt_chase = value != 0;
-    else if (key == 18) c->opt_narrow_halo = value != 0;
-    else if (key == 19) c->opt_self_exchange = value != 0;
-    else if (key == 20) c->opt_mask_diag = value != 0;
-    else if (key == 22) c->opt_lean_mem = value != 0;   // (before xb_set_grid)
-    else if (key == 24) c->opt_async_comm = value != 0;
-    else if (key == 25) c->opt_tile_dilate = value != 0;
     else if (key == 17 && value >= 1) c->grow_kill_launches = value;
-    else if (key == 13) c->opt_mirror = value != 0;   // 0: pass A runs the exact ongrid plane test for every open face (tests compare)
+    else if (key == 19) c->opt_self_exchange = value != 0;
+    else if (key == 24) c->opt_async_comm = value != 0;
     else return fail(XB_E_ARG, "xb_set_option: unknown key %d", key);
     return XB_OK;
 }

@@ -271,7 +271,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                 c->walk = walk;
                 // (the persistent kernel pays off from ~10^5 list items on: 0.24 vs 0.29 ms with the plain launch for an eighth of
                 // 512^3, 6.9 vs 7.7 ms for half of 1024^3)
-                fast_slab = table_windowed(c) && c->slab_sparse && c->opt_fused &&
+                fast_slab = table_windowed(c) && c->slab_sparse &&
                             (long long)(g.x1 - g.x0) * g.ny * g.nz >= 65536LL * 512;
                 int *walk_count = c->counters + 13;
                 if (fast_slab) {   // the state block of the device-side control flow: list length, cursors, maxima and redo counts
@@ -301,7 +301,7 @@ int xb_assign_trace(xb_ctx *c, int method, int64_t *n_local) {
                     ScopedTimer tw(c, 6);
                     int *redo = (int *)c->stage;
                     const int redo_cap = (int)std::min<size_t>(c->stage_bytes / sizeof(int), 0x7fffffffu);
-                    k_ng_trace_g<2, 0><<<std::max(1, c->opt_trace_grid / XB_TRACE_WAVES), XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
+                    k_ng_trace_g<2, 0><<<std::max(1, c->trace_waves / XB_TRACE_WAVES), XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(light(g), c->grad, box_max, c->blab, c->nbk[1], c->nbk[2], walk,
                                                                                   c->fs, c->labels, c->first, c->max_list, c->max_cap, redo,
                                                                                   redo_cap, maxsteps, c->has_vacuum ? 1 : 0, 8, 1);
                     k_ng_trace_list<2><<<512, TPB, 0, c->stream>>>(
@@ -491,7 +491,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
 static bool fused_ok(const xb_ctx *c) {
     const Grid &g = c->g;
     // (round 4: any grid of at least 16 voxels per axis -- the brick lattice is ceil(n / 8), k_brick_masks PART)
-    return c->opt_fused && c->opt_boxes && c->opt_bricks && g.x0 == 0 && g.x1 == g.nx && !table_windowed(c) &&
+    return c->opt_boxes && c->opt_bricks && g.x0 == 0 && g.x1 == g.nx && !table_windowed(c) &&
            g.nx >= 16 && g.ny >= 16 && g.nz >= 16;
 }
 static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
@@ -540,7 +540,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
     int *box_max = c->boxbuf + BB_REGMAX, *box_first = c->boxbuf + BB_REGFIRST;
     int *bmaxv = walk;   // (free until the walk list is made)
     int *bpot = c->list + 5 * nbr;   // brick potentials of the region growth (k_grow_parent); buf1 doubles as the parent array
-    const bool chase = c->opt_chase != 0;
+    const bool chase = true;   // provisional labels by one chase along the brick potentials
     int *bres = nullptr;   // per walk-list brick: the one maximum all its voxels ended on (k_ng_trace_g), for the edge sweep's uniformity
     c->box_max_tab = box_max;
     // (debug switch 32: wait after every stage and say so -- finds the kernel that does not come back)
@@ -657,7 +657,7 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
 #define XB_TRACE_ARGS gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first, c->max_list, c->max_cap, c->ovf_list, c->ovf_cap, \
                       maxsteps, c->has_vacuum ? 1 : 0
             // persistent workgroups of XB_TRACE_WAVES waves, one brick per pull (per-XCD cursors over the Morton-ordered walk list)
-            const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
+            const int groups = std::max(1, c->trace_waves / XB_TRACE_WAVES);
             if (lean) {   // the lean walker, the own brick's records in LDS
                 // (without vacuum the walkers also leave, per brick, whether all its voxels ended on one maximum: bres)
                 if (!c->has_vacuum) bres = c->list + 6 * nbr;

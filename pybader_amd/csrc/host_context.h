@@ -75,7 +75,7 @@ static int need_scratch(xb_ctx *c) {
     const long long N = c->N ? c->N : (long long)g.nx * g.nyz;
     const int own = g.x1 - g.x0;
     long long planes = own + 2LL * (std::max(c->halo, 16) + 16);
-    if (own == g.nx || planes >= g.nx || !c->opt_lean_mem) planes = g.nx;
+    if (own == g.nx || planes >= g.nx) planes = g.nx;
     const long long list_want = planes == g.nx ? N : std::max<long long>(planes * g.nyz, 8 * (N / 512) + 4096);
     const size_t stage_want = planes == g.nx ? (size_t)N * 8 : std::max<size_t>((size_t)planes * g.nyz * 8, (size_t)64 << 20);
     if (c->list_cap < list_want) {

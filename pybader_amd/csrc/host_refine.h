@@ -832,7 +832,7 @@ static int refine_impl(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t
     if (n_iters) *n_iters = 0;
     if (iters == 0) return XB_OK;  // thread_handlers.py:146-147
     int64_t edges = 0, changed = 0, esc = 0, checked = 0;
-    const bool fused = c->opt_fused && c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
+    const bool fused = c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
     // After an ongrid assignment (no table yet, the bricks' maxima known, no vacuum) the first iteration builds the records
     // itself, after its edge sweep and only where the band is; otherwise the table comes first (the sweep reads it).
     const bool late = fused && !c->grad_valid && c->brick_max_valid && !c->has_vacuum && c->brick_rec && c->g.nx >= 16 && c->g.ny >= 16 && c->g.nz >= 16;
@@ -888,7 +888,7 @@ static int refine_impl(xb_ctx *c, int mode, int64_t iters, int64_t *log, int64_t
 int xb_assign_refine(xb_ctx *c, int method, int mode, int64_t iters, int64_t *n_maxima, int64_t *log, int64_t log_capacity, int64_t *n_iters) {
     NEED_GRID_RAW("xb_assign_refine");
     if (n_iters) *n_iters = 0;
-    const bool fused = c->opt_fused && c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
+    const bool fused = c->g.x0 == 0 && c->g.x1 == c->g.nx && !table_windowed(c);
     if (method == XB_METHOD_NEARGRID && fused && fused_ok(c) && !c->has_vacuum && iters != 0 && (mode == XB_REFINE_ALL || mode == XB_REFINE_CHANGED)) {
         c->labels_zero_pending = false;   // every label is overwritten, none is read
         c->defer_wait = true;

@@ -47,9 +47,6 @@ __global__ void k_flag_window_bricks(int nb0, int per_plane, int b0, int nb, uns
 // and mirrored for negative d.  The thresholds below are 2e-12: a superset of the exact intervals in the two slivers
 // of width 1e-12, equal everywhere else (soundness only needs a superset).
 #define BM_EPS 2e-12
-#ifndef BM_STAGE
-#define BM_STAGE 1   // 0: round 3's staging (kept for A/B runs of the two builds)
-#endif
 #ifdef XB_DEBUG_COUNT
 __device__ unsigned long long xb_dbg[65536];   // [0..15] pass A's counters; [16..] the trace's time probes (k_ng_trace_g)
 __device__ signed char *xb_dbg_steps;          // per start voxel: the steps its walker took (tools/walk_lengths.py), else nullptr
@@ -63,30 +60,13 @@ __device__ signed char *xb_dbg_steps;          // per start voxel: the steps its
 //           x-face either -- there wave 3 skips the gradient altogether (only the maximum test is left).
 // A border wave needs the ongrid face test on its own faces only, and a field that points the same way across the tile
 // leaves one of the two border waves without any face to test.
-#ifndef BM_LAYOUT
-#define BM_LAYOUT 1   // 0: round 3's column order and row stride (kept for A/B runs of the two builds)
-#endif
-#ifndef BM_ROW
-#if BM_LAYOUT
 // Round 4: the 9 ds_read_b64 of a voxel are served per 32-lane half, bank pair = (address / 8) mod 32 = (35 ty + tz) mod 32
 // at a row stride of 35 doubles.  The order below keeps the four wave classes and arranges every half so that its 32 columns
 // fall on distinct bank pairs (waves 0 and 1: both halves; waves 2 and 3: one half, two columns per pair at most in the
 // other) -- 10 LDS cycles per read of the workgroup where 8 is the floor and round 3's order took 20 (its conflict cycles
 // were three times the cycles the reads themselves needed: profiles/r3_final_pmc_sq_512_neargrid.txt).  A linear layout cannot
-// do better with these classes: the low-side columns want an odd stride, the deep ones a stride of 4 mod 8
-// (scratch analysis).
-#define BM_ROW 35
-#else
-#define BM_ROW 38   // row length of the LDS tile in doubles (34 are used): with the column order below the 9 reads per voxel
-#endif              // meet fewer bank conflicts at a stride of 38 or 39 -- worth 2 % of the kernel (0.918 -> 0.90 ms): LDS time hides behind the VALU work
-#endif
-__device__ __forceinline__ void bm_second_layer(int i, int &yy, int &zz) {   // i = 0..19: the ring y, z in 1..6 with y or z in {1, 6}
-    if (i < 6) { yy = 1; zz = 1 + i; }            // y == 1, z 1..6   (i == 0 is (1,1))
-    else if (i < 12) { yy = 6; zz = i - 5; }      // y == 6, z 1..6
-    else if (i < 16) { yy = i - 10; zz = 1; }     // z == 1, y 2..5
-    else { yy = i - 14; zz = 6; }                 // z == 6, y 2..5
-}
-#if BM_LAYOUT
+// do better with these classes: the low-side columns want an odd stride, the deep ones a stride of 4 mod 8.
+#define BM_ROW 35   // row length of the LDS tile in doubles (34 are used)
 // thread -> column, (ty << 5) | tz.  Waves as above: 0 the low-side border columns (+ the mixed corners, + (1,5) of each brick),
 // 1 the high-side ones (+ (1,1), (1,2), (1,4)), 2 the other second-layer columns, 3 the deep ones.
 __device__ const unsigned char bm_column_tab[TPB] = {
@@ -103,37 +83,6 @@ __device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
     const int c = bm_column_tab[t];
     ty = c >> 5; tz = c & 31;
 }
-#else
-__device__ __forceinline__ void bm_column(int t, int &ty, int &tz) {
-    int bz, yy, zz;
-    if (t < 60) {            // wave 0: per brick 13 low-side columns + 2 mixed corners
-        bz = t / 15;
-        const int i = t - bz * 15;
-        if (i < 7) { yy = 0; zz = i; }                    // y == 0, z 0..6
-        else if (i < 13) { yy = i - 6; zz = 0; }          // z == 0, y 1..6
-        else if (i == 13) { yy = 0; zz = 7; }             // mixed corners
-        else { yy = 7; zz = 0; }
-    } else if (t < 64) {     // 4 second-layer columns fill wave 0
-        bz = t - 60; bm_second_layer(0, yy, zz);
-    } else if (t < 116) {    // wave 1: per brick 13 high-side columns
-        const int u = t - 64;
-        bz = u / 13;
-        const int i = u - bz * 13;
-        if (i < 7) { yy = 7; zz = i + 1; }                // y == 7, z 1..7
-        else { yy = i - 6; zz = 7; }                      // z == 7, y 1..6
-    } else if (t < 128) {    // 12 second-layer columns fill wave 1
-        const int u = t - 116;
-        bz = u / 3; bm_second_layer(1 + u % 3, yy, zz);
-    } else if (t < 192) {    // wave 2: the other 16 second-layer columns of each brick
-        const int u = t - 128;
-        bz = u >> 4; bm_second_layer(4 + (u & 15), yy, zz);
-    } else {                 // wave 3: the 16 deep columns of each brick
-        const int u = t - 192;
-        bz = u >> 4; yy = 2 + ((u >> 2) & 3); zz = 2 + (u & 3);
-    }
-    ty = yy; tz = bz * 8 + zz;
-}
-#endif
 
 // v_max_f64 without the canonicalisation fmax() adds for operands that come straight from memory (no NaNs in a density)
 __device__ __forceinline__ double max_raw(double a, double b) {
@@ -428,45 +377,8 @@ __global__ __launch_bounds__(TPB) void k_brick_masks(GT g, const double *__restr
     if (threadIdx.x < GT_Z / 8) { s_mask[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0; s_mv[threadIdx.x] = -1; s_pot[threadIdx.x] = -2147483647 - 1; }
     if (threadIdx.x == 0) s_bmax = 0;
     __syncthreads();
-#if BM_STAGE == 0
-    {   // row-wise staging, every load of a wave in flight before the first wait (see k_grad_field)
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / XB_WAVE), lane = threadIdx.x % XB_WAVE;
-        int Z = z0 + lane - 1;
-        if (small & 1) Z = ((Z % g.nz) + g.nz) % g.nz;
-        else Z = wrap_u(Z, g.nz);
-        constexpr int ROWS = (GT_X + 2) * (GT_Y + 2) / (TPB / XB_WAVE);
-        double val[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const int r = wv + k * (TPB / XB_WAVE);
-            const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
-            int X = x0 + ex - 1, Y = y0 + ey - 1;
-            if (small & 1) {
-                X = ((X % g.nx) + g.nx) % g.nx; Y = ((Y % g.ny) + g.ny) % g.ny;
-            } else {
-                X = wrap_u(X, g.nx); Y = wrap_u(Y, g.ny);
-            }
-            val[k] = (lane < GT_Z + 2) ? rho[(X * g.ny + Y) * g.nz + Z] : 0.;
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            const int r = wv + k * (TPB / XB_WAVE);
-            const int ex = r / (GT_Y + 2), ey = r - ex * (GT_Y + 2);
-            if (lane < GT_Z + 2) tile[ex][ey][lane] = val[k];
-        }
-        if (mirror) {
-            unsigned hi = 0;
-#pragma unroll
-            for (int k = 0; k < ROWS; k++) hi = max(hi, (unsigned)__double2hiint(val[k]) & 0x7fffffffu);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) hi = max(hi, (unsigned)__shfl_xor((int)hi, o));
-            if (lane == 0) atomicMax(&s_bmax, hi);
-        }
-    }
-#else
     if (small & 1) bm_stage<true, PART>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
     else bm_stage<false, PART>(g, rho, tile, &s_bmax, x0, y0, z0, mirror);
-#endif
     __syncthreads();
     // mu: see bm_mirror; the double whose high word is s_bmax + 1 bounds every |rho| of the tile from above
     const double mu = mirror ? __hiloint2double((int)min(s_bmax + 1u, 0x7ff00000u), 0) * mu_scale : 0.;

@@ -178,7 +178,7 @@ static int slab_need_wbuf(xb_ctx *c) {
 static bool slab_step_ok(const xb_ctx *c, int nranks) {
     const Grid &g = c->g;
     const long long nbr = c->N / (BRK * BRK * BRK);
-    return slab_sparse_ok(c) && c->opt_fused && !c->has_vacuum && nranks >= 2 && nranks <= XB_SLAB_RANKS_MAX && g.nz % 4 == 0 &&
+    return slab_sparse_ok(c) && !c->has_vacuum && nranks >= 2 && nranks <= XB_SLAB_RANKS_MAX && g.nz % 4 == 0 &&
            c->list_cap >= 7 * nbr && c->halo >= 3;
 }
 
@@ -327,7 +327,7 @@ int xb_slab_assign_trace(xb_ctx *c) {
     c->regions_pending = false;
     c->buni_valid = false; c->regions_labels = false;
     c->list_valid = false; c->chg_n = -1;
-    const bool chase = c->opt_chase != 0;
+    const bool chase = true;   // provisional labels by one chase along the brick potentials
     {
         ScopedTimer t4(c, 4);
         k_slab_any_flag<<<1, 1, 0, c->stream>>>(slab_flags(c), c->slab_nranks, fs);
@@ -381,7 +381,7 @@ int xb_slab_assign_trace(xb_ctx *c) {
             // (the lean walker in workgroups of eight waves, one brick per pull, its records through LDS -- as on one GPU --
             // when the index products fit 24 bits; 32-bit table offsets up to 2^27 window voxels)
             const bool lean = gl.use24 && c->opt_lean;
-            const int groups = std::max(1, c->opt_trace_grid / XB_TRACE_WAVES);
+            const int groups = std::max(1, c->trace_waves / XB_TRACE_WAVES);
             if (lean && (long long)g.wlen * g.nyz <= (1LL << 27))
                 k_ng_trace_g<2, 4, true><<<groups, XB_WAVE * XB_TRACE_WAVES, 0, c->stream>>>(gl, c->grad, box_max, c->blab, nb1, nb2, walk, fs, c->labels, c->first,
                                                                                c->max_list, c->max_cap, redo, redo_cap, maxsteps, 0, 8, 1);

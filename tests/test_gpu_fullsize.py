@@ -367,9 +367,8 @@ def test_mirror_prefilter_and_lean_walker_do_not_change_the_map(shape, lattice, 
         ctx.upload_density(rho)
     res = []
     for mirror, lean, diag in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)):
-        ctx.set_option(13, mirror)
-        ctx.set_option(14, lean)
-        ctx.set_option(20, diag)      # the three-product T_grad . grad of orthogonal lattices (exact zeros off the diagonal)
+        # option 2, the cross-check bits: 1 no mirror prefilter, 2 the generic walker, 4 the full T_grad . grad product
+        ctx.set_option(2, (0 if mirror else 1) | (0 if lean else 2) | (0 if diag else 4))
         ctx.set_option(6, 1)
         ctx.vacuum_assign(None, 1.0)
         n = ctx.assign('neargrid')
@@ -405,7 +404,7 @@ def test_tile_wise_dilation_leaves_the_same_flags(shape, lattice, noise, tol):
         ctx.upload_density(rho)
     res = []
     for tiled in (1, 0):
-        ctx.set_option(25, tiled)
+        ctx.set_option(2, 0 if tiled else 8)      # cross-check bit 8: the dilation from the edge list
         ctx.set_option(6, 1)
         ctx.vacuum_assign(tol, 1.0)
         n = ctx.assign('neargrid')
@@ -456,7 +455,7 @@ def test_brick_uniformity_left_by_the_walkers_equals_the_label_scan():
     ctx.synth_density(synth.TRICLINIC, synth.ATOMS8, synth.BACKGROUND)
     res = []
     for lean in (1, 0):
-        ctx.set_option(14, lean)
+        ctx.set_option(2, 0 if lean else 2)       # cross-check bit 2: the generic walker
         ctx.set_option(6, 1)
         ctx.vacuum_assign(None, 1.0)
         n = ctx.assign('neargrid')

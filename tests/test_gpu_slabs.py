@@ -338,7 +338,7 @@ def test_rccl_transport_through_the_c_abi_single_rank():
     nyz = rho.shape[1] * rho.shape[2]
     ctx.set_option(19, 1)
     for narrow, width in ((1, 1), (0, 4)):
-        ctx.set_option(18, narrow)
+        ctx.set_option(2, 0 if narrow else 16)      # cross-check bit 16: int32 label halos
         ctx.upload_labels(before.astype(np.int8))   # (the wire width follows the uploaded dtype: bader_calc hands refine its int8 map)
         sent0 = ctx.comm_bytes_sent()
         ctx.comm_exchange_planes(0, [(0, 3, 7), (0, 60, 62)], [(0, 40, 44), (0, 10, 12)])
@@ -348,7 +348,7 @@ def test_rccl_transport_through_the_c_abi_single_rank():
         assert ctx.comm_bytes_sent() - sent0 == 6 * nyz * width
     # the wire width follows whoever wrote the labels last, not the last assignment's basin count -- a map with
     # more basins than the 8-basin assignment above, uploaded for a standalone refine, must cross the halo untruncated
-    ctx.set_option(18, 1)
+    ctx.set_option(2, 0)
     many = (before.astype(np.int64) * 37 + (np.arange(before.size).reshape(before.shape) % 29)).astype(np.int32)   # labels 0..287
     assert many.max() > 127
     for up, width in ((many.astype(np.int16), 2), (many, 4)):

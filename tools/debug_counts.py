@@ -29,7 +29,7 @@ ctx.set_grid(shape, distance_matrix(vl), gradient_transform(vl))
 ctx.synth_density(synth.CUBIC6, synth.ATOMS8, synth.BACKGROUND)
 out = (ctypes.c_ulonglong * 16)()
 for mirror in (1, 0):
-    ctx.set_option(13, mirror)
+    ctx.set_option(2, 0 if mirror else 1)
     raw.xb_debug_counts(out, 1)
     ctx.vacuum_assign(None, 1.0)
     ctx.assign('neargrid')
