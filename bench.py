@@ -139,11 +139,7 @@ def user_legs(size, steps, warmup, mode, iters, headline_ns_per_voxel, stage_nam
     shape = (size,) * 3
     nv = float(size) ** 3
     legs = {}
-    rng = np.random.default_rng(5)
-    k = 6
-    cells = np.stack(np.meshgrid(*(np.arange(k),) * 3, indexing='ij'), -1).reshape(-1, 3)
-    frac = (cells + 0.5 + 0.18 * (rng.random(cells.shape) - 0.5)) / k
-    atoms216 = np.concatenate([frac, 0.09 + 0.04 * rng.random((len(frac), 1)), 2.0 + 6.0 * rng.random((len(frac), 1))], 1)
+    atoms216 = synth.atoms_jittered_grid(6, 5)
     cases = [('triclinic_8_atoms', synth.TRICLINIC, synth.ATOMS8, None,
               'triclinic cell [[6,0,0],[1.5,5.5,0],[0.7,1.1,6.2]], the headline\'s 8 atoms'),
              ('cubic_216_atoms', synth.CUBIC6, atoms216, None, '216 atoms (6 x 6 x 6, jittered) in the cubic cell'),

@@ -51,7 +51,7 @@ void *xb_stream(xb_ctx *c);                      /* the hipStream_t every kernel
  * slab scheduler; x0=0,x1=nx for one GPU).  Every rank holds the full density.
  * SIZE LIMIT (the reference indexes with int64 throughout, methods.py / refinement.py): voxel indices are int32 on the
  * device, so a grid needs nx*ny*nz < 2^31 - 1 voxels (1024^3 = 2^30 fits; 1290^3 is the largest cube) -- more returns
- * XB_E_LIMIT before anything is allocated.  'changed' refinement (xb_edge_check*) stops at 2^30 voxels, see there. */
+ * XB_E_LIMIT before anything is allocated.  Every entry point works up to that size. */
 int xb_set_grid(xb_ctx *c, const int64_t shape[3], const double dist_mat[27], const double T_grad[9],
                 int64_t x0, int64_t x1);
 int xb_upload_density(xb_ctx *c, const double *rho_host);           /* H2D, nx*ny*nz float64 */
@@ -137,9 +137,8 @@ int xb_walkers_fetch(xb_ctx *c, int64_t *walkers, int64_t *results);
 int xb_walkers_continue(xb_ctx *c, const int64_t *walkers, int64_t n);
 int xb_walkers_apply(xb_ctx *c, const int64_t *results, int64_t n, int64_t *changed, int64_t *stuck);
 /* refinement.edge_check (refinement.py:409-508), bug-compatible (no vacuum test on the box voxels).
- * SIZE LIMIT: at most 2^30 voxels (1024^3 is exactly the last size): the seed / overflow lists of the dependency chase keep
- * two flag bits beside the voxel index in a 32-bit entry.  A larger grid returns XB_E_LIMIT (xb_refine in 'changed' mode
- * with it; refine mode 'all' has no such limit below xb_set_grid's). */
+ * No size limit of its own below xb_set_grid's (round 6: the two flag bits of a queue entry moved out of the voxel's 32-bit
+ * word; rounds 1-5 stopped at 2^30 voxels, exactly 1024^3). */
 int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges);
 /* refinement.edge_check across slabs ('changed' refinement on N GPUs): the greedy scan of refinement.py:420-427 is
  * global, so every rank resolves the global list of changed voxels.  _local: the owned changed voxels and their

@@ -452,7 +452,7 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
         // 'changed' refinement needs them).
         // (the seed / overflow lists: in `stage` when it is grid sized, else in a buffer of their own -- at most every listed
         // voxel is queued at once)
-        int cap = (int)std::min<long long>(c->N, 1LL << 30);
+        int cap = (int)std::min<long long>(c->N, 0x7fffffffLL);
         int *buf[2] = {(int *)c->stage, (int *)c->stage + c->N};
         if (c->stage_bytes < 8 * (size_t)c->N) {
             cap = (int)std::min<long long>(c->N, std::max<long long>(2LL * n + 65536, 1 << 20));
@@ -540,7 +540,7 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
     k_ec_collect<<<nblocks(n), TPB, 0, c->stream>>>(c->known, c->list, n, c->st, c->counters + 25);
     if (near_np < g.nx) k_ec_keep_near<<<nblocks(n), TPB, 0, c->stream>>>(g, c->list, n, c->st, near_xa, near_np);
     HIPCHK(hipMemsetAsync(c->counters64, 0, 2 * sizeof(unsigned long long), c->stream));
-    const int new_cap = (int)std::min<long long>(c->list_cap - n, 1LL << 30);   // the rest of `list` behind the compacted edges
+    const int new_cap = (int)std::min<long long>(c->list_cap - n, 0x7fffffffLL);   // the rest of `list` behind the compacted edges
     HIPCHK(hipMemsetAsync(c->counters + 7, 0, sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(c->counters + 26, 0, 2 * sizeof(int), c->stream));
     k_ec_mark<<<nblocks(n), TPB, 0, c->stream>>>(c->list, n, c->st, c->ec_pflag, (int8_t)1, plist, c->counters + 27, plist_cap);
@@ -561,7 +561,7 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
     }
     // (the sweep also lists the voxels flagged -2 afterwards, the retrace list of the next pass, into `list` itself: its
     // compacted entries and the new-edge list behind them have served)
-    const int fin_cap = (int)std::min<long long>(c->list_cap, 1LL << 30);
+    const int fin_cap = (int)std::min<long long>(c->list_cap, 0x7fffffffLL);
     k_ec_finish<<<(unsigned)std::min<long long>(nblocks((c->N + 15) / 16), 2048), TPB, 0, c->stream>>>(c->known, c->N, c->counters64,
                                                                                                       count_lo, count_hi, c->list, c->counters + 26, fin_cap);
     HIPCHK(hipGetLastError());
@@ -583,7 +583,6 @@ int xb_edge_check(xb_ctx *c, int64_t *checked, int64_t *edges) {
     c->list_valid = false; c->chg_n = -1;
     c->buni_valid = false;
     if (g.x1 - g.x0 != g.nx) return fail(XB_E_STATE, "xb_edge_check: one slab only; slabs use xb_edge_check_local + xb_edge_check_global");
-    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
     int n = 0;
     bool listed = false;
     if (chg_n >= 0) {   // the last retrace pass listed its relabelled voxels: exactly the known == -2 ones
@@ -641,7 +640,6 @@ int xb_edge_check_global(xb_ctx *c, const int64_t *idx, const int8_t *cls, int64
     if (checked) *checked = 0;
     if (edges) *edges = 0;
     if (n < 0 || n > c->N) return fail(XB_E_ARG, "xb_edge_check_global: bad list length");
-    if (c->N > (1LL << 30)) return fail(XB_E_LIMIT, "xb_edge_check: more than 2^30 voxels (queue entries keep two flag bits)");
     if (c->halo < 3 && g.vlen < g.nx) return fail(XB_E_STATE, "xb_edge_check_global: needs a halo of at least 3 planes");
     if (!n) return XB_OK;
     std::vector<int> i32(n);
@@ -777,9 +775,9 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
     // The relabelled start voxels (known == -2 now) are listed for the next edge_check in the upper half of `stage` -- launched only
     // when there are any (round 5: the launch came before the wait and returned at once in the usual case of a neargrid
     // assignment, nothing changed: 5 us of every step).  The list is complete when nothing went to the exact slow kernel.
-    if (novf == 0 && hr[1] > 0 && c->stage_bytes >= 8 * (size_t)c->N && hr[1] <= (int)std::min<long long>(c->N, 1LL << 30)) {
+    if (novf == 0 && hr[1] > 0 && c->stage_bytes >= 8 * (size_t)c->N && hr[1] <= (int)std::min<long long>(c->N, 0x7fffffffLL)) {
         k_list_changed<<<1024, TPB, 0, c->stream>>>(c->list, fs + FS_N_EDGES, c->known, (int *)c->stage + c->N, fs + FS_N_CHGLIST,
-                                                    (int)std::min<long long>(c->N, 1LL << 30), fs + FS_CHANGED);
+                                                    (int)std::min<long long>(c->N, 0x7fffffffLL), fs + FS_CHANGED);
         HIPCHK(hipGetLastError());
         c->chg_n = hr[1];   // (every relabelled voxel is an entry of the edge list: the kernel lists exactly that many)
     } else if (novf == 0 && hr[1] == 0)

@@ -1118,21 +1118,25 @@ __global__ void k_ec_keep_near(Grid g, const int *__restrict__ list, int n, int8
 }
 // Decide v if its word allows it and tell the later listed neighbours; push(e) receives, for every voxel that became
 // decidable through this decision, its queue entry.
-// `entry` (64 bits): bits 0-29 the voxel; bit 31 set when the notifier already knows the decision is "skipped", bit 30
+// `entry` (64 bits): bits 0-30 the voxel; bit 63 set when the notifier already knows the decision is "skipped", bit 62
 // when it knows "processed" (the notifier has the neighbour's word from its atomic); bits 32-58 the voxel's later
 // listed neighbours (from the same word).  Neither flag: read the word (blanket scan of round 1, where a voxel may not be
-// decidable yet).  CLAIM: wait for the status claim and give way to whoever decided the voxel first (blanket scan and
+// decidable yet; and every entry that went through a 32-bit list -- seeds, queue overflows: the word says the same thing once the
+// notification that made the entry has landed, and it has: the notifier had its atomic's result).  Round 6: the flags used to sit
+// in bits 30 / 31 of the voxel's own word, which capped 'changed' refinement at 2^30 voxels -- exactly 1024^3.  CLAIM: wait for the status claim and give way to whoever decided the voxel first (blanket scan and
 // its seeds); without it the entry is known to be the only one for its voxel and the status is published on the side.
-#define EC_E_SKIP 0x80000000u
-#define EC_E_PROC 0x40000000u
+#define EC_E_SKIP 0x8000000000000000ull
+#define EC_E_PROC 0x4000000000000000ull
+#define EC_E_VOXEL 0x7FFFFFFFull
+#define EC_E_LATER 0x07FFFFFF00000000ull
 template <bool CLAIM, typename Push>
 __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word *pend, ec_word entry, Push push) {
-    const int v = (int)(entry & 0x3FFFFFFFu);
+    const int v = (int)(entry & EC_E_VOXEL);
     int d;
     unsigned int later;
     if ((entry & (EC_E_SKIP | EC_E_PROC)) && !CLAIM) {
         d = (entry & EC_E_SKIP) ? 2 : 1;
-        later = (unsigned int)(entry >> 32);
+        later = (unsigned int)((entry & EC_E_LATER) >> 32);
     } else {
         const ec_word b = __hip_atomic_load(pend + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         later = (unsigned int)(b >> 32);
@@ -1184,7 +1188,7 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
         const unsigned int ob = (unsigned int)o[s] & 0xffffu;
         const bool wake = (uu[s] >= 0) & !(ob & (EC_NPROC | EC_CLS1)) & ((d == 1) | ((ob & EC_CNT) == 1));
         // first processed earlier neighbour: u gets skipped / the last one u waited for, none processed: processed
-        if (wake) push((ec_word)((unsigned int)uu[s] | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o[s] & 0xFFFFFFFF00000000ull));
+        if (wake) push((ec_word)(unsigned int)uu[s] | (d == 1 ? EC_E_SKIP : EC_E_PROC) | (o[s] & EC_E_LATER));
     }
     while (later) {  // the later neighbours beyond the slots
         const int u = ec_box_voxel(g, rows, z, __ffs(later) - 1);
@@ -1192,7 +1196,7 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
         const ec_word ow = atomicAdd(pend + u, delta);
         const unsigned int ob = (unsigned int)ow & 0xffffu;
         if (!(ob & (EC_NPROC | EC_CLS1)) && (d == 1 || (ob & EC_CNT) == 1))
-            push((ec_word)((unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (ow & 0xFFFFFFFF00000000ull));
+            push((ec_word)(unsigned int)u | (d == 1 ? EC_E_SKIP : EC_E_PROC) | (ow & EC_E_LATER));
     }
 }
 // The same for a QUEUE entry of the chase (the decision and the later-neighbour mask ride in the entry), spread over 16 lanes:
@@ -1210,9 +1214,9 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
 template <typename Push>
 __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, double inv_nz, int8_t *known, ec_word *pend, ec_word entry,
                                                  int sub, Push push) {
-    const int v = (int)(entry & 0x3FFFFFFFu);
+    const int v = (int)(entry & EC_E_VOXEL);
     const int d = (entry & EC_E_SKIP) ? 2 : 1;
-    const unsigned int later = (unsigned int)(entry >> 32);
+    const unsigned int later = (unsigned int)((entry & EC_E_LATER) >> 32);
     if (sub == 0) {   // publish the decision (a queue entry is the only one for its voxel: nobody waits for the result)
         const int sh = (v & 3) * 8;
         __hip_atomic_fetch_and(reinterpret_cast<unsigned int *>(known + (v & ~3)), ~((d == 1 ? 0x02u : 0x08u) << sh), __ATOMIC_RELAXED,
@@ -1226,9 +1230,10 @@ __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, 
     static_assert(EC_LANES == 8, "a lane's positions are sub + 8 k");
     unsigned int mine = later & (0x01010101u << sub);
     if (!mine) return;
-    // v -> (x, y, z) with two multiplications by reciprocals and a correction step (exact: v < 2^30)
+    // v -> (x, y, z) with two multiplications by reciprocals and a correction step (exact for every int32 index; the product in
+    // unsigned arithmetic: a quotient one too large may pass 2^31 - 1 on the largest grids)
     int x = (int)((double)v * inv_nyz);
-    int r = v - x * g.nyz;
+    int r = (int)((unsigned)v - (unsigned)x * (unsigned)g.nyz);
     if (r < 0) { x--; r += g.nyz; } else if (r >= g.nyz) { x++; r -= g.nyz; }
     int y = (int)((double)r * inv_nz);
     int z = r - y * g.nz;
@@ -1250,7 +1255,7 @@ __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, 
     for (int k = 0; k < 4; k++) {
         const unsigned int b = (unsigned int)o[k] & 0xffffu;
         if (u[k] >= 0 && !(b & (EC_NPROC | EC_CLS1)) && (d == 1 || (b & EC_CNT) == 1))
-            push((ec_word)((unsigned int)u[k] | (d == 1 ? EC_E_SKIP : EC_E_PROC)) | (o[k] & 0xFFFFFFFF00000000ull));
+            push((ec_word)(unsigned int)u[k] | (d == 1 ? EC_E_SKIP : EC_E_PROC) | (o[k] & EC_E_LATER));
     }
 }
 // Round 1: every listed voxel once; what is decidable at once (no earlier listed neighbour, or edge&max) is
@@ -1261,7 +1266,7 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word
     for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
         ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)in[e], [&](ec_word u) {
             const int at = atomicAdd(n_out, 1);
-            if (at < out_cap) out[at] = (int)(unsigned int)u;
+            if (at < out_cap) out[at] = (int)(u & EC_E_VOXEL);
         });
 }
 // The rest: the dependency chains are ~1000 voxels long while only a few thousand voxels are decidable at any
@@ -1359,7 +1364,7 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
             if (at < qcap) nq[at] = u;
             else {  // queue full: hand over to the next launch (as a seed: it reads its word again)
                 const int o = atomicAdd(n_ovf, 1);
-                if (o < ovf_cap) ovf[o] = (int)(unsigned int)u;
+                if (o < ovf_cap) ovf[o] = (int)(u & EC_E_VOXEL);
             }
         };
         // what this round gives away: up to 64 entries from the end of the queue -- in the chains' tail whatever it holds beyond
@@ -1410,7 +1415,7 @@ __global__ __launch_bounds__(EC_CHASE_THREADS) void k_ec_chase(Grid g, int8_t *k
                         if (at + lane - now < qcap) nq[at + lane - now] = got;
                         else {
                             const int o = atomicAdd(n_ovf, 1);
-                            if (o < ovf_cap) ovf[o] = (int)(unsigned int)got;
+                            if (o < ovf_cap) ovf[o] = (int)(got & EC_E_VOXEL);
                         }
                     }
                 }

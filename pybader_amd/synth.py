@@ -108,3 +108,12 @@ def rough_density(shape, lattice=CUBIC6, atoms=ATOMS8, noise=0.0, seed=7, sig_di
     if quantum:
         rho = np.round(rho / np.float64(quantum)) * np.float64(quantum)
     return np.ascontiguousarray(rho)
+
+
+def atoms_jittered_grid(k=6, seed=5):
+    """k^3 atoms on a jittered k x k x k lattice of fractional positions with random widths and charges (rows as ATOMS8):
+    the many-atom cell of bench.py's user leg and of the golden case c128_216atoms (k = 6: 216 atoms)."""
+    rng = np.random.default_rng(seed)
+    cells = np.stack(np.meshgrid(*(np.arange(k),) * 3, indexing='ij'), -1).reshape(-1, 3)
+    frac = (cells + 0.5 + 0.18 * (rng.random(cells.shape) - 0.5)) / k
+    return np.concatenate([frac, 0.09 + 0.04 * rng.random((len(frac), 1)), 2.0 + 6.0 * rng.random((len(frac), 1))], 1)

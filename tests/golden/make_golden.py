@@ -510,6 +510,9 @@ CASES = {
     # round 5: a large NON-cubic pin -- the generic Grid instantiations (no mirror prefilter, full T_grad) above 128^3
     'c320_tric': dict(shape=(320, 320, 320), lattice=synth.TRICLINIC, full_maps=False, do_F=True,
                       modes=(('changed', 2),)),
+    # round 6: many atoms -- 216 maxima, bricks with several of them, twice the dividing surface per voxel
+    'c128_216atoms': dict(shape=(128, 128, 128), lattice=synth.CUBIC6, atoms=synth.atoms_jittered_grid(6, 5), full_maps=False,
+                          modes=(('changed', 2), ('all', -1))),
     # (the reference's default two iterations do not converge here -- its log ends with 33 relabelled voxels -- so the converged
     # ('changed', -1) result is captured as well: that one is the own-trajectory map)
     'c1024_cubic': dict(shape=(1024, 1024, 1024), lattice=synth.CUBIC6, full_maps=False, do_F=False,

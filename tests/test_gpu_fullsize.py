@@ -2,11 +2,13 @@
 conservation, maxima consistency, idempotence of refinement, translation invariance of the
 partition, and N-slab == 1-GPU."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
 import torch  # noqa: F401  (before the library: see conftest)
+import oracle
 from conftest import load_golden
 from pybader_amd import _lib, synth
 from pybader_amd.interface import distance_matrix, gradient_transform
@@ -494,14 +496,40 @@ def test_host_waits_of_one_gpu_steps():
 
 
 def test_size_limits_fail_loudly():
-    """the reference indexes with int64 (refinement.py:409-508, methods.py); this library's voxel indices are
-    int32 and 'changed' refinement keeps two flag bits beside them.  Both limits are stated at the boundary
-    (include/bader_hip.h) and must come back as errors, never as wrapped indices."""
+    """the reference indexes with int64 (refinement.py:409-508, methods.py); this library's voxel indices
+    are int32.  The limit is stated at the boundary (include/bader_hip.h) and must come back as an
+    error, never as wrapped indices.  (Rounds 1-5 had a second limit, 2^30 voxels for 'changed' refinement: gone, see below.)"""
     ctx = _lib.Context(0)
     dm, tg = matrices((8, 8, 8), synth.CUBIC6)
     with pytest.raises(_lib.BaderHipError, match='int32 index range'):
         ctx.set_grid((2048, 1024, 1024), dm, tg)                      # 2^31 voxels: refused before anything is allocated
-    ctx.set_grid((1032, 1024, 1024), dm, tg)                          # 2^30 + 2^23 voxels: fine for everything ...
-    with pytest.raises(_lib.BaderHipError, match='2\\^30 voxels'):
-        ctx.edge_check()                                              # ... but refinement.edge_check
     ctx.close()
+
+
+@pytest.mark.skipif(os.environ.get('XB_BIG_EDGE_CHECK') != '1', reason='1.08 G voxels against the CPU oracle: ~10 min of host time (XB_BIG_EDGE_CHECK=1)')
+def test_edge_check_above_2_30_voxels_against_the_oracle():
+    """Round 6: `edge_check`'s queue entries no longer keep their flag bits beside the voxel index, so 'changed' refinement runs up
+    to the grid limit.  1032 x 1024 x 1024 (2^30 + 2^23 voxels), ongrid assignment + neargrid refinement ('changed', 2) -- the
+    combination that relabels voxels and so goes through the dependency chase with voxel indices above 2^30 -- against the CPU
+    oracle's map and log.  Run by hand (XB_BIG_EDGE_CHECK=1); the result of the round-6 run is recorded in DESIGN.md."""
+    shape = (1032, 1024, 1024)
+    lat = synth.CUBIC6 * (np.array(shape, np.float64) / 1024.0)[:, None]
+    dm, tg = matrices(shape, lat)
+    ctx = _lib.Context(0)
+    ctx.set_grid(shape, dm, tg)
+    ctx.synth_density(lat, synth.ATOMS8, synth.BACKGROUND)
+    rho = ctx.download_density()
+    ctx.vacuum_assign(None, 1.0)
+    n = ctx.assign('ongrid')
+    log = ctx.refine('changed', 2)
+    got = ctx.download_labels(np.int8)
+    mx = ctx.maxima()
+    ctx.close()
+    bmax, want = oracle.bader_calc('ongrid', rho, np.zeros(shape, np.int32), dm, tg, 1)
+    wlog = []
+    oracle.refine('neargrid', ('changed', 2), rho, want, dm, tg, 1, log=wlog)
+    assert n == bmax.shape[0] and np.array_equal(mx, bmax)
+    assert [tuple(r) for r in log] == [tuple(r) for r in wlog], (log, wlog)
+    high = np.flatnonzero(got.reshape(-1)[1 << 30:] != want.reshape(-1)[1 << 30:].astype(np.int8))
+    assert np.array_equal(got, want.astype(np.int8)), f'{int((got != want).sum())} voxels differ ({high.size} of them above index 2^30)'
+    assert sum(ch for _, ch in log) > 0, 'the case must relabel voxels, or edge_check never runs'

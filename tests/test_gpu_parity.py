@@ -9,6 +9,7 @@ import pytest
 
 from conftest import GOLDEN, case_density, load_golden
 from pybader_amd import _lib, synth
+from pybader_amd.utils import dtype_calc
 
 pytestmark = pytest.mark.gpu
 
@@ -140,7 +141,7 @@ def test_ongrid_and_speed_profile(ctx, name):
     assert np.array_equal(ctx.download_labels(np.int8), g['og_atoms_volumes_speed'])
 
 
-@pytest.mark.parametrize('name', ['c128_tric', 'c256_cubic', 'c320_tric', 'c512_cubic'])   # (c320_tric, round 5: the generic Grid instantiations above 128^3)
+@pytest.mark.parametrize('name', ['c128_tric', 'c128_216atoms', 'c256_cubic', 'c320_tric', 'c512_cubic'])   # (c320_tric, round 5: the generic Grid instantiations above 128^3)
 def test_large_golden_hashes(ctx, name):
     g = load_golden(name)
     shape = tuple(int(s) for s in g['shape'])
@@ -150,7 +151,7 @@ def test_large_golden_hashes(ctx, name):
     ctx.vacuum_assign(None, vv)
     n = ctx.assign('neargrid')
     assert np.array_equal(ctx.maxima(), g['ng_bader_max'])
-    dt = np.int8
+    dt = np.dtype(dtype_calc(-n))        # what the reference narrows its map to (int8 up to 63 basins, int16 for the 216 atoms)
     assert sha(ctx.download_labels(dt)) == str(g['ng_F_sha256'])
     log = ctx.refine('changed', 2)
     assert all(ch == 0 for _, ch in log)

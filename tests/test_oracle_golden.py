@@ -28,7 +28,7 @@ def check(g, key, arr):
         assert arr.dtype == g[key].dtype and np.array_equal(arr, g[key]), key
 
 
-@pytest.mark.parametrize('name', FULL + ['c128_tric'])
+@pytest.mark.parametrize('name', FULL + ['c128_tric', 'c128_216atoms'])
 def test_neargrid_pipeline(name):
     g = load_golden(name)
     rho = case_density(g)
@@ -81,7 +81,7 @@ def test_neargrid_sums_and_atoms(name):
     np.testing.assert_allclose(avol, g['ng_atoms_volume'], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize('name', FULL + ['c128_tric'])
+@pytest.mark.parametrize('name', FULL + ['c128_tric', 'c128_216atoms'])
 def test_ongrid_pipeline(name):
     g = load_golden(name)
     rho = case_density(g)
