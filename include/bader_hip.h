@@ -266,7 +266,8 @@ int xb_enable_timing(xb_ctx *c, int on);
 /* Switches (nine keys).  A USER of the library sets none of them: every default is the measured best, and no switch changes a
  * result.  What each is for:
  *   6   drop the cached gradient-field table (benchmarks: a table kept from an earlier step would hide 1.6 ms per step);
- *   3   debug prints (bit 2 edge_check passes, bit 4 slab statistics, bit 5 wait after every stage of an assignment);
+ *   3   debug (bit 2 edge_check passes, bit 4 slab statistics, bit 5 wait after every stage of an assignment, bit 6 the exact
+ *       slow path with tiers of 3 / 5 / 8 path voxels, so that a test reaches its last tier);
  *   24  collectives return without waiting (set by pybader_amd.slab itself);
  *   1   trapping regions (0: plain full trajectories from a record per voxel) -- the exactness cross-check of the whole design;
  *   2   cross-check bits, each selecting the second implementation of one step so that a test can compare the two:

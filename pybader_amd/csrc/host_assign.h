@@ -169,7 +169,8 @@ static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int 
     if (!escaped) escaped = c->counters + 3;
     if (n <= 0) return XB_OK;
     const size_t budget = (size_t)128 << 20;   // ints of path scratch per launch (512 MB)
-    static const int tiers[3] = {64, 2048, 1 << 15};
+    // (+ a last tier of 2^20, below; debug switch 64: tiers of 3 / 5 / 8 voxels, so that a test reaches every one of them)
+    const int tiers[3] = {(c->opt_dbg & 64) ? 3 : 64, (c->opt_dbg & 64) ? 5 : 2048, (c->opt_dbg & 64) ? 8 : 1 << 15};
     const bool blind = (size_t)n * tiers[1] <= budget;
     const size_t have = std::max<size_t>(std::min<size_t>(budget, (size_t)n * tiers[0]), blind ? (size_t)n * tiers[1] : 0) + (size_t)(1 << 15) * 64;
     const size_t n_lists = 2 * (size_t)n + 8;
@@ -200,29 +201,42 @@ static int run_slow(xb_ctx *c, int n, int refine, int *max_count = nullptr, int 
     }
     for (int tier = 0; tier < 3 && n_cur > 0; tier++) {
         const int lmax = tiers[tier];
-        const bool last = tier == 2;
         int *next = lists + (size_t)(tier & 1) * n, *next_cnt = cnt + (tier & 1);
-        const int chunk = (blind && !last) ? n_cur : (int)std::max<size_t>(64, std::min<size_t>(have / lmax, (size_t)n_cur) & ~(size_t)63);
+        const int chunk = (blind && tier < 2) ? n_cur : (int)std::max<size_t>(64, std::min<size_t>(have / lmax, (size_t)n_cur) & ~(size_t)63);
         for (int o = 0; o < n_cur; o += chunk) {   // (blind: one chunk -- the bound times the tier's path length fits)
             const int m = std::min(chunk, n_cur - o);
             k_trace_slow<<<(m + 63) / 64, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, cur + o, m, path, lmax, refine,
                                                              c->first, c->max_list, max_count, c->max_cap, changed, escaped, cnt + 2, nullptr,
-                                                             c->has_vacuum ? 1 : 0, m, 1, last ? nullptr : next, last ? nullptr : next_cnt, cur_n_dev);
+                                                             c->has_vacuum ? 1 : 0, m, 1, next, next_cnt, cur_n_dev);
         }
         HIPCHK(hipGetLastError());
-        if (last) break;
         cur = next;
         if (blind && tier == 0) { cur_n_dev = next_cnt; continue; }   // (tier 1 right behind: its list's length stays on the device)
         HIPCHK(hipMemcpyAsync(c->host_ints, next_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         n_cur = c->host_ints[0];
         cur_n_dev = nullptr;
-        if (tier == 0) HIPCHK(hipMemsetAsync(cnt + 1, 0, sizeof(int), c->stream));
-        if (tier == 1 && n_cur == 0) return XB_OK;   // (only the last tier can fail: the others list what does not fit)
+        if (n_cur == 0) return XB_OK;
+        HIPCHK(hipMemsetAsync(cnt + ((tier + 1) & 1), 0, sizeof(int), c->stream));   // the list the next tier fills
     }
-    HIPCHK(hipMemcpyAsync(c->host_ints, cnt + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // (the scratch may go afterwards)
-    if (c->host_ints[0]) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", tiers[2]);
+    // Round 6, the last tier: what even 32768 path voxels did not hold (nothing on any density seen so far; rounds 1-5 failed the
+    // call here, the reference has no such limit) gets 2^20 voxels per walker in a buffer of its own, a wave of walkers at a time.
+    // Only this tier can fail -- loudly.
+    {
+        const int lmax = 1 << 20;
+        DevBuf<int> long_buf;
+        HIPCHK(long_buf.alloc((size_t)64 * lmax));
+        for (int o = 0; o < n_cur; o += 64) {
+            const int m = std::min(64, n_cur - o);
+            k_trace_slow<<<1, 64, 0, c->stream>>>(c->g, c->rho, c->labels, c->known, c->known, cur + o, m, long_buf.p, lmax, refine,
+                                                 c->first, c->max_list, max_count, c->max_cap, changed, escaped, cnt + 2, nullptr,
+                                                 c->has_vacuum ? 1 : 0, m, 1, nullptr, nullptr, nullptr);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->host_ints, cnt + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));   // (the scratch may go afterwards)
+        if (c->host_ints[0]) return fail(XB_E_LIMIT, "trajectory longer than %d voxels", lmax);
+    }
     return XB_OK;
 }
 
@@ -440,11 +454,11 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     if (c->regions_pending && c->blab) {
         // (one brick-label lookup per 8 rows; 16-byte stores when the rows are aligned.  The launch covers 4-plane groups from x0 on)
         if (g.nz % 4 == 0)
-            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
+            k_relabel_regions_brick<4><<<dim3((g.nz / 4 + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
                 light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX),
                 nullptr, nullptr, c->n_boxes);
         else
-            k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
+            k_relabel_regions_brick<1><<<dim3((g.nz + 63) / 64, c->nbk[1], (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(
                 light(g), c->labels, c->first, c->blab, c->nbk[1], c->nbk[2], (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX),
                 nullptr, nullptr, c->n_boxes);
         if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
@@ -475,7 +489,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
     c->regions_pending = false;
     HIPCHK(hipGetLastError());
     if (n_global) {  // leave `first` clean (INT_MAX everywhere) for the next assignment
-        k_reset_first<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global);
+        k_reset_first<<<(unsigned)((n_global + 255) / 256), 256, 0, c->stream>>>(c->first, c->max_aux, (int)n_global, nullptr, nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -510,10 +524,10 @@ static int fused_numbering_launch(xb_ctx *c) {
     int *buni = reinterpret_cast<int *>(c->st);
     if (c->regions_pending) {
         if (g.nz % 4 == 0)
-            k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+            k_relabel_regions_brick<4><<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                         box_max, fs, fs + FS_SORT_OK);
         else
-            k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+            k_relabel_regions_brick<1><<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                      box_max, fs, fs + FS_SORT_OK);
         if (bres) k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, walk, fs + FS_N_WALK, bres);
         else {
@@ -522,7 +536,7 @@ static int fused_numbering_launch(xb_ctx *c) {
         }
     } else
         k_relabel<<<nblocks(c->N), TPB, 0, c->stream>>>(g, c->labels, c->first, fs + FS_SORT_OK);
-    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    k_reset_first<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, 0, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
     return XB_OK;
 }
@@ -891,14 +905,14 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux, fs + FS_TOTAL);
     int *buni = reinterpret_cast<int *>(c->st);
     if (g.nz % 4 == 0)
-        k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+        k_relabel_regions_brick<4><<<dim3((g.nz / 4 + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                     box_max, fs, fs + FS_SORT_OK);
     else
-        k_relabel_regions_brick1<<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
+        k_relabel_regions_brick<1><<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                  box_max, fs, fs + FS_SORT_OK);
     k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
     k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
-    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    k_reset_first<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, 0, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->host_ints, fs, (FS_TOTAL + XB_SORT_MAX) * sizeof(int), hipMemcpyDeviceToHost, c->stream));   // state block + sorted maxima: one transfer
     HIPCHK(hipStreamSynchronize(c->stream));

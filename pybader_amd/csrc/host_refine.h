@@ -224,7 +224,7 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
     if (scatter) {
         if (e == hipSuccess) e = hipMemcpyAsync(dlab, lab, n * sizeof(int), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dkn, kn, n, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) k_scatter_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, dlab, dkn, c->labels, c->known);
+        if (e == hipSuccess) k_move_voxels<true><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
         c->list_valid = false; c->chg_n = -1;
         c->buni_valid = false; c->regions_labels = false;
         c->zero_outside[0] = -1;
@@ -234,7 +234,7 @@ static int voxel_io(xb_ctx *c, const int64_t *idx, int64_t n, int32_t *lab, int8
         // agrees on the width with xb_label_wire before its next exchange (slab.py does).
         c->label_wire = std::max(c->label_wire, labels_fit_wire(lab, n));
     } else {
-        if (e == hipSuccess) k_gather_voxels<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
+        if (e == hipSuccess) k_move_voxels<false><<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(d, (int)n, c->labels, c->known, dlab, dkn);
         if (e == hipSuccess) e = hipMemcpyAsync(lab, dlab, n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(kn, dkn, n, hipMemcpyDeviceToHost, c->stream);
     }

@@ -176,14 +176,11 @@ __global__ void k_set_rank(int *first, const int *max_sorted, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) first[max_sorted[i]] = i;
 }
-__global__ void k_reset_first(int *first, const int *max_list, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) first[max_list[i]] = XB_INT_MAX;
-}
-// the same for a device-side count (and only when `gate` is set: the device-side numbering succeeded)
-__global__ void k_reset_first_dev(int *first, const int *max_list, const int *n_dev, const int *gate) {
-    if (!*gate) return;
-    const int n = *n_dev;
+// first[] back to "nobody arrived" for the listed maxima: n of them, or *n_dev (and then only when `gate` is set: the
+// device-side numbering succeeded)
+__global__ void k_reset_first(int *first, const int *max_list, int n, const int *n_dev, const int *gate) {
+    if (gate && !*gate) return;
+    if (n_dev) n = *n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) first[max_list[i]] = XB_INT_MAX;
 }
 // labels[v] (maximum index) -> rank stored in first[maximum]

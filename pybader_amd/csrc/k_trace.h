@@ -51,76 +51,54 @@ __global__ void k_note_certain_bricks(GridL g, int nb0, int nb1, int nb2, int b_
 }
 // labels := rank of the maximum; voxels of certain bricks take it from the brick label, the others from the maximum index the
 // trace left in `labels`.
-// Brick-shaped version: a thread owns the 8 y-rows of one brick at one (x, z/4): ONE brick-label lookup (through a
-// per-block LDS table of the region ranks) for 8 16-byte stores; a block covers 4 x-planes x 256 voxels of z.
+// Brick-shaped version: a thread owns the 8 y-rows of one brick at one (x, z / V): ONE brick-label lookup (through a
+// per-block LDS table of the region ranks) for 8 stores of V labels; a block covers 4 x-planes x 64 V voxels of z.
+// V = 4: 16-byte stores (z extents that are multiples of 4: rows are 16-byte aligned); V = 1: any z extent -- 4-byte
+// stores, a wave writes 256 contiguous bytes of a row (round 4; before, such grids took the per-voxel k_relabel: three
+// integer divisions and a brick lookup per voxel, 0.48 instead of 0.14 ms at 500^3).
+template <int V>
 __global__ __launch_bounds__(TPB) void k_relabel_regions_brick(GridL g, int *labels, const int *__restrict__ rank,
                                                                const int *__restrict__ blab, int nb1, int nb2,
                                                                const int *__restrict__ box_max, const int *__restrict__ fs,
                                                                const int *gate, int n_boxes = -1) {
+    static_assert(V == 1 || V == 4, "a label or four of them per store");
+    struct alignas(4 * V) Vec { int l[V]; };
     __shared__ int s_rank[XB_BOXES_MAX];
     if (gate && !*gate) return;
     // (n_boxes: the number of regions when the caller knows it -- a slab, whose planes x0..x1 the launch covers)
     for (int i = threadIdx.x; i < min(n_boxes >= 0 ? n_boxes : fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
     __syncthreads();
-    const int z = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = g.x0 + blockIdx.z * 4 + (threadIdx.x >> 6);
+    const int z = V * (blockIdx.x * 64 + (threadIdx.x & 63)), by = blockIdx.y, x = g.x0 + blockIdx.z * 4 + (threadIdx.x >> 6);
     if (z >= g.nz || x >= g.x1) return;
     const int b = blab[((x >> 3) * nb1 + by) * nb2 + (z >> 3)];
-    int4 *p = reinterpret_cast<int4 *>(labels + ((size_t)(x * g.ny + by * 8) * g.nz + z));
-    const int stride = g.nz >> 2;   // int4 per row
+    Vec *p = reinterpret_cast<Vec *>(labels + ((size_t)(x * g.ny + by * 8) * g.nz + z));
+    const int stride = g.nz / V;   // vectors per row
     const int rows = min(8, g.ny - by * 8);   // (a brick the grid cuts in y: its rows inside the grid)
     if (b > 0) {
         const int l = b <= XB_BOXES_MAX ? s_rank[b - 1] : rank[box_max[b - 1]];
-        const int4 v = make_int4(l, l, l, l);
+        Vec v;
+#pragma unroll
+        for (int k = 0; k < V; k++) v.l[k] = l;
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            if (r < rows) p[r * stride] = v;
+            if (r < rows) p[(size_t)r * stride] = v;
     } else {
-        int4 m[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) m[r] = r < rows ? p[r * stride] : make_int4(-1, -1, -1, -1);
+        Vec m[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            if (m[r].x >= 0) m[r].x = rank[m[r].x];
-            if (m[r].y >= 0) m[r].y = rank[m[r].y];
-            if (m[r].z >= 0) m[r].z = rank[m[r].z];
-            if (m[r].w >= 0) m[r].w = rank[m[r].w];
+            if (r < rows) m[r] = p[(size_t)r * stride];
+            else
+#pragma unroll
+                for (int k = 0; k < V; k++) m[r].l[k] = -1;
         }
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            if (r < rows) p[r * stride] = m[r];
-    }
-}
-// The same for a z extent that is not a multiple of 4 (rows are not 16-byte aligned): a thread owns the 8 y-rows of one brick
-// at one (x, z) -- 4-byte stores, a wave writes 256 contiguous bytes of a row.  (Round 4; before, such grids took the
-// per-voxel k_relabel_regions: three integer divisions and a brick lookup per voxel, 0.48 instead of 0.14 ms at 500^3.)
-__global__ __launch_bounds__(TPB) void k_relabel_regions_brick1(GridL g, int *labels, const int *__restrict__ rank,
-                                                                const int *__restrict__ blab, int nb1, int nb2,
-                                                                const int *__restrict__ box_max, const int *__restrict__ fs,
-                                                                const int *gate, int n_boxes = -1) {
-    __shared__ int s_rank[XB_BOXES_MAX];
-    if (gate && !*gate) return;
-    for (int i = threadIdx.x; i < min(n_boxes >= 0 ? n_boxes : fs[FS_N_BOXES], XB_BOXES_MAX); i += TPB) s_rank[i] = rank[box_max[i]];
-    __syncthreads();
-    const int z = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y, x = g.x0 + blockIdx.z * 4 + (threadIdx.x >> 6);
-    if (z >= g.nz || x >= g.x1) return;
-    const int b = blab[((x >> 3) * nb1 + by) * nb2 + (z >> 3)];
-    int *p = labels + ((size_t)(x * g.ny + by * 8) * g.nz + z);
-    const int rows = min(8, g.ny - by * 8);
-    if (b > 0) {
-        const int l = b <= XB_BOXES_MAX ? s_rank[b - 1] : rank[box_max[b - 1]];
+#pragma unroll
+            for (int k = 0; k < V; k++)
+                if (m[r].l[k] >= 0) m[r].l[k] = rank[m[r].l[k]];
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            if (r < rows) p[(size_t)r * g.nz] = l;
-    } else {
-        int m[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) m[r] = r < rows ? p[(size_t)r * g.nz] : -1;
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-            if (m[r] >= 0) m[r] = rank[m[r]];
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-            if (r < rows) p[(size_t)r * g.nz] = m[r];
+            if (r < rows) p[(size_t)r * stride] = m[r];
     }
 }
 // 16 bricks per thread, one atomic per block; the list keeps brick order inside a block's range
@@ -665,15 +643,13 @@ __global__ void k_path_pack(const int *__restrict__ path, int lmax, const int *_
     if (threadIdx.x == 0) packed[off[t]] = P[0];
     for (int k = first[t] + threadIdx.x; k < len[t]; k += blockDim.x) packed[off[t] + 1 + k - first[t]] = P[k];
 }
-__global__ void k_gather_voxels(const int *__restrict__ idx, int n, const int *__restrict__ labels,
-                                const int8_t *__restrict__ known, int *lab_out, int8_t *kn_out) {
+// labels / known of listed voxels out of the grid arrays (SCATTER false) or back into them (remote path queries)
+template <bool SCATTER>
+__global__ void k_move_voxels(const int *__restrict__ idx, int n, int *labels, int8_t *known, int *lab_buf, int8_t *kn_buf) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) { lab_out[t] = labels[idx[t]]; kn_out[t] = known[idx[t]]; }
-}
-__global__ void k_scatter_voxels(const int *__restrict__ idx, int n, const int *__restrict__ lab_in,
-                                 const int8_t *__restrict__ kn_in, int *labels, int8_t *known) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) { labels[idx[t]] = lab_in[t]; known[idx[t]] = kn_in[t]; }
+    if (t >= n) return;
+    if (SCATTER) { labels[idx[t]] = lab_buf[t]; known[idx[t]] = kn_buf[t]; }
+    else { lab_buf[t] = labels[idx[t]]; kn_buf[t] = known[idx[t]]; }
 }
 
 // Exact slow path for the (rare) trajectories whose path membership could not be decided from the

@@ -419,14 +419,14 @@ int xb_slab_assign_finish(xb_ctx *c, int64_t *n_maxima, int64_t *status) {
     k_slab_merge_min<<<c->slab_nranks, 256, 0, c->stream>>>(tabs, c->first);
     k_slab_merge_list<<<1, 1024, 0, c->stream>>>(tabs, c->slab_nranks, c->max_list, c->max_cap, fs);
     k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux);
-    k_relabel_regions_brick<<<dim3((g.nz / 4 + 63) / 64, nb1, (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max,
+    k_relabel_regions_brick<4><<<dim3((g.nz / 4 + 63) / 64, nb1, (g.x1 - g.x0 + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2, box_max,
                                                                                                           fs, fs + FS_SORT_OK);
     // per-brick uniformity for the edge sweep: the regions' bricks are uniform on every rank, the owned walk-list bricks are
     // scanned, every other brick counts as mixed -- right whatever the peers' halo planes bring
     k_fill<int><<<(nbr + 4 * TPB - 1) / (4 * TPB), TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
     k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
     k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
-    k_reset_first_dev<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, fs + FS_N_MAX, fs + FS_SORT_OK);
+    k_reset_first<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, 0, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
     // the ONE host wait of the assignment: state block + the sorted maxima
     HIPCHK(hipMemcpyAsync(c->host_ints, fs, FS_COUNT * sizeof(int), hipMemcpyDeviceToHost, c->stream));
