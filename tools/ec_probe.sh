@@ -10,6 +10,6 @@ mkdir -p gpurun_out
     -DXB_EC_PROBE -DXB_DEBUG_COUNT -o pybader_amd/libbader_hip_ecprobe.so pybader_amd/csrc/bader_hip.hip 2> /dev/null || exit 1
 for share in 1 0; do
   echo "== sharing $share"
-  XB_LIBRARY=$ROOT/pybader_amd/libbader_hip_ecprobe.so XB_OPT_29=$share XB_OPT_DBG=4 timeout -k 10 120 python3 bench.py --method ongrid --steps 1 --warmup 1 \
+  XB_LIBRARY=$ROOT/pybader_amd/libbader_hip_ecprobe.so XB_OPT_2=$((share ? 0 : 32)) XB_OPT_DBG=4 timeout -k 10 120 python3 bench.py --method ongrid --steps 1 --warmup 1 \
       --no-cpu --no-dropin --no-odd --no-user-legs --no-batch --no-config5 2>&1 > /dev/null | grep "edge_check sharing\|  rounds" | tail -6
 done | tee gpurun_out/ec_probe.txt

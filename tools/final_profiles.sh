@@ -21,7 +21,7 @@ for part in $PARTS; do
     sizes) for s in 64 256 1024; do
              python3 bench.py --size $s --steps 5 --warmup 1 --no-cpu --no-dropin --no-config5 --no-user-legs --no-batch > $OUT/bench_$s.json 2> $OUT/bench_$s.err; echo "size $s rc=$?"
            done
-           ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_1024 -o ks -- python3 $ROOT/bench.py --size 1024 --steps 3 --warmup 1 --no-cpu --no-dropin --no-config5 --no-user-legs --no-batch --no-stage-steps > $OUT/stats_1024.log 2>&1 ) ;;
+           ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_1024 -o ks -- python3 $ROOT/bench.py --size 1024 --steps 3 --warmup 1 --no-cpu --no-dropin --no-config5 --no-user-legs --no-batch --no-sustained --no-stage-steps > $OUT/stats_1024.log 2>&1 ) ;;
     emul) timeout -k 10 400 python3 tools/slab_emulation.py --size 512 --ranks 1 2 4 8 --halo 16 --steps 10 --warmup 3 > $OUT/slab_emulation_512.jsonl 2> $OUT/slab_emulation_512.err; echo "emul 512 rc=$?"
           timeout -k 10 600 python3 tools/slab_emulation.py --size 1024 --ranks 1 2 4 8 --halo 16 --margin 64 --steps 3 --warmup 1 > $OUT/slab_emulation_1024.jsonl 2> $OUT/slab_emulation_1024.err; echo "emul 1024 rc=$?"
           ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_8slabs -o ks -- python3 $ROOT/tools/slab_emulation.py --size 512 --ranks 8 --halo 16 --steps 10 --warmup 3 > $OUT/stats_8slabs.log 2>&1 ) ;;

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for counters in "$@"; do
-  timeout -k 10 180 rocprofv3 --pmc $counters --output-format csv -d $OUT/p$i -o pmc -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-dropin --no-odd --no-user-legs --no-batch --no-stage-steps --steps 1 --warmup 0 > $OUT/p$i.log 2>&1
+  timeout -k 10 180 rocprofv3 --pmc $counters --output-format csv -d $OUT/p$i -o pmc -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-dropin --no-odd --no-user-legs --no-batch --no-sustained --no-stage-steps --steps 1 --warmup 0 > $OUT/p$i.log 2>&1
   echo "pass $i ($counters): rc=$?"
   i=$((i+1))
 done
