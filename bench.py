@@ -145,7 +145,11 @@ def user_legs(size, steps, warmup, mode, iters, headline_ns_per_voxel, stage_nam
              ('cubic_216_atoms', synth.CUBIC6, atoms216, None, '216 atoms (6 x 6 x 6, jittered) in the cubic cell'),
              ('noisy_vacuum', synth.CUBIC6, synth.ATOMS8, 2e-3,
               'the headline\'s density + uniform noise of amplitude 2e-3 wherever it is below 0.2 (tests/test_gpu_fullsize.py::test_noisy_vacuum_keeps_the_atoms_regions at full size)')]
-    for name, lat, atoms, noise, what in cases:
+    cases = [c + (None,) for c in cases]
+    # ... and that density the way its users run it: with a vacuum tolerance that takes the noise out
+    cases.append(('noisy_vacuum_with_tol', synth.CUBIC6, synth.ATOMS8, 2e-3,
+                  'the noisy-vacuum density with vacuum_tol = 0.21 (every voxel the noise touches is vacuum)', 0.21))
+    for name, lat, atoms, noise, what, vac_tol in cases:
         vl = np.divide(lat, shape)
         c = _lib.Context(0)
         c.set_grid(shape, distance_matrix(vl), gradient_transform(vl))
@@ -160,7 +164,7 @@ def user_legs(size, steps, warmup, mode, iters, headline_ns_per_voxel, stage_nam
 
         def step():
             c.set_option(6, 1)
-            c.vacuum_assign(None, vv)
+            c.vacuum_assign(vac_tol, vv)
             n = c.assign('neargrid')
             return n, c.refine(mode, iters)
         for _ in range(max(1, warmup)):

@@ -508,19 +508,48 @@ static bool fused_ok(const xb_ctx *c) {
     return c->opt_boxes && c->opt_bricks && g.x0 == 0 && g.x1 == g.nx && !table_windowed(c) &&
            g.nx >= 16 && g.ny >= 16 && g.nz >= 16;
 }
-static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima);
 static int assign_neargrid_tail(xb_ctx *c, int64_t *n_maxima);
 static int fused_numbering_launch(xb_ctx *c);
 
 // numbering + relabel on the device (skipped by their gate when the numbering has to be done on the host), the per-brick
 // uniformity for the edge sweep, `first` left clean, and the state block + the sorted maxima on their way to the host
+static int fused_relabel_launch(xb_ctx *c);
 static int fused_numbering_launch(xb_ctx *c) {
+    k_number_maxima<<<1, 1024, 0, c->stream>>>(c->fs, c->first, c->max_list, c->max_cap, c->max_aux, c->fs + FS_TOTAL);
+    return fused_relabel_launch(c);
+}
+// More maxima than k_number_maxima sorts (XB_SORT_MAX): the bitmap numbering of k_fused.h (k_rank_*), then the same relabel
+// launches, and the sorted list to the host.  `nmax` maxima are noted, every walker has arrived.  Scratch: N / 4 bytes of `stage`
+// (nobody's after an assignment's trace) or an allocation of its own.
+static int number_maxima_big(xb_ctx *c, int nmax) {
+    const long long n_words = (c->N + 31) / 32, n_blocks = (n_words + 1023) / 1024;
+    const size_t need = (size_t)(2 * n_words + n_blocks) * sizeof(int);
+    DevBuf<int> own;
+    int *scratch = (int *)c->stage;
+    if (!c->stage || c->stage_bytes < need) {
+        HIPCHK(own.alloc((size_t)(2 * n_words + n_blocks)));
+        scratch = own.p;
+    }
+    unsigned *bits = reinterpret_cast<unsigned *>(scratch);
+    int *wprefix = scratch + n_words, *bsum = scratch + 2 * n_words;
+    HIPCHK(hipMemsetAsync(bits, 0, (size_t)n_words * sizeof(int), c->stream));
+    k_rank_mark<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, bits);
+    k_rank_scan<<<(unsigned)n_blocks, 1024, 0, c->stream>>>(bits, (int)n_words, wprefix, bsum);
+    k_rank_blocks<<<1, 1024, 0, c->stream>>>(bsum, (int)n_blocks);
+    k_rank_assign<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, bits, wprefix, bsum, c->max_aux, c->fs);
+    HIPCHK(hipGetLastError());
+    if (int rc = fused_relabel_launch(c)) return rc;
+    c->maxima_sorted.resize(nmax);
+    HIPCHK(hipMemcpyAsync(c->maxima_sorted.data(), c->max_aux, (size_t)nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // (the scratch may go afterwards)
+    return XB_OK;
+}
+static int fused_relabel_launch(xb_ctx *c) {
     Grid &g = c->g;
     int *fs = c->fs;
     const GridL gl = light(g);
     const int nb1 = c->nbk[1], nb2 = c->nbk[2], nbr = c->nbk[0] * nb1 * nb2;
     int *walk = c->walk, *box_max = c->box_max_tab, *bres = c->bres_last;
-    k_number_maxima<<<1, 1024, 0, c->stream>>>(fs, c->first, c->max_list, c->max_cap, c->max_aux, fs + FS_TOTAL);
     int *buni = reinterpret_cast<int *>(c->st);
     if (c->regions_pending) {
         if (g.nz % 4 == 0)
@@ -808,7 +837,16 @@ static int assign_neargrid_tail(xb_ctx *c, int64_t *n_maxima) {
             return XB_OK;
         }
     }
-    return finish_numbering_on_host(c, nmax, n_maxima);
+    // more maxima than the LDS sort takes (and every walker in): the bitmap numbering, on the device as well (round 6; the host
+    // used to fetch the table, sort it and send the ranks back: 15 of the 66 ms of a noisy vacuum's step)
+    if (int rc = number_maxima_big(c, nmax)) return rc;
+    c->label_wire = label_wire_for(nmax);
+    c->regions_pending = false;
+    c->buni_valid = !c->has_vacuum;
+    c->regions_labels = !c->has_vacuum;
+    c->first_clean = true;
+    if (n_maxima) *n_maxima = nmax;
+    return XB_OK;
 }
 
 
@@ -928,33 +966,22 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     c->n_walk = h[FS_N_WALK];
     const int nmax = h[FS_N_MAX];
     if (nmax > c->max_cap) return fail(XB_E_LIMIT, "%d maxima exceed the table capacity %d", nmax, c->max_cap);
-    if (h[FS_SORT_OK]) {
-        c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
-        c->label_wire = label_wire_for(nmax);
-        c->regions_pending = false;
-        c->buni_valid = true;
-        c->first_clean = true;
-        if (n_maxima) *n_maxima = nmax;
-        return XB_OK;
+    if (h[FS_SORT_OK]) c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
+    else {   // more maxima than the LDS sort takes: the bitmap numbering + the same relabel launches (round 6)
+        c->bres_last = nullptr;
+        c->regions_pending = true;
+        if (int rc = number_maxima_big(c, nmax)) return rc;
     }
-    return finish_numbering_on_host(c, nmax, n_maxima);   // more maxima than the device sort takes
+    c->label_wire = label_wire_for(nmax);
+    c->regions_pending = false;
+    c->buni_valid = true;
+    c->first_clean = true;
+    if (n_maxima) *n_maxima = nmax;
+    return XB_OK;
 }
 
-// maxima table -> host, sort by first voxel, rank + relabel (the tail of the host-driven path)
+// maxima table -> host, sort by first voxel, rank + relabel (the tail of the host-driven path: slabs, vacuum ongrid, small grids)
 static int sort_and_finish(xb_ctx *c, int64_t n, int64_t *n_maxima);
-static int finish_numbering_on_host(xb_ctx *c, int nmax, int64_t *n_maxima) {
-    c->local_max.resize(nmax);
-    c->local_first.resize(nmax);
-    if (nmax) {
-        k_gather_first<<<(nmax + 255) / 256, 256, 0, c->stream>>>(c->first, c->max_list, nmax, c->max_aux);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->local_max.data(), c->max_list, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(c->local_first.data(), c->max_aux, nmax * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    return sort_and_finish(c, nmax, n_maxima);
-}
-
 int xb_assign(xb_ctx *c, int method, int64_t *n_maxima) {
     NEED_GRID_RAW("xb_assign");
     if (method == XB_METHOD_NEARGRID && fused_ok(c)) {

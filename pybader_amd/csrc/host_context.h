@@ -535,7 +535,7 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
     c->zero_outside[0] = -1;
     HIPCHK(hipMemsetAsync(c->dsum, 0, sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->counters64, 0, sizeof(unsigned long long), c->stream));
-    k_vacuum_assign<<<nblocks(c->N), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, vac_tol, c->dsum, c->counters64);
+    k_vacuum_assign<<<(unsigned)std::min<long long>(nblocks(c->N), 4096), TPB, 0, c->stream>>>(c->g, c->rho, c->labels, vac_tol, c->dsum, c->counters64);
     HIPCHK(hipGetLastError());
     double s;
     unsigned long long n;

@@ -296,3 +296,74 @@ __global__ __launch_bounds__(1024) void k_number_maxima(int *fs, int *first, con
     }
     if (threadIdx.x == 0) fs[FS_SORT_OK] = 1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Numbering of ANY number of maxima on the device (round 6; k_number_maxima sorts up to XB_SORT_MAX of them in LDS, and a
+// density whose noise makes millions -- 1.6 M in the noisy vacuum of bench.py's user leg -- went to the host for a counting
+// sort: fetch the table, sort, send the ranks back, 15 ms).  No sort is needed: the rank of a maximum is the number of maxima
+// whose FIRST voxel (the smallest voxel index that reaches them) is smaller, and first voxels are distinct -- a voxel reaches
+// one maximum.  So: mark the first voxels in a bitmap over the grid, prefix-count the bitmap (a popcount per word, a scan per
+// 1024 words, a scan of the block sums) and every maximum reads its rank off its own bit.  N / 4 bytes of scratch.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_rank_mark(const int *__restrict__ first, const int *__restrict__ max_list, int n, unsigned *bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned v = (unsigned)first[max_list[i]];
+    atomicOr(&bits[v >> 5], 1u << (v & 31));
+}
+// exclusive scan of `x` over the 1024 threads of a workgroup; `total`: the sum
+__device__ __forceinline__ int scan1024_excl(int x, int &total) {
+    __shared__ int wsum[1024 / XB_WAVE];
+    const int lane = threadIdx.x % XB_WAVE, w = threadIdx.x / XB_WAVE;
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < XB_WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == XB_WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int q = 0; q < 1024 / XB_WAVE; q++) {
+        if (q < w) base += wsum[q];
+        total += wsum[q];
+    }
+    __syncthreads();
+    return base + incl - x;
+}
+// per workgroup 1024 words of the bitmap: wprefix[w] = set bits in the words of the block before w, bsum[block] = its set bits
+__global__ __launch_bounds__(1024) void k_rank_scan(const unsigned *__restrict__ bits, int n_words, int *__restrict__ wprefix, int *__restrict__ bsum) {
+    const int w = blockIdx.x * 1024 + threadIdx.x;
+    const int cnt = w < n_words ? __popc(bits[w]) : 0;
+    int total;
+    const int excl = scan1024_excl(cnt, total);
+    if (w < n_words) wprefix[w] = excl;
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+// exclusive scan of the block sums in place (one workgroup, 1024 at a time with a carry)
+__global__ __launch_bounds__(1024) void k_rank_blocks(int *bsum, int n_blocks) {
+    int carry = 0;
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int x = i < n_blocks ? bsum[i] : 0;
+        int total;
+        const int excl = scan1024_excl(x, total);
+        if (i < n_blocks) bsum[i] = carry + excl;
+        carry += total;
+    }
+}
+// first[m] := rank of m; sorted[rank] := m; the numbering is on the device now (FS_SORT_OK: the relabel kernels' gate)
+__global__ void k_rank_assign(int *first, const int *__restrict__ max_list, int n, const unsigned *__restrict__ bits,
+                              const int *__restrict__ wprefix, const int *__restrict__ bsum, int *__restrict__ sorted, int *fs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) fs[FS_SORT_OK] = 1;
+    if (i >= n) return;
+    const int m = max_list[i];
+    const unsigned v = (unsigned)first[m];
+    const unsigned w = v >> 5;
+    const int r = bsum[w >> 10] + wprefix[w] + __popc(bits[w] & ((1u << (v & 31)) - 1u));
+    sorted[r] = m;
+    first[m] = r;
+}
