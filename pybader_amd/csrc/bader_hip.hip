@@ -91,6 +91,8 @@ struct xb_ctx {
     int8_t *ec_pflag = nullptr;             // ... and a flag byte per voxel, set on the processed voxels while their boxes are applied (zero otherwise)
     std::vector<int8_t> esc_complete;
     bool has_vacuum = true;    // false only when volumes_init proved there is no -1 label
+    bool vac_by_tol = false;   // the -1 labels are exactly the voxels with rho <= vac_tol (xb_vacuum_assign wrote them, nobody since)
+    double vac_tol = 0.;
     bool regions_pending = false;  // labels of certain bricks are written by the relabel pass
     bool buni_valid = false;       // per-brick label uniformity (in `st`) matches the resident labels
     bool buni_halo_safe = false;   // ... and marks every brick outside the owned planes that is not of a trapping region as mixed:

@@ -671,8 +671,11 @@ static int assign_neargrid_fused(xb_ctx *c, int64_t *n_maxima) {
             int bits = 0;
             while ((1 << bits) < std::max(std::max(nb0, nb1), nb2)) bits++;
             const unsigned n_codes = 1u << (3 * bits);
+            // (with a vacuum tolerance the bricks that lie below it altogether stay off the list: k_brick_walk_list_morton)
+            const bool vac = c->has_vacuum && c->vac_by_tol;
             k_brick_walk_list_morton<<<(n_codes + 16 * TPB - 1) / (16 * TPB), TPB, 0, c->stream>>>(nb0, nb1, nb2, n_codes, c->blab, walk,
-                                                                                                  fs + FS_N_WALK, fs + FS_GROW_RETRY);
+                                                                                                  fs + FS_N_WALK, fs + FS_GROW_RETRY,
+                                                                                                  vac ? bpot : nullptr, c->vac_tol);
         }
         {   // pass B: records for the bricks of the walk list only
             ScopedTimer t7(c, 7);

@@ -299,6 +299,7 @@ static int staged_d2h(xb_ctx *c, void *dst_host, const void *src_dev, size_t byt
 }
 
 int xb_upload_density(xb_ctx *c, const double *rho_host) {
+    if (c) c->vac_by_tol = false;   // (the -1 labels no longer say "rho <= vac_tol" of the density on the card)
     NEED_GRID("xb_upload_density");
     c->grad_valid = false; c->brick_max_valid = false;
     if (int rc = staged_h2d(c, c->rho, rho_host, c->N * sizeof(double))) return rc;
@@ -332,6 +333,7 @@ static int device_scan(xb_ctx *c, int *data, int n, int *scratch) {
 }
 int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double divisor, int64_t *n_tokens,
                           int64_t *n_host) {
+    if (c) c->vac_by_tol = false;   // (the -1 labels no longer say "rho <= vac_tol" of the density on the card)
     NEED_GRID("xb_parse_density_text");
     const Grid &g = c->g;
     if (!text || nbytes <= 0) return fail(XB_E_ARG, "xb_parse_density_text: empty text");
@@ -410,6 +412,7 @@ int xb_parse_density_text(xb_ctx *c, const char *text, int64_t nbytes, double di
 }
 
 int xb_synth_density(xb_ctx *c, const double lattice[9], const double *atoms5, int64_t n_atoms, double background) {
+    if (c) c->vac_by_tol = false;   // (the -1 labels no longer say "rho <= vac_tol" of the density on the card)
     NEED_GRID("xb_synth_density");
     if (n_atoms < 0 || n_atoms > 4096) return fail(XB_E_ARG, "xb_synth_density: bad atom count");
     c->grad_valid = false; c->brick_max_valid = false;
@@ -430,6 +433,7 @@ int xb_upload_labels(xb_ctx *c, const void *labels_host, int dtype) {
     c->zero_outside[0] = -1;
     c->list_valid = false; c->chg_n = -1;
     c->has_vacuum = true;
+    c->vac_by_tol = false;
     c->buni_valid = false; c->regions_labels = false;
     const size_t sz = dtype_size(dtype);
     if (!sz) return fail(XB_E_ARG, "xb_upload_labels: bad dtype code %d", dtype);
@@ -528,6 +532,7 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
         } else
             c->labels_zero_pending = true;   // (owed for the owned + halo planes; a neargrid assignment on regions writes every owned label itself)
         c->has_vacuum = false;
+        c->vac_by_tol = false;
         if (vac_charge) *vac_charge = 0.;
         if (vac_volume) *vac_volume = 0.;
         return XB_OK;
@@ -543,6 +548,7 @@ int xb_vacuum_assign(xb_ctx *c, double vac_tol, double voxel_volume, double *vac
     HIPCHK(hipMemcpyAsync(&n, c->counters64, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->has_vacuum = true;   // (the count covers the owned slab only: stay conservative)
+    c->vac_by_tol = true; c->vac_tol = vac_tol;
     if (vac_charge) *vac_charge = s * voxel_volume;  // utils.py:400
     if (vac_volume) *vac_volume = (double)n * voxel_volume;
     return XB_OK;
