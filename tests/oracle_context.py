@@ -90,6 +90,10 @@ class OracleContext:
         oracle.refine('neargrid', (mode, int(iters)), self.rho, self.labels, self.dm, self.tg, 1, log=log)
         return [tuple(int(v) for v in row) for row in log]
 
+    def assign_refine(self, method, mode, iters):             # xb_assign_refine: the two calls, one after the other
+        n = self.assign(method)
+        return n, self.refine(mode, iters)
+
     def charge_sum(self, voxel_volume, n_labels):             # xb_charge_sum: per-label sums, charge already times voxel_volume
         ch, vo = np.zeros(n_labels), np.zeros(n_labels)
         oracle.charge_sum(ch, vo, float(voxel_volume), self.rho, self.labels)
