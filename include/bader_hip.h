@@ -291,7 +291,8 @@ int xb_memory_stats(xb_ctx *c, int64_t *bytes_total, int64_t *bytes_table, int64
 /* statistics of the last assignment: trapping boxes found and voxels they cover */
 int xb_box_stats(xb_ctx *c, int64_t *n_boxes, int64_t *box_voxels);
 /* The brick lattice of the last neargrid assignment and, per 8^3 brick (C order over dims), the trapping region it was
- * certified for (> 0) or 0 (its voxels were walked).  dims = ceil(shape / 8): a brick the grid cuts holds the voxels the
+ * certified for (> 0), 0 (its voxels were walked) or INT32_MIN (round 6: with a vacuum tolerance, a brick whose largest
+ * density lies below it -- nothing to assign, no records).  dims = ceil(shape / 8): a brick the grid cuts holds the voxels the
  * grid leaves of it.  A diagnostic of the library's own decomposition (the reference has no counterpart); capacity in ints. */
 int xb_brick_labels(xb_ctx *c, int32_t *out, int64_t capacity, int64_t dims[3]);
 /* trajectories / retraces handed to the exact slow kernel since the context was created */

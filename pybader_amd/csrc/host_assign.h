@@ -57,7 +57,7 @@ static int ensure_grad(xb_ctx *c, bool force, bool boxes, bool main_rule) {
         const int small = (g.nx < 16 || g.ny < 16 || g.nz < 80);
         ScopedTimer t(c, 4);
         int *buni = reinterpret_cast<int *>(c->st);
-        if (!c->buni_valid) k_label_uniform<<<(unsigned)nbr, TPB, 0, c->stream>>>(light(g), c->labels, nb1, nb2, buni, 0, nbr);
+        if (!c->buni_valid) k_label_uniform_list<<<4096, TPB, 0, c->stream>>>(light(g), c->labels, nb1, nb2, nullptr, nbr, nullptr, nullptr, buni, 0, nbr);
         c->buni_valid = true;
         k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
         k_flag_mixed_bricks<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, buni + nbr, c->brick_rec);
@@ -464,7 +464,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
         if (g.x1 - g.x0 == g.nx) {  // one slab: the per-brick label uniformity edge_find wants comes for free
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr);
+            k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr, nullptr, nullptr, nullptr);
             if (c->n_walk)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
                                                                                 c->walk, c->n_walk, nullptr, nullptr, buni);
@@ -476,7 +476,7 @@ int xb_assign_finish(xb_ctx *c, const int64_t *max_idx_sorted, int64_t n_global)
             const int nbr = c->nbk[0] * c->nbk[1] * c->nbk[2];
             int *buni = reinterpret_cast<int *>(c->st);
             k_fill<int><<<(nbr + 4 * TPB - 1) / (4 * TPB), TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr);
+            k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, (c->box_max_tab ? c->box_max_tab : c->boxbuf + BB_REGMAX), c->first, buni, nullptr, nullptr, nullptr, nullptr);
             if (c->n_walk)
                 k_label_uniform_list<<<(c->n_walk + 3) / 4, TPB, 0, c->stream>>>(light(g), c->labels, c->nbk[1], c->nbk[2],
                                                                                 c->walk, c->n_walk, nullptr, nullptr, buni);
@@ -560,7 +560,7 @@ static int fused_relabel_launch(xb_ctx *c) {
                                                                                                      box_max, fs, fs + FS_SORT_OK);
         if (bres) k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, walk, fs + FS_N_WALK, bres);
         else {
-            k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+            k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, nullptr, nullptr, nullptr);
             k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
         }
     } else
@@ -769,7 +769,7 @@ static int assign_neargrid_tail(xb_ctx *c, int64_t *n_maxima) {
         c->maxima_sorted.assign(h + FS_TOTAL, h + FS_TOTAL + nmax);
         c->label_wire = label_wire_for(nmax);
         c->regions_pending = false;
-        c->buni_valid = !c->has_vacuum;   // k_buni_from_regions + k_label_uniform_list ran
+        c->buni_valid = !c->has_vacuum;   // k_buni_after_relabel + k_label_uniform_list ran
         c->regions_labels = !c->has_vacuum;
         c->first_clean = true;
         if (n_maxima) *n_maxima = nmax;
@@ -951,7 +951,7 @@ static int assign_ongrid_fused(xb_ctx *c, int64_t *n_maxima) {
     else
         k_relabel_regions_brick<1><<<dim3((g.nz + 63) / 64, nb1, (g.nx + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, c->first, c->blab, nb1, nb2,
                                                                                                  box_max, fs, fs + FS_SORT_OK);
-    k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+    k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, nullptr, nullptr, nullptr);
     k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
     k_reset_first<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, 0, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());

@@ -40,7 +40,7 @@ static int edge_find_launch(xb_ctx *c, bool *dilate_owned) {
                     b_off = (p0 / 8) * per_plane;
                     count = ((np + 8 + 7 + (p0 % 8)) / 8 + 1) * per_plane;
                 }
-                k_label_uniform<<<(unsigned)count, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, buni, b_off, nbr);
+                k_label_uniform_list<<<(unsigned)std::min(4096, (count + 3) / 4), TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, nullptr, count, nullptr, nullptr, buni, b_off, nbr);
                 c->buni_halo_safe = false;
             }
             k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
@@ -696,7 +696,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
             const int nb0 = (g.nx + 7) / 8, nb1 = (g.ny + 7) / 8, nb2 = (g.nz + 7) / 8, nbr = nb0 * nb1 * nb2;
             buni = reinterpret_cast<int *>(c->st);
             if (!c->buni_valid)
-                k_label_uniform<<<(unsigned)nbr, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, buni, 0, nbr);
+                k_label_uniform_list<<<4096, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, nullptr, nbr, nullptr, nullptr, buni, 0, nbr);
             k_buni3<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nb0, nb1, nb2, buni, buni + nbr);
             buni += nbr;
         }

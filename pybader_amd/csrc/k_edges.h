@@ -47,39 +47,10 @@ __device__ __forceinline__ void classify27(const Grid &g, const double *__restri
 // buni[K] = the label shared by all 512 voxels of brick K, or INT_MIN when the brick is mixed.
 // Lets the edge sweep skip tiles whose whole 3x3x3 surroundings carry one label (no edge possible).
 #define XB_MIXED (-2147483647 - 1)
-// (b_off, nbr: the launch covers the bricks b_off, b_off + 1, ... modulo nbr -- slabs only scan the bricks of their planes)
-__global__ __launch_bounds__(TPB) void k_label_uniform(GridL g, const int *__restrict__ labels, int nb1, int nb2,
-                                                       int *__restrict__ buni, int b_off, int nbr) {
-    __shared__ int s_min, s_max;
-    if (threadIdx.x == 0) { s_min = 2147483647; s_max = XB_MIXED; }
-    __syncthreads();
-    int b = blockIdx.x + b_off;
-    if (b >= nbr) b -= nbr;
-    const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
-    int lo = 2147483647, hi = XB_MIXED;
-    for (int t = threadIdx.x; t < 512; t += TPB) {
-        const int x = b0 * 8 + t / 64, y = b1 * 8 + (t / 8) % 8, z = b2 * 8 + t % 8;
-        if (x < g.nx && y < g.ny && z < g.nz) {   // (a brick the grid cuts: its voxels inside the grid)
-            const int l = labels[(x * g.ny + y) * g.nz + z];
-            lo = min(lo, l); hi = max(hi, l);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    if (threadIdx.x % XB_WAVE == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
-    __syncthreads();
-    if (threadIdx.x == 0) buni[b] = (s_min == s_max) ? s_min : XB_MIXED;
-}
 // After an assignment without vacuum every certain brick is uniform by construction (all its voxels
 // carry the rank of the region's maximum): only the bricks of the walk list need the label scan.
-__global__ void k_buni_from_regions(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
-                                    const int *__restrict__ rank, int *__restrict__ buni, const int *gate) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbr || (gate && !*gate)) return;
-    const int l = blab[b];
-    if (l > 0) buni[b] = rank[box_max[l - 1]];
-}
-// Round 5: the two uniformity launches behind the relabel of the one-GPU assignment in one -- the regions' bricks
-// (k_buni_from_regions) and the walk-list bricks from their walkers' verdicts (k_buni_from_walk).  Element-wise, disjoint bricks.
+// The bricks' label uniformity behind the relabel of an assignment: the regions' bricks (uniform by construction) and -- when
+// the walkers left their verdicts (bres) -- the walk-list bricks.  Element-wise, disjoint bricks.
 __global__ __launch_bounds__(256) void k_buni_after_relabel(int nbr, const int *__restrict__ blab, const int *__restrict__ box_max,
                                                             const int *__restrict__ rank, int *__restrict__ buni, const int *gate,
                                                             const int *__restrict__ walk, const int *n_walk, const int *__restrict__ bres) {
@@ -89,6 +60,7 @@ __global__ __launch_bounds__(256) void k_buni_after_relabel(int nbr, const int *
         const int l = blab[b];
         if (l > 0) buni[b] = rank[box_max[l - 1]];
     }
+    if (!bres) return;   // (no verdicts from the walkers: the caller scans the walk-list bricks' labels, k_label_uniform_list)
     const int n = *n_walk;
     for (int e = t; e < n; e += nt) {
         const int b = walk[e], r = bres[b];
@@ -111,23 +83,26 @@ __global__ void k_buni3(int nb0, int nb1, int nb2, const int *__restrict__ buni,
     }
     buni3[b] = ok ? l : XB_MIXED;
 }
-// one WAVE per listed brick (8 labels per lane), bricks strided over the grid; the list length may live on the
-// device (n_dev) and `gate` (when given) must be non-zero for the kernel to do anything
+// one WAVE per brick (8 labels per lane), bricks strided over the grid.  The bricks: the entries of `walk` (their number may live on
+// the device, n_dev), or -- walk == nullptr -- the n_walk bricks b_off, b_off + 1, ... modulo nbr (a slab scans the bricks of its
+// planes only).  `gate` (when given) must be non-zero for the kernel to do anything.
 __global__ __launch_bounds__(TPB) void k_label_uniform_list(GridL g, const int *__restrict__ labels, int nb1, int nb2,
                                                             const int *__restrict__ walk, int n_walk, const int *n_dev,
-                                                            const int *gate, int *__restrict__ buni) {
+                                                            const int *gate, int *__restrict__ buni, int b_off = 0, int nbr = 0) {
     if (gate && !*gate) return;
     const int n = n_dev ? *n_dev : n_walk;
     const int lane = threadIdx.x % XB_WAVE;
     for (int e = blockIdx.x * (TPB / XB_WAVE) + threadIdx.x / XB_WAVE; e < n; e += gridDim.x * (TPB / XB_WAVE)) {
-        const int b = walk[e];
+        int b;
+        if (walk) b = walk[e];
+        else { b = e + b_off; if (b >= nbr) b -= nbr; }
         const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
         int lo = 2147483647, hi = XB_MIXED;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int t = lane + k * XB_WAVE;
             const int x = b0 * 8 + t / 64, y = b1 * 8 + (t / 8) % 8, z = b2 * 8 + t % 8;
-            if (x < g.nx && y < g.ny && z < g.nz) {
+            if (x < g.nx && y < g.ny && z < g.nz) {   // (a brick the grid cuts: its voxels inside the grid)
                 const int l = labels[(x * g.ny + y) * g.nz + z];
                 lo = min(lo, l); hi = max(hi, l);
             }

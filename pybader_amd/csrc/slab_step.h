@@ -424,7 +424,7 @@ int xb_slab_assign_finish(xb_ctx *c, int64_t *n_maxima, int64_t *status) {
     // per-brick uniformity for the edge sweep: the regions' bricks are uniform on every rank, the owned walk-list bricks are
     // scanned, every other brick counts as mixed -- right whatever the peers' halo planes bring
     k_fill<int><<<(nbr + 4 * TPB - 1) / (4 * TPB), TPB, 0, c->stream>>>(buni, XB_MIXED, nbr);
-    k_buni_from_regions<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK);
+    k_buni_after_relabel<<<(nbr + 255) / 256, 256, 0, c->stream>>>(nbr, c->blab, box_max, c->first, buni, fs + FS_SORT_OK, nullptr, nullptr, nullptr);
     k_label_uniform_list<<<2048, TPB, 0, c->stream>>>(gl, c->labels, nb1, nb2, walk, 0, fs + FS_N_WALK, fs + FS_SORT_OK, buni);
     k_reset_first<<<8, 256, 0, c->stream>>>(c->first, c->max_aux, 0, fs + FS_N_MAX, fs + FS_SORT_OK);
     HIPCHK(hipGetLastError());
