@@ -685,6 +685,7 @@ def test_label_array_stays_on_the_device_inside_resident():
 
 @pytest.mark.parametrize('name,mode,iters', [('c64_cubic', 'changed', 2), ('c40x48x56_tric', 'all', -1), ('c48_cubic_vac', 'changed', 2),
                                               ('r48_sig5', 'changed', -1), ('r40_noise04', 'changed', 2), ('r32_quant8', 'all', -1),
+                                              ('r64_noise04', 'changed', 2),      # 6 141 maxima: the bitmap numbering behind the gated call
                                               ('c12_cubic', 'changed', 2)])
 def test_assign_refine_in_one_call_equals_the_two_calls(ctx, name, mode, iters):
     """xb_assign_refine (round 5: the refinement's first iteration queued behind the assignment, one host wait for both) against
