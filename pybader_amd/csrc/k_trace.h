@@ -306,7 +306,7 @@ __device__ __forceinline__ GradRec fetch_rec_o(const GradRec *__restrict__ G, in
 // (the cache is a file-scope LDS array, not a pointer argument: handed over as a generic pointer it made the gfx950 backend of
 // this ROCm emit `v_cmp_ne_u32 0, src_shared_base` -- "illegal instruction, operand has incorrect register class" -- for
 // some shapes of the surrounding code)
-// The shape of a workgroup of the group trace: XB_TRACE_WAVES waves share out the eight 4x4x4 eighths of ONE brick.  What counts
+// The shape of a workgroup of the group trace: XB_TRACE_WAVES waves share out the eight eighths (brick_sub_voxel) of ONE brick.  What counts
 // is eighths per wave (two: a wave that drew a short one takes another instead of waiting at the barrier) and WAVES PER BARRIER
 // (the slowest of them sets the pace).  Measured at 512^3 (round 5): 8 waves x 1 brick 1.22 ms, 8 x 2 1.175, 16 x 4 1.29, 8 x 3 1.58
 // (48 KB of LDS: three workgroups per compute unit), **4 x 1 1.135**, 4 x 2 1.56, 2 x 1 1.45 (the last two lose occupancy to LDS).
@@ -410,12 +410,14 @@ __device__ __forceinline__ int ng_walk_lean(const GridL &g, const GradRec *__res
     }
     return result;
 }
-// lane -> voxel of the 4x4x4 eighth `sub` of brick b (z fastest: 4 lanes per 128-B table line)
+// lane -> voxel of the eighth `sub` of brick b: 4 x 2 x 8 voxels, z fastest -- a wave's 16 rows of 8 records, two table lines
+// each.  Measured at 512^3 (round 6, k_ng_trace_g): 4x4x4 1.052 ms, 2x4x8 1.035, **4x2x8 1.017**, 1x8x8 1.09, 8x1x8 1.06, 2x8x4 1.10,
+// 4x8x2 1.20, 8x8x1 1.55 (64 lines per gather instead of 16: the lines a gather instruction touches cost, whole rows are cheapest)
 __device__ __forceinline__ void brick_sub_voxel(int b, int sub, int lane, int nb1, int nb2, int &sx, int &sy, int &sz) {
     const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;
     sx = b0 * 8 + ((sub >> 2) << 2) + (lane >> 4);
-    sy = b1 * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
-    sz = b2 * 8 + ((sub & 1) << 2) + (lane & 3);
+    sy = b1 * 8 + ((sub & 3) << 1) + ((lane >> 3) & 1);
+    sz = b2 * 8 + (lane & 7);
 }
 template <int K, bool WIN>
 __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__restrict__ G,
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(TPB) void k_ng_trace(GridL g, const GradRec *__rest
     const int wave = blk * wpb + threadIdx.x / XB_WAVE;
     const int lane = threadIdx.x % XB_WAVE;
     int sx, sy, sz;
-    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (4x4x4 each) per brick
+    if (walk) {     // work list of the 8^3 bricks outside the trapping regions: 8 waves (an eighth each: brick_sub_voxel) per brick
         if ((wave >> 3) >= n_walk) return;
         brick_sub_voxel(walk[wave >> 3], wave & 7, lane, nb1, nb2, sx, sy, sz);
         if (sx < g.x0 || sx >= g.x1) return;  // whole wave: 4 planes of one brick half, slab edges are brick aligned or not owned
@@ -490,7 +492,7 @@ __device__ __forceinline__ int xcc_id() {
 }
 
 // Group form of the persistent trace: a workgroup of XB_TRACE_WAVES waves pulls ONE brick (eight consecutive items) of the Morton
-// ordered walk list and its waves take the brick's eight 4x4x4 eighths one by one from a counter in LDS, so that the eighths --
+// ordered walk list and its waves take the brick's eight eighths (4x2x8 voxels each) one by one from a counter in LDS, so that the eighths --
 // whose walkers converge onto the same voxels within a few steps -- run on ONE compute unit at the same time: their record
 // loads meet in that unit's L1 (hit, or merged with the miss in flight) instead of each occupying a miss slot of a
 // different unit.  The trace is bound by exactly that: L2 requests x L2 latency / misses in flight per compute unit
