@@ -127,18 +127,20 @@ __global__ __launch_bounds__(TPB) void k_og_masks(GT g, const double *__restrict
 // With trapping regions only the voxels of the listed (uncertain) bricks chase their pointers, and only until the chain enters
 // a certain brick or reaches a root.  labels[] holds successor indices on entry; a walker overwrites its own entry with the
 // root it found -- also an ancestor, so a chain that reads it mid-way still ends at the same root.  The list length lives on
-// the device: a fixed grid of one-wave workgroups strides over the 4x4x4 eighths of the listed bricks (lanes beyond the grid,
+// the device: a fixed grid of one-wave workgroups strides over the eighths of the listed bricks (lanes beyond the grid,
 // in a brick the grid cuts, stay idle).
 __global__ __launch_bounds__(XB_WAVE) void k_og_walk_dev(GridL g, const int *__restrict__ box_max, const int *__restrict__ blab,
                                                          int nb1, int nb2, const int *__restrict__ walk, int *fs, int *labels,
                                                          int *first, int *max_list, int max_cap, int maxsteps) {
     if (fs[FS_GROW_RETRY]) return;
     const int n_items = fs[FS_N_WALK] * 8, lane = threadIdx.x;
+    const double inv_nyz = 1.0 / (double)g.nyz, inv_nz = 1.0 / (double)g.nz;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        // (the eighths are 4 x 2 x 8 voxels as in the neargrid trace, brick_sub_voxel: whole rows of 8 pointers)
         const int b = walk[item >> 3], sub = item & 7;
         const int x = (b / (nb1 * nb2)) * 8 + ((sub >> 2) << 2) + (lane >> 4);
-        const int y = ((b / nb2) % nb1) * 8 + (((sub >> 1) & 1) << 2) + ((lane >> 2) & 3);
-        const int z = (b % nb2) * 8 + ((sub & 1) << 2) + (lane & 3);
+        const int y = ((b / nb2) % nb1) * 8 + ((sub & 3) << 1) + ((lane >> 3) & 1);
+        const int z = (b % nb2) * 8 + (lane & 7);
         const bool valid = x < g.nx && y < g.ny && z < g.nz;
         const int v = valid ? (x * g.ny + y) * g.nz + z : 0;
         int cur = v, p = valid ? labels[v] : -1, result = -1;
@@ -146,11 +148,18 @@ __global__ __launch_bounds__(XB_WAVE) void k_og_walk_dev(GridL g, const int *__r
         for (int s = 0; s <= maxsteps && !done; s++) {
             if (p < 0) { done = true; break; }                    // vacuum: the chain inherits -1 (methods.py:166-168)
             if (p == cur) { result = p; done = true; break; }     // a root
-            const int px = p / g.nyz, r = p - px * g.nyz;
-            const int bl = blab[((px >> 3) * nb1 + ((r / g.nz) >> 3)) * nb2 + ((r % g.nz) >> 3)];
+            const int pn = labels[p];   // the next pointer, in flight together with the brick label of p
+            // p -> (px, py, pz): two multiplications by reciprocals and a correction step (exact for every int32 index)
+            int px = (int)((double)p * inv_nyz);
+            int r = (int)((unsigned)p - (unsigned)px * (unsigned)g.nyz);
+            if (r < 0) { px--; r += g.nyz; } else if (r >= g.nyz) { px++; r -= g.nyz; }
+            int py = (int)((double)r * inv_nz);
+            int pz = r - py * g.nz;
+            if (pz < 0) { py--; pz += g.nz; } else if (pz >= g.nz) { py++; pz -= g.nz; }
+            const int bl = blab[((px >> 3) * nb1 + (py >> 3)) * nb2 + (pz >> 3)];
             if (bl > 0) { result = box_max[bl - 1]; done = true; break; }
             cur = p;
-            p = labels[cur];
+            p = pn;
         }
         if (!done) atomicOr(&fs[FS_ERR], 1);  // the pointer field is acyclic: cannot happen, reported loudly if it does
         if (valid) labels[v] = result;
