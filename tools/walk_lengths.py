@@ -106,7 +106,9 @@ def report(name, cost):
 
 
 cubes = B.reshape(n, 2, 4, 2, 4, 2, 4).transpose(0, 1, 3, 5, 2, 4, 6).reshape(n, 8, 64)
-report('4x4x4 eighths (what ships)', cubes.max(2).sum())
+report('4x4x4 eighths (until round 6)', cubes.max(2).sum())
+slabs = B.reshape(n, 2, 4, 4, 2, 8).transpose(0, 1, 3, 2, 4, 5).reshape(n, 8, 64)   # k_trace.h brick_sub_voxel
+report('4x2x8 eighths (what ships)', slabs.max(2).sum())
 srt = -np.sort(-flat, axis=1)
 report('sorted by the true length (bound)', srt[:, ::64].sum())
 px = B.reshape(n, 8, 64).max(2).sum(1)
