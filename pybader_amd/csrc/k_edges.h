@@ -742,8 +742,13 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     static_assert(!RESUME || (RHO && K == 2), "walkers are carried on by the from-rho kernel");
     const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
     int n_ch = 0, n_es = 0;
-  for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {   // uniform per block (any block size up to TPB)
-    const int t = base + threadIdx.x;
+  // Workgroups go to the eight XCDs in turn and the list is in tile order: XCD k retraces the k-th contiguous eighth of the list, so
+  // that neighbouring edge voxels -- whose retraces read the same records -- meet in ONE L2 (as in k_edge_flag_listed)
+  const int n_chunks = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int n_xcd = (gridDim.x % 8 == 0) ? 8 : 1, per_xcd = (n_chunks + n_xcd - 1) / n_xcd;
+  const int chunk_end = min(n_chunks, ((int)(blockIdx.x % n_xcd) + 1) * per_xcd);
+  for (int chunk = (int)(blockIdx.x % n_xcd) * per_xcd + (int)(blockIdx.x / n_xcd); chunk < chunk_end; chunk += gridDim.x / n_xcd) {   // uniform per block (any block size up to TPB)
+    const int t = chunk * (int)blockDim.x + threadIdx.x;
     bool valid = t < n;
     int v = (valid && !RESUME) ? list[t] : 0;
     bool moving = false;
