@@ -53,6 +53,21 @@ struct GridL {
 #define XB_INT_MAX 0x7fffffff
 #define XB_WAVE 64
 
+// A work list dealt out by XCD: workgroups go to the eight XCDs in turn (blockIdx.x % 8), each XCD has an L2 of its own, and the
+// lists of this library are in spatial order (tiles, Morton bricks) -- so XCD k takes the k-th contiguous part of the list and
+// neighbours, which read the same lines, meet in ONE L2.  The chunks [0, n_chunks) of a list: this workgroup takes
+// begin, begin + step, ... below end (`whole`: parts are multiples of it).  A grid that is not a multiple of 8 deals in turn.
+struct XcdRange { int begin, end, step; };
+__device__ __forceinline__ XcdRange xcd_range(int n_chunks, int whole = 1) {
+    const int n_xcd = (gridDim.x % 8 == 0) ? 8 : 1, k = (int)(blockIdx.x % n_xcd);
+    int per = (n_chunks + n_xcd - 1) / n_xcd;
+    per = (per + whole - 1) / whole * whole;
+    XcdRange r;
+    r.begin = k * per + (int)(blockIdx.x / n_xcd);
+    r.end = min(n_chunks, (k + 1) * per);
+    r.step = (int)(gridDim.x / n_xcd);
+    return r;
+}
 __device__ __forceinline__ int wrapi(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
 __device__ __forceinline__ int lin3(const Grid &g, int x, int y, int z) { return (x * g.ny + y) * g.nz + z; }
 template <typename GT>

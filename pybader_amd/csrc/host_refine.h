@@ -476,7 +476,7 @@ static int edge_check_resolve(xb_ctx *c, int n, const int8_t *cls, int near_xa, 
         HIPCHK(hipMemsetAsync(c->counters + 6, 0, 2 * sizeof(int), c->stream));
         HIPCHK(hipMemsetAsync(c->counters + 24, 0, 4 * sizeof(int), c->stream));
         if (cls) k_ec_init_cls<<<nblocks(n), TPB, 0, c->stream>>>(g, c->known, c->list, n, cls, pend_w);
-        else k_ec_init<<<nblocks(n), TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, pend_w);
+        else k_ec_init<<<(nblocks(n) + 7) & ~7u, TPB, 0, c->stream>>>(g, c->rho, c->labels, c->known, c->list, n, pend_w);
         k_ec_first<<<(unsigned)std::min<long long>(nblocks(n), 4096), TPB, 0, c->stream>>>(g, c->known, pend_w, c->list, n, buf[0],
                                                                                          c->counters + 6, cap);
         HIPCHK(hipGetLastError());

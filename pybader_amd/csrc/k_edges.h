@@ -742,12 +742,9 @@ __global__ __launch_bounds__(TPB) void k_refine_trace(GridL g, const GradRec *__
     static_assert(!RESUME || (RHO && K == 2), "walkers are carried on by the from-rho kernel");
     const int n = n_dev ? *n_dev : n_host;   // the list length may live on the device: the grid strides over it
     int n_ch = 0, n_es = 0;
-  // Workgroups go to the eight XCDs in turn and the list is in tile order: XCD k retraces the k-th contiguous eighth of the list, so
-  // that neighbouring edge voxels -- whose retraces read the same records -- meet in ONE L2 (as in k_edge_flag_listed)
-  const int n_chunks = (n + (int)blockDim.x - 1) / (int)blockDim.x;
-  const int n_xcd = (gridDim.x % 8 == 0) ? 8 : 1, per_xcd = (n_chunks + n_xcd - 1) / n_xcd;
-  const int chunk_end = min(n_chunks, ((int)(blockIdx.x % n_xcd) + 1) * per_xcd);
-  for (int chunk = (int)(blockIdx.x % n_xcd) * per_xcd + (int)(blockIdx.x / n_xcd); chunk < chunk_end; chunk += gridDim.x / n_xcd) {   // uniform per block (any block size up to TPB)
+  // (XCD k retraces the k-th contiguous eighth of the list, which is in tile order: xcd_range)
+  const XcdRange xr = xcd_range((n + (int)blockDim.x - 1) / (int)blockDim.x);
+  for (int chunk = xr.begin; chunk < xr.end; chunk += xr.step) {   // uniform per block (any block size up to TPB)
     const int t = chunk * (int)blockDim.x + threadIdx.x;
     bool valid = t < n;
     int v = (valid && !RESUME) ? list[t] : 0;
@@ -1013,8 +1010,9 @@ __device__ __forceinline__ int ec_box_voxel(const Grid &g, const int rows[9], in
 __global__ __launch_bounds__(TPB) void k_ec_init(Grid g, const double *__restrict__ rho, const int *__restrict__ labels,
                                                  const int8_t *__restrict__ known, const int *__restrict__ list, int n,
                                                  ec_word *pend) {
-    const int t = blockIdx.x * TPB + threadIdx.x;
-    if (t >= n) return;
+    const XcdRange xr = xcd_range((n + TPB - 1) / TPB);   // (a grid of one workgroup per chunk: each takes one)
+    const int t = xr.begin * TPB + threadIdx.x;
+    if (xr.begin >= xr.end || t >= n) return;
     const int v = list[t];
     const int x = v / g.nyz;
     const int r = v - x * g.nyz;
@@ -1243,7 +1241,9 @@ __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, 
 // their word again).
 __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word *pend, const int *__restrict__ in,
                                                   int n, int *out, int *n_out, int out_cap) {
-    for (int e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB)
+    const XcdRange xr = xcd_range((n + TPB - 1) / TPB);
+    for (int chunk = xr.begin; chunk < xr.end; chunk += xr.step)
+      if (const int e = chunk * TPB + (int)threadIdx.x; e < n)
         ec_resolve<true>(g, known, pend, (ec_word)(unsigned int)in[e], [&](ec_word u) {
             const int at = atomicAdd(n_out, 1);
             if (at < out_cap) out[at] = (int)(u & EC_E_VOXEL);
@@ -1502,8 +1502,9 @@ __global__ __launch_bounds__(TPB) void k_ec_apply(Grid g, const double *__restri
     app.init(s_buf, s_n, new_edges, n_new, new_cap);
     unsigned int nchk = 0;
     const long long pairs = 27LL * *n_proc;
-    for (long long base = (long long)blockIdx.x * TPB; base < pairs; base += (long long)gridDim.x * TPB) {   // (uniform per block)
-        const long long p = base + threadIdx.x;
+    const XcdRange xr = xcd_range((int)((pairs + TPB - 1) / TPB));   // (the list is in C order: neighbours' boxes overlap)
+    for (int chunk = xr.begin; chunk < xr.end; chunk += xr.step) {   // (uniform per block)
+        const long long p = (long long)chunk * TPB + threadIdx.x;
         const int t = (int)(p / 27), j = (int)(p - 27LL * t);
         const bool act = p < pairs;
         int new_edge = -1;

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(TPB, 4) void k_brick_records(GT g, const double *__
         goff[j] = (ex * g.ny + ey) * g.nz + ez;
         loff[j] = (ex * 10 + ey) * BR_ROW + ez;
     }
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+    const XcdRange xr = xcd_range(n);   // (neighbouring bricks -- their haloed tiles overlap -- are staged through one L2)
+    for (int item = xr.begin; item < xr.end; item += xr.step) {
         const int b = walk ? walk[item] : item;
         if (!walk && !(brick_rec[b] & 1)) continue;   // uniform per block
         const int b0 = b / (nb1 * nb2), b1 = (b / nb2) % nb1, b2 = b % nb2;

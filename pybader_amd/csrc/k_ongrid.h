@@ -135,7 +135,8 @@ __global__ __launch_bounds__(XB_WAVE) void k_og_walk_dev(GridL g, const int *__r
     if (fs[FS_GROW_RETRY]) return;
     const int n_items = fs[FS_N_WALK] * 8, lane = threadIdx.x;
     const double inv_nyz = 1.0 / (double)g.nyz, inv_nz = 1.0 / (double)g.nz;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const XcdRange xr = xcd_range(n_items, 8);   // (whole bricks per XCD: the eighths of a brick and its neighbours read the same pointers)
+    for (int item = xr.begin; item < xr.end; item += xr.step) {
         // (the eighths are 4 x 2 x 8 voxels as in the neargrid trace, brick_sub_voxel: whole rows of 8 pointers)
         const int b = walk[item >> 3], sub = item & 7;
         const int x = (b / (nb1 * nb2)) * 8 + ((sub >> 2) << 2) + (lane >> 4);
