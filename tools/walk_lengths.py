@@ -140,3 +140,45 @@ for cap in (4, 6, 8, 12, 16):
 m = cubes.max(2).ravel()
 print(f'eighth maxima: mean {m.mean():.1f}, p50 {np.median(m):.0f}, p90 {np.percentile(m, 90):.0f}, p99 {np.percentile(m, 99):.0f}, max {m.max()}')
 np.save(os.path.join(ROOT, 'gpurun_out', f'walk_lengths_{size}.npy'), flat.astype(np.int8)[:4096])
+
+# The tail of the persistent trace: 2 048 workgroups take the bricks of their XCD's eighth of the Morton-ordered list as they come;
+# a brick costs about (the maxima of its eight eighths, four waves at a time) wave-steps.  How long is the tail, and would a
+# "heavy bricks first" order shorten it?  The predictor a list kernel could afford: how many of a brick's 26 neighbours are walk
+# bricks themselves (a walk ends on entering a certified brick).
+import heapq
+Bg = steps.reshape(nb, 8, nb, 8, nb, 8).transpose(0, 2, 4, 1, 3, 5)
+Wm = Bg.reshape(nb, nb, nb, 512).max(3) > 0
+e8 = Bg.reshape(nb, nb, nb, 2, 4, 4, 2, 8).transpose(0, 1, 2, 3, 5, 4, 6, 7).reshape(nb, nb, nb, 8, 64).max(4).astype(np.int64)
+cost = np.sort(e8, axis=3)[..., ::-1]
+cost = cost[..., 0] + cost[..., 4]          # four waves: the slowest of the first four eighths + the slowest of the rest (roughly)
+nbrs = sum(np.roll(Wm, (a, b, c), (0, 1, 2)) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)).astype(np.int64) - Wm
+cw, nw = cost[Wm], nbrs[Wm]
+print(f'brick cost (wave-steps): mean {cw.mean():.1f}, p90 {np.percentile(cw, 90):.0f}, p99 {np.percentile(cw, 99):.0f}, max {cw.max()}; '
+      f'correlation with the number of walk-brick neighbours {np.corrcoef(cw, nw)[0, 1]:.2f}')
+
+
+def morton(ix, iy, iz):
+    m = np.zeros_like(ix)
+    for b in range(8):
+        m |= ((ix >> b) & 1) << (3 * b + 2) | ((iy >> b) & 1) << (3 * b + 1) | ((iz >> b) & 1) << (3 * b)
+    return m
+
+
+ix, iy, iz = np.nonzero(Wm)
+order = np.argsort(morton(ix, iy, iz), kind='stable')
+c_m, n_m = cost[ix, iy, iz][order], nbrs[ix, iy, iz][order]
+
+
+def makespan(c, workers):
+    h = [0] * workers
+    for x in c:
+        heapq.heapreplace(h, h[0] + int(x))
+    return max(h), sum(h) / workers
+
+
+for name, seq in (('Morton order (what ships)', c_m),
+                  ('heavy first by the neighbour count (>= 20), Morton within', np.concatenate([c_m[n_m >= 20], c_m[n_m < 20]])),
+                  ('heavy first by the true cost (bound)', -np.sort(-c_m))):
+    per = (len(seq) + 7) // 8
+    spans = [makespan(seq[k * per:(k + 1) * per] if 'bound' not in name and 'heavy first by the n' not in name else seq[k::8], 256) for k in range(8)]
+    print(f'  {name:62s} makespan {max(s[0] for s in spans)} wave-steps, mean load {np.mean([s[1] for s in spans]):.0f}')
