@@ -148,9 +148,7 @@ static int read_counter(xb_ctx *c, int idx, int *out) {
     return XB_OK;
 }
 
-#ifndef XB_MID_K
 #define XB_MID_K 32   // voxels of the exact path window of the middle tier (k_ng_trace_list / k_refine_trace over the lean kernels' undecided walkers)
-#endif
 // The exact slow kernel over ovf_list[0..n): whole path in scratch, membership by scanning it (methods.py:411 / refinement.py:200).
 // Round 5: in TIERS -- tier 1 gives every walker 64 path voxels (interleaved storage, up to 2 M walkers per launch), the ones whose
 // path is longer are listed and go on to 2048, then 32768 voxels.  A density with a noisy vacuum hands MILLIONS of walkers over

@@ -751,9 +751,7 @@ static int refine_iteration_fused(xb_ctx *c, int64_t *edges, int64_t *changed, b
         ScopedTimer t(c, 3);
         int *defer = (int *)c->stage;
         WalkerIO wl{};   // (no walkers on one GPU)
-#ifndef XB_RT_BLOCK
-#define XB_RT_BLOCK 128   // (threads per workgroup of the retrace kernel: 64 / 128 / 256 measured 0.538 / 0.501 / 0.517 ms on the whole list)
-#endif
+        constexpr int XB_RT_BLOCK = 128;   // (threads per workgroup of the retrace kernel: 64 / 128 / 256 measured 0.512 / 0.495 / 0.514 ms on the whole list)
         k_refine_trace<2, false><<<(unsigned)((c->N / 16 + XB_RT_BLOCK - 1) / XB_RT_BLOCK), XB_RT_BLOCK, 0, c->stream>>>(gl, c->grad, c->labels, c->known, c->list, 0, fs + FS_N_EDGES,
                                                               fs + FS_CHANGED, fs + FS_ESCAPED, c->ovf_list, fs + FS_R_OVF,
                                                               c->ovf_cap, maxsteps, c->rho, c->dist_dev, brec, defer, fs + FS_R_DEFER,

@@ -150,15 +150,9 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_list(GridL g, int8_t *known
 // neighbourhoods, and the block appends its owned edge voxels to the edge list with ONE atomic
 // (the list length is the edge count edge_find returns).  rho is only read for the few voxels
 // that have a foreign neighbour (the is_max test, refinement.py:374-375).
-#ifndef EDGE_P2_NEW
-#define EDGE_P2_NEW 1
-#endif
 #define ET_X 4
 #define ET_Y 8
 #define ET_Z 64
-#ifndef XB_EF_XCD
-#define XB_EF_XCD 1   // the sweeps over listed tiles: an eighth of the list per XCD (k_edge_flag_listed); 0: tiles dealt out in turn (A/B)
-#endif
 // one tile at (tx0 planes from xa, y0, z0); `buni` null: no uniformity shortcut (the caller knows the tile is mixed)
 __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restrict__ rho, const int *__restrict__ labels,
                                           int8_t *__restrict__ known, int xa, int nplanes, int *__restrict__ list,
@@ -317,7 +311,6 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
             }
         }
     }
-#if EDGE_P2_NEW
     // pass 2: refinement.py:374-383, an edge unless it is a 26-neighbour maximum.  Round 4: the brick byte comes from LDS, and
     // the table keys the candidates need are gathered TOGETHER (one 8-byte load per candidate, all in flight) -- round 3 walked
     // the candidates one by one, a brick byte and then a record per candidate: up to eight times two dependent loads per
@@ -384,51 +377,6 @@ __device__ __forceinline__ void edge_tile(const GridL &g, const double *__restri
         }
         if (!is_max) edges |= 1u << k;
     }
-#else
-    // pass 2 (a loop, not unrolled: it runs for the edge candidates only and its loads must not cost registers for
-    // all 8 voxels at once): refinement.py:374-383, an edge unless it is a 26-neighbour maximum
-    unsigned edges = 0;
-#pragma unroll 1
-    for (unsigned m = cand; m; m &= m - 1) {
-        const int k = __ffs(m) - 1;
-        const int tx = k >> 1, ty = tyb + ((k & 1) << 2);
-        int x = xa + tx0 + tx;
-        if (x >= g.nx) x -= g.nx;
-        const int y = y0 + ty, z = z0 + tz;
-        const int v = (x * g.ny + y) * g.nz + z;
-        bool is_max = true, decided = false;
-        const int binfo = brick_rec ? brick_rec[((x >> 3) * ((g.ny + 7) >> 3) + (y >> 3)) * ((g.nz + 7) >> 3) + (z >> 3)] : 1;
-        if (brick_rec && no_vacuum && !(binfo & 2)) {
-            // no voxel of this brick is a 26-neighbour maximum: each has a strictly denser neighbour
-            // (weighted > rho(v) implies rho(n) > rho(v)), and without vacuum no neighbour is skipped
-            is_max = false;
-            decided = true;
-        } else if (G && plane_in_window(g, x) && (binfo & 1)) {  // (slabs: a window of planes; sparse table: flagged bricks)
-            // the table knows the best distance-weighted neighbour of v; if there is one (and it is not vacuum) that
-            // neighbour is denser than v: not a maximum.  (weighted > rho(v) implies rho(n) > rho(v); the converse can
-            // fail by rounding, so "no such neighbour" still takes the full test)
-            const int og = key_og(G[rec_slot(g, v)].key);
-            if (og != XB_OG_SELF && tile[tx + og / 9][ty + (og / 3) % 3][tz + og % 3] != -1) {
-                is_max = false;
-                decided = true;
-            }
-        }
-        if (!decided) {
-            const double c = rho[v];
-            for (int dx = -1; dx < 2; dx++) {
-                const int X = wrapi(x + dx, g.nx);
-                for (int dy = -1; dy < 2; dy++) {
-                    const int Y = wrapi(y + dy, g.ny);
-                    for (int dz = -1; dz < 2; dz++) {
-                        const int Z = wrapi(z + dz, g.nz);
-                        if (tile[tx + 1 + dx][ty + 1 + dy][tz + 1 + dz] != -1 && rho[(X * g.ny + Y) * g.nz + Z] > c) is_max = false;
-                    }
-                }
-            }
-        }
-        if (!is_max) edges |= 1u << k;
-    }
-#endif
     // pass 3: the flags, and the owned edge voxels for the list
     int vidx[8];
     int cnt = 0;
@@ -474,7 +422,7 @@ __global__ __launch_bounds__(TPB) void k_edge_dilate_tiles(GridL g, int8_t *know
     __shared__ __attribute__((aligned(16))) int8_t s[(ET_X + 2) * (ET_Y + 2) * ROW];
     static_assert(ET_X * ET_Y * (ET_Z / 8) == TPB && (ET_X + 2) * (ET_Y + 2) * 4 <= TPB, "one 8-voxel chunk per thread");
     const int ntz = g.nz / ET_Z, nty = (g.ny + ET_Y - 1) / ET_Y, n = *n_tiles;
-    const int n_xcd = (XB_EF_XCD && gridDim.x % 8 == 0) ? 8 : 1;   // (an eighth of the list per XCD, as in k_edge_flag_listed)
+    const int n_xcd = (gridDim.x % 8 == 0) ? 8 : 1;   // (an eighth of the list per XCD, as in k_edge_flag_listed)
     const int part = (n + n_xcd - 1) / n_xcd, part0 = (int)(blockIdx.x % n_xcd) * part, part1 = min(n, part0 + part);
   for (int item = part0 + blockIdx.x / n_xcd; item < part1; item += gridDim.x / n_xcd) {   // (uniform per block)
     const int t = (int)((unsigned)tiles[item] & 0x7fffffffu);
@@ -576,7 +524,7 @@ __global__ __launch_bounds__(TPB) void k_edge_flag_listed(GridL g, const double 
     // XCD k sweeps the k-th contiguous eighth of the list, so that the tiles whose halos overlap -- neighbours in z, y and x -- are
     // staged through ONE L2 at about the same time (round 4 dealt consecutive tiles to different XCDs: 83 % of the sweep's L2
     // requests missed, every halo line came from HBM once per XCD that touched it).
-    const int n_xcd = (XB_EF_XCD && gridDim.x % 8 == 0) ? 8 : 1;
+    const int n_xcd = (gridDim.x % 8 == 0) ? 8 : 1;
     const int part = (n + n_xcd - 1) / n_xcd, part0 = (int)(blockIdx.x % n_xcd) * part, part1 = min(n, part0 + part);
 #pragma unroll 1
     for (int item = part0 + blockIdx.x / n_xcd; item < part1; item += gridDim.x / n_xcd) {
@@ -1183,12 +1131,8 @@ __device__ __forceinline__ void ec_resolve(const Grid &g, int8_t *known, ec_word
 // notifications of a voxel (decode with two integer divisions, nine row bases, ten address computations, ten wake tests, the
 // pushes) were ~700 instructions, 1.3 of the 3.0 us per hop; a device-scope atomic with its result takes 0.4-0.7 us on this
 // card and a pair of barriers 0.08 (tools/ubench_rtt.hip).  Sixteen lanes cut the chain to ~100 instructions.
-#ifndef EC_LANES
 #define EC_LANES 8
-#endif
-#ifndef EC_LONG_N
 #define EC_LONG_N 128   // a queue longer than this takes the lane-per-entry form (measured: 64 / 96 / 128 / 256 / 512 entries)
-#endif
 template <typename Push>
 __device__ __forceinline__ void ec_resolve_lanes(const Grid &g, double inv_nyz, double inv_nz, int8_t *known, ec_word *pend, ec_word entry,
                                                  int sub, Push push) {
@@ -1277,10 +1221,8 @@ __global__ __launch_bounds__(TPB) void k_ec_first(Grid g, int8_t *known, ec_word
 // capacity -- a full mailbox or a closed one -- simply keeps the entries.  So every entry is resolved by somebody, whatever the
 // order of events.  WHEN to close is only a matter of speed: `active` (a hint: the workgroups that have started and have work)
 // is zero, or EC_LINGER idle rounds have passed -- helpers should be around while fronts are being carried.
-#ifndef EC_SHARE_KEEP
 #define EC_SHARE_KEEP 32
-#endif
-#ifndef EC_MB_CAP
+#ifndef EC_MB_CAP   // (EC_MB_CAP and EC_LINGER: the only two build-time values -- a TEST builds the library with a tiny mailbox, see below)
 #define EC_MB_CAP 8192            // slots of a workgroup's mailbox (64-bit entries; single use per launch)
 #endif
 #define EC_MB_CLOSED (1 << 30)    // a tail at or beyond this: the mailbox takes no more entries
