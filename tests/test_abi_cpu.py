@@ -158,3 +158,28 @@ def test_pinned_pool_is_capped_and_falls_back(monkeypatch):
     fail['on'] = True
     d = _lib.pinned_empty((3 << 20,), np.int8)           # no page-locked memory to be had: a pageable array, not an error
     assert isinstance(d, np.ndarray) and d.shape == (3 << 20,) and not _lib.pool_owned(d)
+
+
+def test_xcd_range_hands_out_every_chunk_exactly_once():
+    """The dealing of work lists to XCDs (csrc/bader_kernels.h xcd_range), restated: whatever the list length, the grid and the
+    granularity, every chunk is taken by exactly one workgroup, and with a grid that is a multiple of 8 the chunks a workgroup
+    takes lie in the contiguous part of its XCD (blockIdx % 8)."""
+    def xcd_range(n_chunks, grid, block, whole=1):
+        n_xcd = 8 if grid % 8 == 0 else 1
+        k = block % n_xcd
+        per = -(-n_chunks // n_xcd)
+        per = -(-per // whole) * whole
+        return k * per + block // n_xcd, min(n_chunks, (k + 1) * per), grid // n_xcd, k, per
+
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        n_chunks = int(rng.integers(0, 5000))
+        grid = int(rng.choice([1, 3, 8, 16, 40, 512, 4096, int(rng.integers(1, 700))]))
+        whole = int(rng.choice([1, 8]))
+        taken = np.zeros(n_chunks, np.int32)
+        for b in range(grid):
+            begin, end, step, k, per = xcd_range(n_chunks, grid, b, whole)
+            for c in range(begin, end, step):
+                assert k * per <= c < (k + 1) * per
+                taken[c] += 1
+        assert (taken == 1).all(), (n_chunks, grid, whole)
